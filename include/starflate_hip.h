@@ -1,0 +1,107 @@
+/*
+ * starflate_hip.h -- C-ABI of the MI355X DEFLATE compressor (libstarflate_hip.so).
+ *
+ * The reference (garymm/starflate) has no FFI/plugin interface and no
+ * compressor (README.md:5-7).  The boundary kept here is the shape of its one
+ * public function,
+ *     starflate::decompress(span<const byte> src, span<byte> dst) -> DecompressStatus
+ *     (/root/reference/src/decompress.hpp:63-71):
+ * caller-owned buffers in, callee never allocates output, no exceptions, a small
+ * integer status out.  sfh_compress* produce raw RFC 1951 streams (no zlib/gzip
+ * wrapper, as /root/reference/tools/deflate_compress.py:8-13 does for the
+ * reference's fixtures) that the reference's decompress() inverts.
+ * The C++23 wrapper starflate::compress() (include/starflate/compress.hpp) is the
+ * only intended caller besides tests and bench.py (ctypes).
+ *
+ * Threading: a ctx is not thread-safe; distinct ctxs are independent.  A ctx owns
+ * its device scratch; all other buffers are caller-owned.
+ */
+#ifndef STARFLATE_HIP_H
+#define STARFLATE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sfh_ctx sfh_ctx;
+
+/* negative return values of every sfh_* function returning int */
+enum sfh_status {
+  SFH_OK = 0,
+  SFH_E_INVALID_ARG = -1,   /* null pointer, bad option value, misaligned device pointer */
+  SFH_E_DST_TOO_SMALL = -2, /* cap < sfh_compress_bound(n) -- mirrors DecompressStatus::DstTooSmall */
+  SFH_E_NO_DEVICE = -3,     /* no HIP device / device index out of range */
+  SFH_E_HIP = -4,           /* a HIP runtime call failed; see sfh_last_error() */
+  SFH_E_NOMEM = -5          /* device scratch allocation failed */
+};
+
+/* block strategy (inverse of src/decompress.cpp:416-458 dispatch) */
+enum sfh_strategy {
+  SFH_AUTO = 0,   /* per chunk: smallest of stored / fixed / dynamic */
+  SFH_STORED = 1, /* BTYPE 00 only  (src/decompress.cpp:416-436) */
+  SFH_FIXED = 2,  /* BTYPE 01 only  (src/decompress.cpp:437-446) */
+  SFH_DYNAMIC = 3 /* BTYPE 10 only  (src/decompress.cpp:447-458) */
+};
+
+typedef struct sfh_options {
+  uint32_t strategy;     /* enum sfh_strategy */
+  uint32_t final_stream; /* 1: last block carries BFINAL (src/decompress.cpp:410-415);
+                            0: stream ends byte-aligned and non-final (a GPU shard
+                            that is not the last one) */
+  uint32_t lazy;         /* 1: one-step lazy match deferral */
+  uint32_t reserved[5];  /* must be 0 */
+} sfh_options;
+
+/* fills *o with defaults: AUTO, final_stream=1, lazy=1 */
+void sfh_default_options(sfh_options* o);
+
+int sfh_device_count(void);
+int sfh_create(sfh_ctx** out, int device);
+void sfh_destroy(sfh_ctx* ctx);
+const char* sfh_last_error(const sfh_ctx* ctx);
+
+/* worst-case output bytes for n input bytes (any strategy) */
+size_t sfh_compress_bound(size_t n);
+
+/* Host buffers: H2D copy, compress, D2H copy, synchronous.  *out_n = stream bytes. */
+int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap, size_t* out_n,
+                 const sfh_options* opt);
+
+/* Device buffers (d_src 16-byte aligned), enqueued on `stream` (a hipStream_t,
+ * NULL = the ctx's own stream); synchronises the stream and returns the size. */
+int sfh_compress_device(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap,
+                        size_t* out_n, const sfh_options* opt, void* stream);
+
+/* Same, but only enqueues: no host synchronisation.  The stream size is left in
+ * device memory at *d_out_n (uint64_t, device pointer, may not be NULL). */
+int sfh_compress_device_async(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap,
+                              uint64_t* d_out_n, const sfh_options* opt, void* stream);
+
+/* ---- measurement hooks (bench.py, tests) ---- */
+
+#define SFH_NSTAGES 4 /* 0 lz77 match+parse, 1 code plan, 2 offset scan, 3 emit */
+
+/* on != 0: bracket every kernel launch with HIP events on the launch stream */
+void sfh_set_profiling(sfh_ctx* ctx, int on);
+/* after the stream has been synchronised: milliseconds per stage of the last call */
+int sfh_last_stage_ms(sfh_ctx* ctx, float ms[SFH_NSTAGES]);
+const char* sfh_stage_name(int stage);
+
+/* ---- stage inspection for parity tests: copies device scratch of the last call ---- */
+enum sfh_debug_what {
+  SFH_DBG_NTOK = 0,   /* uint32 per chunk */
+  SFH_DBG_TOKENS = 1, /* uint32[32768] per chunk, first ntok valid */
+  SFH_DBG_HIST = 2,   /* uint32[320] per chunk: ll[0..285], d at [288..317] */
+  SFH_DBG_PLAN = 3,   /* uint32[4] per chunk: btype, out_bytes, header_bits, body_bits */
+  SFH_DBG_LENS = 4,   /* uint8[320] per chunk: ll lens [0..287], d lens [288..319] */
+  SFH_DBG_OFFSETS = 5 /* uint64 per chunk */
+};
+int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,800 @@
+/*
+ * sf_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY (see sf_oracle.h).
+ *
+ * Part 1 restates /root/reference/src/decompress.cpp (file:line cited per
+ * function).  Part 2 is the scalar specification of the block-parallel DEFLATE
+ * encoder implemented by starflate_amd/csrc/ (no reference counterpart).
+ */
+#include "sf_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ====================================================================== */
+/* Part 1: decoder restatement                                            */
+/* ====================================================================== */
+
+/* huffman/src/bit_span.hpp:18-183: LSB-first bit view; stream bit i is
+ * (byte[i/8] >> (i%8)) & 1  (bit_span.hpp:46-53). */
+typedef struct {
+  const uint8_t* p;
+  size_t nbits; /* total bits in the span */
+  size_t pos;   /* bits consumed */
+} bitr;
+
+static inline unsigned br_bit(const bitr* b, size_t i) { return (b->p[i >> 3] >> (i & 7)) & 1u; }
+static inline size_t br_left(const bitr* b) { return b->nbits - b->pos; }
+
+/* src/decompress.cpp:94-114 pop_bits<T>: n bits, LSB-first.  The reference
+ * asserts "bits contains at least n bits"; here that case returns -1. */
+static int pop_bits(bitr* b, unsigned n, unsigned* out) {
+  if (br_left(b) < n) return -1;
+  unsigned r = 0;
+  for (unsigned i = 0; i < n; i++) r |= br_bit(b, b->pos + i) << i;
+  b->pos += n;
+  *out = r;
+  return 0;
+}
+
+/* A canonical table in the shape huffman::table has after canonicalize()
+ * (huffman/src/table.hpp:177-216): entries sorted by (bitsize, symbol), codes
+ * consecutive within a bitsize, `base_code <<= delta` on a bitsize change.
+ * table::find (table.hpp:426-452) walks bitsize groups using `skip` = group size;
+ * first[len] / count[len] / index[len] are that walk, tabulated. */
+#define MAXLEN 32
+typedef struct {
+  uint32_t count[MAXLEN + 1];
+  uint64_t first[MAXLEN + 1];
+  uint32_t index[MAXLEN + 1];
+  uint16_t syms[320];
+  uint64_t code[320]; /* by sorted index */
+  uint32_t n;         /* entries */
+  uint32_t maxlen;
+} ctab;
+
+static void ctab_build(ctab* t, const uint8_t* bitsize, uint32_t nsyms) {
+  memset(t, 0, sizeof *t);
+  for (uint32_t s = 0; s < nsyms; s++)
+    if (bitsize[s]) {
+      t->count[bitsize[s]]++;
+      if (bitsize[s] > t->maxlen) t->maxlen = bitsize[s];
+    }
+  uint32_t idx = 0;
+  for (uint32_t l = 1; l <= MAXLEN; l++) {
+    t->index[l] = idx;
+    idx += t->count[l];
+  }
+  t->n = idx;
+  uint32_t fill[MAXLEN + 1];
+  memcpy(fill, t->index, sizeof fill);
+  for (uint32_t s = 0; s < nsyms; s++)
+    if (bitsize[s]) t->syms[fill[bitsize[s]]++] = (uint16_t)s;
+  /* canonicalize(), table.hpp:190-210 */
+  uint64_t base_code = 0;
+  uint32_t cur_len = 0;
+  for (uint32_t l = 1; l <= MAXLEN; l++) {
+    for (uint32_t k = 0; k < t->count[l]; k++) {
+      uint64_t value;
+      if (cur_len == l) {
+        value = base_code; /* next_code.value()+1 == base_code */
+      } else {
+        base_code <<= (l - cur_len);
+        value = base_code;
+        cur_len = l;
+      }
+      if (k == 0) t->first[l] = value;
+      t->code[t->index[l] + k] = value;
+      ++base_code;
+    }
+  }
+}
+
+/* huffman/src/decode.hpp:83-102 decode_one: bits enter the code MSB-first
+ * (`current_code << bit`, code.hpp:90-96).  Returns encoded size, 0 = invalid
+ * (decode_result::kInvalidEncodedSize). */
+static unsigned decode_one(const ctab* t, const bitr* b, unsigned* sym) {
+  uint64_t code = 0;
+  size_t left = br_left(b);
+  for (unsigned len = 1;; len++) {
+    if (len > left) return 0; /* `for (auto bit : bits)` ran out */
+    code = (code << 1) | br_bit(b, b->pos + len - 1);
+    if (len <= MAXLEN && t->count[len]) {
+      uint64_t d = code - t->first[len]; /* unsigned, as table.hpp:441 */
+      if (d < t->count[len]) {
+        *sym = t->syms[t->index[len] + d];
+        return len;
+      }
+    }
+    if (len >= t->maxlen) return 0; /* find() returned end() (decode.hpp:96-98) */
+  }
+}
+
+void sfo_canonical_codes(const uint8_t* bitsize, uint32_t n, uint32_t* code_out) {
+  ctab t;
+  ctab_build(&t, bitsize, n);
+  for (uint32_t s = 0; s < n; s++) code_out[s] = 0;
+  for (uint32_t k = 0; k < t.n; k++) code_out[t.syms[k]] = (uint32_t)t.code[k];
+}
+
+size_t sfo_huffman_decode(const uint8_t* bitsize, uint32_t nsyms, const uint8_t* src,
+                          size_t nbits, uint16_t* out, size_t out_cap) {
+  ctab t;
+  ctab_build(&t, bitsize, nsyms);
+  bitr b = {src, nbits, 0};
+  size_t n = 0;
+  while (br_left(&b) > 0 && n < out_cap) { /* decode.hpp:29-36 */
+    unsigned sym;
+    unsigned sz = decode_one(&t, &b, &sym);
+    if (!sz) break;
+    out[n++] = (uint16_t)sym;
+    b.pos += sz;
+  }
+  return n;
+}
+
+/* src/decompress.cpp:53-84 */
+static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2,
+                                      2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t len_base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
+                                      31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2,  3,  3,  4,  4,  5,  5,  6,
+                                       6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+static const uint16_t dist_base[30] = {1,   2,   3,   4,   5,   7,    9,    13,   17,   25,
+                                       33,  49,  65,  97,  129, 193,  257,  385,  513,  769,
+                                       1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+/* src/decompress.cpp:250-251 */
+static const uint8_t cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+/* src/decompress.cpp:370-385 */
+static int read_header(bitr* b, int* final, int* type) {
+  if (br_left(b) < 3) return SFO_INVALID_BLOCK_HEADER;
+  int t = (int)(br_bit(b, b->pos + 1) | (br_bit(b, b->pos + 2) << 1));
+  if (t == 3) return SFO_INVALID_BLOCK_HEADER;
+  *final = (int)br_bit(b, b->pos);
+  *type = t;
+  b->pos += 3;
+  return SFO_SUCCESS;
+}
+
+int sfo_read_header(const uint8_t* src, size_t src_bits, int* final, int* type) {
+  bitr b = {src, src_bits, 0};
+  return read_header(&b, final, type);
+}
+
+/* src/decompress.cpp:388-398 */
+void sfo_copy_from_before(uint16_t distance, uint8_t* dst, uint16_t n) {
+  ptrdiff_t left = n;
+  const uint8_t* src = dst - distance;
+  while (left > 0) {
+    ptrdiff_t k = left < (dst - src) ? left : (dst - src);
+    memcpy(dst, src, (size_t)k);
+    dst += k;
+    left -= k;
+  }
+}
+
+/* src/decompress.cpp:197-242 with :122-187 inlined */
+static int block_huffman(bitr* b, uint8_t* dst, size_t dst_cap, size_t* written, const ctab* lt,
+                         const ctab* dt) {
+  for (;;) {
+    unsigned sym;
+    unsigned sz = decode_one(lt, b, &sym);
+    if (!sz) return SFO_INVALID_LIT_OR_LEN; /* :214-216 */
+    b->pos += sz;
+    if (sym < 256) { /* :125-127, :146-155 */
+      if (dst_cap - *written < 1) return SFO_DST_TOO_SMALL;
+      dst[(*written)++] = (uint8_t)sym;
+      continue;
+    }
+    if (sym == 256) return SFO_SUCCESS; /* :128-130, :221-223 */
+    if (sym > 285) return SFO_INVALID_LIT_OR_LEN; /* :131-133 */
+    unsigned len;
+    if (sym == 285) {
+      len = 258; /* :134-136 */
+    } else {
+      unsigned ex;
+      if (pop_bits(b, len_extra[sym - 257], &ex)) return SFO_ERROR;
+      len = len_base[sym - 257] + ex;
+    }
+    unsigned dsym;
+    sz = decode_one(dt, b, &dsym);
+    if (!sz) return SFO_INVALID_DISTANCE; /* :166-168 */
+    b->pos += sz;
+    if (dsym >= 30) return SFO_INVALID_LIT_OR_LEN; /* :170-172 */
+    unsigned ex;
+    if (pop_bits(b, dist_extra[dsym], &ex)) return SFO_ERROR;
+    unsigned distance = dist_base[dsym] + ex;
+    if (distance > *written) return SFO_INVALID_DISTANCE; /* :177-179 */
+    if (dst_cap - *written < len) return SFO_DST_TOO_SMALL; /* :180-182 */
+    sfo_copy_from_before((uint16_t)distance, dst + *written, (uint16_t)len);
+    *written += len;
+  }
+}
+
+/* src/decompress.cpp:253-312: one code-length sequence, own zeroed vector, own
+ * RLE state.  The reference does not bound-check runs (hazards A/B in
+ * SURVEY.md section 0); those inputs return SFO_ERROR here. */
+static int read_code_lengths(bitr* b, const ctab* clt, unsigned n_codes, uint8_t* out) {
+  memset(out, 0, n_codes);
+  for (unsigned i = 0; i < n_codes; i++) {
+    unsigned sym;
+    unsigned sz = decode_one(clt, b, &sym);
+    if (!sz) return SFO_INVALID_LIT_OR_LEN; /* :263-265 */
+    b->pos += sz;
+    if (sym < 16) {
+      out[i] = (uint8_t)sym;
+    } else {
+      unsigned nb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
+      unsigned base = sym == 18 ? 11 : 3;
+      unsigned rep;
+      if (sym > 18) return SFO_INVALID_LIT_OR_LEN; /* :297-299 */
+      if (pop_bits(b, nb, &rep)) return SFO_ERROR;
+      rep += base;
+      if (sym == 16 && i == 0) return SFO_ERROR;  /* reads code_bitsizes[-1] in the reference */
+      if (i + rep > n_codes) return SFO_ERROR;    /* writes past the vector in the reference */
+      uint8_t v = sym == 16 ? out[i - 1] : 0;
+      for (unsigned j = 0; j < rep; j++) out[i + j] = v;
+      i += rep - 1;
+    }
+  }
+  return SFO_SUCCESS;
+}
+
+/* src/decompress.cpp:314-367 */
+static int read_dynamic_tables(bitr* b, ctab* lt, ctab* dt) {
+  unsigned hlit, hdist, hclen;
+  if (pop_bits(b, 5, &hlit) || pop_bits(b, 5, &hdist) || pop_bits(b, 4, &hclen)) return SFO_ERROR;
+  unsigned n_len = 257 + hlit, n_dist = 1 + hdist, n_cl = 4 + hclen;
+  uint8_t cl_bits[19] = {0};
+  for (unsigned i = 0; i < n_cl; i++) {
+    unsigned v;
+    if (pop_bits(b, 3, &v)) return SFO_ERROR;
+    cl_bits[cl_order[i]] = (uint8_t)v;
+  }
+  ctab clt;
+  ctab_build(&clt, cl_bits, 19);
+  uint8_t lens[320];
+  int st = read_code_lengths(b, &clt, n_len, lens);
+  if (st) return st;
+  ctab_build(lt, lens, n_len);
+  st = read_code_lengths(b, &clt, n_dist, lens);
+  if (st) return st;
+  ctab_build(dt, lens, n_dist);
+  return SFO_SUCCESS;
+}
+
+static ctab g_fixed_l, g_fixed_d;
+static int g_fixed_ready;
+/* src/decompress.cpp:16-40: 288 lit/len symbols (286/287 exist in the table and
+ * are rejected after decode), 32 distance symbols of 5 bits. */
+static void fixed_tables(void) {
+  if (g_fixed_ready) return;
+  uint8_t l[288], d[32];
+  for (int i = 0; i < 288; i++) l[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+  for (int i = 0; i < 32; i++) d[i] = 5;
+  ctab_build(&g_fixed_l, l, 288);
+  ctab_build(&g_fixed_d, d, 32);
+  g_fixed_ready = 1;
+}
+
+/* src/decompress.cpp:402-461 */
+int sfo_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_cap,
+                   size_t* dst_written) {
+  fixed_tables();
+  bitr b = {src, src_len * 8, 0};
+  size_t written = 0;
+  int st = SFO_SUCCESS;
+  for (int was_final = 0; !was_final;) {
+    int final, type;
+    st = read_header(&b, &final, &type);
+    if (st) break;
+    was_final = final;
+    if (type == 0) {                 /* :416-436 */
+      b.pos = (b.pos + 7) & ~(size_t)7; /* consume_to_byte_boundary */
+      if (br_left(&b) < 32) { st = SFO_ERROR; break; } /* pop_16 asserts in the reference */
+      size_t byte = b.pos >> 3;
+      unsigned len = src[byte] | (src[byte + 1] << 8);
+      unsigned nlen = src[byte + 2] | (src[byte + 3] << 8);
+      b.pos += 32;
+      if (len != (uint16_t)~nlen) { st = SFO_NO_COMPRESSION_LEN_MISMATCH; break; }
+      if (br_left(&b) < (size_t)len * 8) { st = SFO_SRC_TOO_SMALL; break; }
+      if (dst_cap - written < len) { st = SFO_DST_TOO_SMALL; break; }
+      memcpy(dst + written, src + (b.pos >> 3), len);
+      b.pos += (size_t)len * 8;
+      written += len;
+    } else if (type == 1) { /* :437-446 */
+      st = block_huffman(&b, dst, dst_cap, &written, &g_fixed_l, &g_fixed_d);
+      if (st) break;
+    } else { /* :447-458 */
+      ctab lt, dt;
+      st = read_dynamic_tables(&b, &lt, &dt);
+      if (st) break;
+      st = block_huffman(&b, dst, dst_cap, &written, &lt, &dt);
+      if (st) break;
+    }
+  }
+  if (dst_written) *dst_written = written;
+  return st;
+}
+
+/* ====================================================================== */
+/* Part 2: encoder specification                                          */
+/* ====================================================================== */
+
+void sfo_default_params(sfo_params* p) {
+  memset(p, 0, sizeof *p);
+  p->chunk_bytes = 32768;
+  p->step = 1024;
+  p->hash_bits = 12;
+  p->region_bytes = 2048;
+  p->min_match = 4;
+  p->lazy = 1;
+  p->final_stream = 1;
+  p->strategy = 0;
+  p->depth = 1;
+  p->use_near = 1;
+  p->long_hash_bytes = 0;
+  p->chain_depth = 0;
+}
+
+static inline uint32_t load32(const uint8_t* p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+static inline uint32_t hash_of(uint32_t v, const sfo_params* p) {
+  if (p->min_match == 3) v &= 0xFFFFFFu;
+  return (v * 2654435761u) >> (32 - p->hash_bits);
+}
+
+static uint32_t match_len(const uint8_t* d, uint32_t i, uint32_t c, uint32_t maxlen) {
+  uint32_t l = 0;
+  while (l < maxlen && d[i + l] == d[c + l]) l++;
+  return l;
+}
+
+#define NONE 0xFFFFFFFFu
+
+static inline uint32_t hash_long(const uint8_t* q, const sfo_params* p) {
+  uint64_t v = 0;
+  for (uint32_t k = 0; k < p->long_hash_bytes; k++) v |= (uint64_t)q[k] << (8 * k);
+  return (uint32_t)((v * 0x9E3779B185EBCA87ull) >> (64 - p->hash_bits));
+}
+
+/* step-table entry <-> position: ((step+1) << 12) | (4095 - t), t = pos - step*W */
+static inline uint32_t ent_pos(uint32_t v, uint32_t W) { return ((v >> 12) - 1) * W + (4095 - (v & 4095)); }
+
+/*
+ * Stage n1.  Positions are hashed in steps of p->step consecutive positions.
+ * Every position of a step first reads its candidates, then the whole step is
+ * inserted -- exactly what a workgroup does between two barriers, and
+ * independent of the order in which threads run.
+ *
+ * Short table S (hash of min_match bytes) and optional long table L (hash of
+ * long_hash_bytes bytes), each with `depth` history levels:
+ *   level 0: u32 entry = ((step+1) << 12) | (4095 - t), updated by MAX, so it
+ *            names the FIRST position of the LATEST step that contained the hash;
+ *   level k>0: the value level k-1 held before the most recent step that
+ *            inserted this hash (every inserting position of a step writes the
+ *            same value, so the write is order-independent).
+ * Candidates of position i: per table, the levels as read before this step's
+ * insertions ("far", all < step start) and, with use_near, level 0 after the
+ * insertions if it names a position < i ("near": first same-hash position of
+ * this step).  Best = longest; ties -> smallest distance.
+ * chain_depth > 0 (analysis only, not on the GPU): exact serial hash chains.
+ */
+void sfo_match_chunk(const uint8_t* src, uint32_t n, const sfo_params* p, uint16_t* len16,
+                     uint16_t* dist16) {
+  const uint32_t W = p->step, HS = 1u << p->hash_bits, R = p->region_bytes, MM = p->min_match;
+  const uint32_t D = p->depth ? p->depth : 1, LB = p->long_hash_bytes;
+  const uint32_t NT = LB ? 2 : 1;
+  uint8_t* d = (uint8_t*)calloc((size_t)n + 16, 1);
+  memcpy(d, src, n);
+  memset(len16, 0, (size_t)n * 2);
+  memset(dist16, 0, (size_t)n * 2);
+
+  if (p->chain_depth) {
+    uint32_t* H = (uint32_t*)malloc(HS * 4);
+    uint32_t* prev = (uint32_t*)malloc((size_t)(n + 1) * 4);
+    for (uint32_t k = 0; k < HS; k++) H[k] = NONE;
+    for (uint32_t i = 0; i + MM <= n; i++) {
+      uint32_t h = hash_of(load32(d + i), p);
+      uint32_t rend = (i / R + 1) * R;
+      uint32_t maxlen = n - i < 258 ? n - i : 258;
+      if (rend - i < maxlen) maxlen = rend - i;
+      uint32_t best = 0, bc = 0, c = H[h];
+      for (uint32_t k = 0; k < p->chain_depth && c != NONE; k++, c = prev[c]) {
+        uint32_t l = match_len(d, i, c, maxlen);
+        if (l > best) { best = l; bc = c; }
+      }
+      if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)(i - bc); }
+      prev[i] = H[h];
+      H[h] = i;
+    }
+    free(prev);
+    free(H);
+    free(d);
+    return;
+  }
+
+  /* T[table][level][hash] */
+  uint32_t* T = (uint32_t*)calloc((size_t)NT * D * HS, 4);
+  uint32_t* far = (uint32_t*)malloc((size_t)W * NT * D * 4);
+  for (uint32_t s = 0, b = 0; b < n; s++, b += W) {
+    uint32_t e = b + W < n ? b + W : n;
+    /* read phase */
+    for (uint32_t i = b; i < e; i++)
+      for (uint32_t t = 0; t < NT; t++) {
+        uint32_t need = t ? LB : MM;
+        for (uint32_t k = 0; k < D; k++) far[((i - b) * NT + t) * D + k] = 0;
+        if (i + need > n) continue;
+        uint32_t h = t ? hash_long(d + i, p) : hash_of(load32(d + i), p);
+        for (uint32_t k = 0; k < D; k++) far[((i - b) * NT + t) * D + k] = T[(t * D + k) * HS + h];
+      }
+    /* insert phase: level 0 by MAX, deeper levels take what the level above held */
+    for (uint32_t i = b; i < e; i++)
+      for (uint32_t t = 0; t < NT; t++) {
+        uint32_t need = t ? LB : MM;
+        if (i + need > n) continue;
+        uint32_t h = t ? hash_long(d + i, p) : hash_of(load32(d + i), p);
+        uint32_t v = ((s + 1) << 12) | (4095 - (i - b));
+        for (uint32_t k = D - 1; k > 0; k--) T[(t * D + k) * HS + h] = far[((i - b) * NT + t) * D + k - 1];
+        uint32_t* slot = &T[(t * D) * HS + h];
+        if (v > *slot) *slot = v;
+      }
+    /* candidate evaluation */
+    for (uint32_t i = b; i < e; i++) {
+      uint32_t rend = (i / R + 1) * R;
+      uint32_t maxlen = n - i < 258 ? n - i : 258;
+      if (rend - i < maxlen) maxlen = rend - i;
+      uint32_t best = 0, bdist = 0;
+      for (uint32_t t = 0; t < NT; t++) {
+        uint32_t need = t ? LB : MM;
+        if (i + need > n) continue;
+        uint32_t h = t ? hash_long(d + i, p) : hash_of(load32(d + i), p);
+        uint32_t cand[8], nc = 0;
+        if (p->use_near) {
+          uint32_t c = ent_pos(T[(t * D) * HS + h], W);
+          if (c < i) cand[nc++] = c;
+        }
+        for (uint32_t k = 0; k < D; k++) {
+          uint32_t v = far[((i - b) * NT + t) * D + k];
+          if (v) cand[nc++] = ent_pos(v, W);
+        }
+        for (uint32_t k = 0; k < nc; k++) {
+          uint32_t l = match_len(d, i, cand[k], maxlen), dist = i - cand[k];
+          if (l > best || (l == best && l && dist < bdist)) { best = l; bdist = dist; }
+        }
+      }
+      if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)bdist; }
+    }
+  }
+  free(far);
+  free(T);
+  free(d);
+}
+
+/* Stage parse: greedy with one-step lazy deferral, independent per region. */
+void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
+                     const uint16_t* len16, const uint16_t* dist16, uint32_t* tokens,
+                     uint32_t* ntok) {
+  const uint32_t R = p->region_bytes, MM = p->min_match;
+  uint32_t nreg = (n + R - 1) / R;
+  for (uint32_t r = 0; r < nreg; r++) {
+    uint32_t pos = r * R, end = pos + R < n ? pos + R : n, k = 0;
+    uint32_t* out = tokens + (size_t)r * R;
+    while (pos < end) {
+      uint32_t l = len16[pos];
+      int take = l >= MM;
+      if (take && p->lazy && pos + 1 < end && len16[pos + 1] > l) take = 0;
+      if (take) {
+        out[k++] = SFO_TOK_MATCH | ((l - 3) << 16) | (uint32_t)(dist16[pos] - 1);
+        pos += l;
+      } else {
+        out[k++] = data[pos];
+        pos += 1;
+      }
+    }
+    ntok[r] = k;
+  }
+}
+
+static inline uint32_t len_symbol(uint32_t len) { /* 3..258 -> 257..285 */
+  uint32_t s = 28;
+  if (len == 258) return 285;
+  while (len_base[s] > len) s--;
+  return 257 + s;
+}
+static inline uint32_t dist_symbol(uint32_t dist) { /* 1..32768 -> 0..29 */
+  uint32_t s = 29;
+  while (dist_base[s] > dist) s--;
+  return s;
+}
+
+void sfo_histogram(const uint32_t* tokens, const uint32_t* ntok, uint32_t nregions,
+                   uint32_t region_bytes, uint32_t* ll, uint32_t* d) {
+  memset(ll, 0, 286 * 4);
+  memset(d, 0, 30 * 4);
+  for (uint32_t r = 0; r < nregions; r++)
+    for (uint32_t k = 0; k < ntok[r]; k++) {
+      uint32_t t = tokens[(size_t)r * region_bytes + k];
+      if (t & SFO_TOK_MATCH) {
+        ll[len_symbol(((t >> 16) & 0xFF) + 3)]++;
+        d[dist_symbol((t & 0x7FFF) + 1)]++;
+      } else {
+        ll[t & 0xFF]++;
+      }
+    }
+  ll[256] = 1;
+}
+
+/*
+ * Stage n3.  Huffman tree by the two-queue method over symbols sorted ascending
+ * by (freq, symbol) (ties: a leaf is taken before an internal node of equal
+ * weight), leaf depths counted per length with depths beyond maxbits clamped;
+ * the Kraft excess of the clamp is removed by lengthening the deepest leaves
+ * still shorter than maxbits, an overshoot is returned by shortening maxbits
+ * leaves; lengths are then dealt out longest-first to the rarest symbols.
+ * One used symbol gets a 1-bit code (reference: table.hpp:116-120; decoder
+ * accepts it, SURVEY.md 8(c) probe B); zero used symbols -> all lengths 0.
+ */
+void sfo_build_lengths(const uint32_t* freq, uint32_t n, uint32_t maxbits, uint8_t* lens) {
+  uint32_t key[288], m = 0;
+  memset(lens, 0, n);
+  for (uint32_t s = 0; s < n; s++)
+    if (freq[s]) key[m++] = (freq[s] << 9) | s; /* freq <= 2^16+, sym < 512 */
+  if (m == 0) return;
+  if (m == 1) { lens[key[0] & 511] = 1; return; }
+  /* sort ascending (insertion; m <= 286) */
+  for (uint32_t i = 1; i < m; i++) {
+    uint32_t k = key[i], j = i;
+    while (j > 0 && key[j - 1] > k) { key[j] = key[j - 1]; j--; }
+    key[j] = k;
+  }
+  uint32_t w[576], parent[576], depth[576];
+  for (uint32_t i = 0; i < m; i++) w[i] = key[i] >> 9;
+  uint32_t i = 0, j = m, k = m;
+  while (k < 2 * m - 1) {
+    uint32_t a, b;
+    if (i < m && (j >= k || w[i] <= w[j])) a = i++; else a = j++;
+    if (i < m && (j >= k || w[i] <= w[j])) b = i++; else b = j++;
+    w[k] = w[a] + w[b];
+    parent[a] = parent[b] = k;
+    k++;
+  }
+  uint32_t cnt[17] = {0};
+  depth[2 * m - 2] = 0;
+  for (int32_t v = (int32_t)(2 * m - 3); v >= 0; v--) {
+    depth[v] = depth[parent[v]] + 1;
+    if ((uint32_t)v < m) cnt[depth[v] < maxbits ? depth[v] : maxbits]++;
+  }
+  int64_t over = -((int64_t)1 << maxbits);
+  for (uint32_t l = 1; l <= maxbits; l++) over += (int64_t)cnt[l] << (maxbits - l);
+  while (over > 0) {
+    uint32_t l = maxbits - 1;
+    while (cnt[l] == 0) l--;
+    cnt[l]--;
+    cnt[l + 1]++;
+    over -= (int64_t)1 << (maxbits - l - 1);
+  }
+  while (over < 0) {
+    cnt[maxbits]--;
+    cnt[maxbits - 1]++;
+    over++;
+  }
+  uint32_t idx = 0;
+  for (uint32_t l = maxbits; l >= 1; l--)
+    for (uint32_t c = 0; c < cnt[l]; c++) lens[key[idx++] & 511] = (uint8_t)l;
+}
+
+/* LSB-first bit writer (inverse of bit_span / pop_bits) */
+typedef struct {
+  uint8_t* p;
+  size_t bitpos;
+} bitw;
+static void put_bits(bitw* w, uint32_t v, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++, w->bitpos++)
+    if ((v >> i) & 1) w->p[w->bitpos >> 3] |= (uint8_t)(1u << (w->bitpos & 7));
+}
+static uint32_t rev_bits(uint32_t v, uint32_t n) {
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < n; i++) r |= ((v >> i) & 1) << (n - 1 - i);
+  return r;
+}
+
+static uint32_t fixed_ll_len(uint32_t s) { return s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8; }
+
+/* RLE of one code-length sequence (never crosses into the other sequence and
+ * never starts with 16: src/decompress.cpp:253-312 keeps per-sequence state). */
+static uint32_t rle_lengths(const uint8_t* lens, uint32_t n, uint8_t* sym, uint8_t* ext) {
+  uint32_t k = 0, i = 0;
+  while (i < n) {
+    uint8_t v = lens[i];
+    uint32_t r = 1;
+    while (i + r < n && lens[i + r] == v) r++;
+    i += r;
+    if (v == 0) {
+      while (r >= 11) { uint32_t c = r < 138 ? r : 138; sym[k] = 18; ext[k++] = (uint8_t)(c - 11); r -= c; }
+      if (r >= 3) { sym[k] = 17; ext[k++] = (uint8_t)(r - 3); r = 0; }
+      while (r--) { sym[k] = 0; ext[k++] = 0; }
+    } else {
+      sym[k] = v; ext[k++] = 0; r--;
+      while (r >= 3) { uint32_t c = r < 6 ? r : 6; sym[k] = 16; ext[k++] = (uint8_t)(c - 3); r -= c; }
+      while (r--) { sym[k] = v; ext[k++] = 0; }
+    }
+  }
+  return k;
+}
+
+void sfo_plan_chunk(const uint32_t* ll, const uint32_t* d, uint32_t n_raw, int is_last,
+                    const sfo_params* p, sfo_plan* plan) {
+  memset(plan, 0, sizeof *plan);
+  sfo_build_lengths(ll, 286, 15, plan->ll_lens);
+  sfo_build_lengths(d, 30, 15, plan->d_lens);
+
+  uint32_t extra = 0, nmatch = 0, dyn_body = 0, fix_body = 0;
+  for (uint32_t s = 0; s < 286; s++) {
+    dyn_body += ll[s] * plan->ll_lens[s];
+    fix_body += ll[s] * fixed_ll_len(s);
+    if (s >= 257) extra += ll[s] * len_extra[s - 257];
+  }
+  for (uint32_t s = 0; s < 30; s++) {
+    dyn_body += d[s] * plan->d_lens[s];
+    extra += d[s] * dist_extra[s];
+    nmatch += d[s];
+  }
+  dyn_body += extra;
+  fix_body += extra + 5 * nmatch;
+
+  /* dynamic header */
+  uint32_t hlit = 286, hdist = 30;
+  while (hlit > 257 && plan->ll_lens[hlit - 1] == 0) hlit--;
+  while (hdist > 1 && plan->d_lens[hdist - 1] == 0) hdist--;
+  uint8_t sym[320], ext[320];
+  uint32_t nl = rle_lengths(plan->ll_lens, hlit, sym, ext);
+  uint32_t nd = rle_lengths(plan->d_lens, hdist, sym + nl, ext + nl);
+  uint32_t clf[19] = {0};
+  for (uint32_t k = 0; k < nl + nd; k++) clf[sym[k]]++;
+  uint8_t cll[19];
+  sfo_build_lengths(clf, 19, 7, cll);
+  uint32_t hclen = 19;
+  while (hclen > 4 && cll[cl_order[hclen - 1]] == 0) hclen--;
+  uint32_t clc[19];
+  sfo_canonical_codes(cll, 19, clc);
+  bitw w = {plan->header, 0};
+  put_bits(&w, hlit - 257, 5);
+  put_bits(&w, hdist - 1, 5);
+  put_bits(&w, hclen - 4, 4);
+  for (uint32_t k = 0; k < hclen; k++) put_bits(&w, cll[cl_order[k]], 3);
+  for (uint32_t k = 0; k < nl + nd; k++) {
+    put_bits(&w, rev_bits(clc[sym[k]], cll[sym[k]]), cll[sym[k]]);
+    if (sym[k] == 16) put_bits(&w, ext[k], 2);
+    else if (sym[k] == 17) put_bits(&w, ext[k], 3);
+    else if (sym[k] == 18) put_bits(&w, ext[k], 7);
+  }
+  plan->header_bits = (uint32_t)w.bitpos;
+
+  uint32_t dyn_bits = 3 + plan->header_bits + dyn_body;
+  uint32_t fix_bits = 3 + fix_body;
+  /* only the final block of a final stream may end unaligned; every other Huffman
+   * block is followed by an empty stored block so the next chunk / shard starts on a byte */
+  int fin = is_last && p->final_stream;
+  uint32_t dyn_bytes = fin ? (dyn_bits + 7) / 8 : (dyn_bits + 3 + 7) / 8 + 4;
+  uint32_t fix_bytes = fin ? (fix_bits + 7) / 8 : (fix_bits + 3 + 7) / 8 + 4;
+  uint32_t sto_bytes = n_raw + 5;
+  uint32_t bt;
+  if (p->strategy == 1) bt = 0;
+  else if (p->strategy == 2) bt = 1;
+  else if (p->strategy == 3) bt = 2;
+  else {
+    bt = 0;
+    uint32_t best = sto_bytes;
+    if (fix_bytes < best) { bt = 1; best = fix_bytes; }
+    if (dyn_bytes < best) { bt = 2; best = dyn_bytes; }
+  }
+  plan->btype = bt;
+  plan->out_bytes = bt == 0 ? sto_bytes : bt == 1 ? fix_bytes : dyn_bytes;
+  plan->body_bits = bt == 1 ? fix_body : dyn_body;
+}
+
+/* Stage n4 for one chunk; dst zero-initialised by the caller. */
+static void emit_chunk(const uint8_t* data, uint32_t n, const uint32_t* tokens,
+                       const uint32_t* ntok, const sfo_params* p, const sfo_plan* plan,
+                       int is_last, uint8_t* dst) {
+  int bfinal = is_last && p->final_stream;
+  if (plan->btype == 0) {
+    dst[0] = (uint8_t)bfinal; /* BFINAL, BTYPE=00, 5 pad bits */
+    dst[1] = (uint8_t)(n & 0xFF);
+    dst[2] = (uint8_t)(n >> 8);
+    dst[3] = (uint8_t)(~n & 0xFF);
+    dst[4] = (uint8_t)((~n >> 8) & 0xFF);
+    memcpy(dst + 5, data, n);
+    return;
+  }
+  bitw w = {dst, 0};
+  put_bits(&w, (uint32_t)bfinal, 1);
+  put_bits(&w, plan->btype, 2);
+  uint8_t ll_lens[288], d_lens[32];
+  if (plan->btype == 2) {
+    for (uint32_t k = 0; k < plan->header_bits; k++)
+      put_bits(&w, (plan->header[k >> 3] >> (k & 7)) & 1, 1);
+    memcpy(ll_lens, plan->ll_lens, 288);
+    memcpy(d_lens, plan->d_lens, 32);
+  } else {
+    for (uint32_t s = 0; s < 288; s++) ll_lens[s] = (uint8_t)fixed_ll_len(s);
+    for (uint32_t s = 0; s < 32; s++) d_lens[s] = 5;
+  }
+  uint32_t llc[288], dc[32];
+  sfo_canonical_codes(ll_lens, 288, llc);
+  sfo_canonical_codes(d_lens, 32, dc);
+  uint32_t nreg = (n + p->region_bytes - 1) / p->region_bytes;
+  for (uint32_t r = 0; r < nreg; r++)
+    for (uint32_t k = 0; k < ntok[r]; k++) {
+      uint32_t t = tokens[(size_t)r * p->region_bytes + k];
+      if (t & SFO_TOK_MATCH) {
+        uint32_t len = ((t >> 16) & 0xFF) + 3, dist = (t & 0x7FFF) + 1;
+        uint32_t ls = len_symbol(len), ds = dist_symbol(dist);
+        put_bits(&w, rev_bits(llc[ls], ll_lens[ls]), ll_lens[ls]);
+        put_bits(&w, len - len_base[ls - 257], len_extra[ls - 257]);
+        put_bits(&w, rev_bits(dc[ds], d_lens[ds]), d_lens[ds]);
+        put_bits(&w, dist - dist_base[ds], dist_extra[ds]);
+      } else {
+        put_bits(&w, rev_bits(llc[t], ll_lens[t]), ll_lens[t]);
+      }
+    }
+  put_bits(&w, rev_bits(llc[256], ll_lens[256]), ll_lens[256]);
+  if (!bfinal) {
+    /* byte-align with an empty non-final stored block: 000, pad, 00 00 FF FF */
+    put_bits(&w, 0, 3);
+    w.bitpos = (w.bitpos + 7) & ~(size_t)7;
+    size_t o = w.bitpos >> 3;
+    dst[o] = 0; dst[o + 1] = 0; dst[o + 2] = 0xFF; dst[o + 3] = 0xFF;
+  }
+}
+
+size_t sfo_compress_bound(size_t n, const sfo_params* p) {
+  size_t cb = p->chunk_bytes;
+  size_t nchunks = n ? (n + cb - 1) / cb : 1;
+  return nchunks * (cb + cb / 8 + 640);
+}
+
+int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,
+                 const sfo_params* p) {
+  if (p->chunk_bytes == 0 || p->chunk_bytes > 32768 || p->region_bytes == 0 ||
+      p->step == 0 || p->step > 4096 || p->hash_bits < 8 || p->hash_bits > 16 ||
+      (p->min_match != 3 && p->min_match != 4))
+    return -1;
+  const size_t cb = p->chunk_bytes;
+  const size_t nchunks = n ? (n + cb - 1) / cb : 1;
+  uint16_t* len16 = (uint16_t*)malloc(cb * 2 + 2);
+  uint16_t* dist16 = (uint16_t*)malloc(cb * 2 + 2);
+  uint32_t* tokens = (uint32_t*)malloc((cb + p->region_bytes) * 4);
+  uint32_t ntok[64];
+  uint8_t* tmp = (uint8_t*)malloc(cb + cb / 8 + 1024);
+  size_t off = 0;
+  int rc = 0;
+  if ((cb + p->region_bytes - 1) / p->region_bytes > 64) { rc = -1; goto out; }
+  for (size_t c = 0; c < nchunks; c++) {
+    const uint8_t* data = src + c * cb;
+    uint32_t cn = (uint32_t)(n - c * cb < cb ? n - c * cb : cb);
+    int is_last = c + 1 == nchunks;
+    uint32_t ll[286], d[30];
+    sfo_plan plan;
+    sfo_match_chunk(data, cn, p, len16, dist16);
+    sfo_parse_chunk(data, cn, p, len16, dist16, tokens, ntok);
+    uint32_t nreg = (cn + p->region_bytes - 1) / p->region_bytes;
+    sfo_histogram(tokens, ntok, nreg, p->region_bytes, ll, d);
+    sfo_plan_chunk(ll, d, cn, is_last, p, &plan);
+    if (off + plan.out_bytes > cap) { rc = -2; goto out; }
+    memset(tmp, 0, plan.out_bytes + 8);
+    emit_chunk(data, cn, tokens, ntok, p, &plan, is_last, tmp);
+    memcpy(dst + off, tmp, plan.out_bytes);
+    off += plan.out_bytes;
+  }
+  *out_len = off;
+out:
+  free(tmp);
+  free(tokens);
+  free(dist16);
+  free(len16);
+  return rc;
+}

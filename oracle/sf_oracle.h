@@ -1,0 +1,140 @@
+/*
+ * sf_oracle.h -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (starflate_amd/, include/, the HIP C-ABI
+ * library) never links, imports or calls anything in oracle/.
+ *
+ * Two halves:
+ *
+ *  (1) sfo_decompress(): a plain-C restatement of the reference's DEFLATE
+ *      decoder, /root/reference/src/decompress.cpp:402-461 and everything it
+ *      calls (bit order: huffman/src/bit_span.hpp:46-53; canonical codes:
+ *      huffman/src/table.hpp:177-216; per-bit decode: huffman/src/decode.hpp:83-102).
+ *      Same status codes (src/decompress.hpp:13-23).  This is the gate every
+ *      compressed stream must pass ("the reference decompressor round-trips it").
+ *
+ *  (2) sfo_compress() and its stages: the serial, scalar SPECIFICATION of the
+ *      deterministic block-parallel DEFLATE encoder that the HIP kernels
+ *      implement.  The reference has no compressor (README.md:5-7), so this half
+ *      restates no reference code; it is pinned by (a) round-trip through (1)
+ *      and through zlib inflate, and (b) the emitter contract derived from the
+ *      reference decoder.  GPU output must be bit-exact
+ *      equal to sfo_compress() output for the same parameters.
+ *
+ * Pinning status: the reference itself cannot be built in this image (it
+ * includes <expected>, which libstdc++-11 lacks, and writing a stand-in header
+ * is not allowed), so (1) is pinned by the reference's own test vectors:
+ * src/test/decompress_test.cpp:62-181 (header KATs, stored "rose"/"bud" stream
+ * incl. DstTooSmall/SrcTooSmall, starfleet.html fixed + dynamic fixtures made by
+ * the reference's tools/deflate_compress.py, copy_from_before), and the huffman
+ * KATs of huffman/test/{decode,table_from_symbol_bitsize,table_find_code}_test.cpp.
+ * See tests/test_oracle_*.py.
+ */
+#ifndef SF_ORACLE_H
+#define SF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/decompress.hpp:13-23 */
+enum sfo_status {
+  SFO_SUCCESS = 0,
+  SFO_ERROR = 1, /* "unused" in the reference; here: input on which the reference
+                    asserts / has undefined behaviour (truncated bit reads,
+                    code-length runs overshooting, repeat-prev at index 0) */
+  SFO_INVALID_BLOCK_HEADER = 2,
+  SFO_NO_COMPRESSION_LEN_MISMATCH = 3,
+  SFO_DST_TOO_SMALL = 4,
+  SFO_SRC_TOO_SMALL = 5,
+  SFO_INVALID_LIT_OR_LEN = 6,
+  SFO_INVALID_DISTANCE = 7
+};
+
+/* restates starflate::decompress(); *dst_written (may be NULL) is an extra the
+ * reference does not report (src/decompress.hpp:63-64). */
+int sfo_decompress(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_cap,
+                   size_t* dst_written);
+
+/* restates detail::read_header (src/decompress.cpp:370-385) on the first byte(s):
+ * returns status; on success *final / *type (0 stored, 1 fixed, 2 dynamic). */
+int sfo_read_header(const uint8_t* src, size_t src_bits, int* final, int* type);
+
+/* restates detail::copy_from_before (src/decompress.cpp:388-398) */
+void sfo_copy_from_before(uint16_t distance, uint8_t* dst, uint16_t n);
+
+/* restates huffman::table{symbol_bitsize,...} + canonicalize (table.hpp:177-216):
+ * bitsize[i] for symbol i (0 = absent) -> canonical code value per symbol. */
+void sfo_canonical_codes(const uint8_t* bitsize, uint32_t n, uint32_t* code_out);
+
+/* restates huffman::decode (decode.hpp:25-37) for a table given as symbol->bitsize:
+ * decodes symbols from `nbits` bits of src until no code matches; returns count. */
+size_t sfo_huffman_decode(const uint8_t* bitsize, uint32_t nsyms, const uint8_t* src,
+                          size_t nbits, uint16_t* out, size_t out_cap);
+
+/* ---------------- encoder specification ---------------- */
+
+typedef struct sfo_params {
+  uint32_t chunk_bytes;  /* independent DEFLATE block per chunk; <= 32768 */
+  uint32_t step;         /* positions hashed per insertion step (GPU: threads*pos/thread) */
+  uint32_t hash_bits;    /* hash table = 1<<hash_bits entries */
+  uint32_t region_bytes; /* parse region; matches never cross a region boundary */
+  uint32_t min_match;    /* 3 or 4 */
+  uint32_t lazy;         /* 1: defer a match when the next position has a longer one */
+  uint32_t final_stream; /* 1: last chunk carries BFINAL (0 for a non-last GPU shard) */
+  uint32_t strategy;     /* 0 auto (smallest of stored/fixed/dynamic), 1 stored, 2 fixed, 3 dynamic */
+  uint32_t depth;        /* history levels per hash table (1..3) */
+  uint32_t use_near;     /* 1: also try the first same-hash position of the current step */
+  uint32_t long_hash_bytes; /* 0: off; 5..8: second table keyed by that many bytes */
+  uint32_t chain_depth;  /* analysis only (not on the GPU): >0 = exact hash chains */
+} sfo_params;
+
+void sfo_default_params(sfo_params* p);
+
+/* token: bit31 = match; match: bits16..23 = len-3, bits0..14 = dist-1; literal: byte */
+#define SFO_TOK_MATCH 0x80000000u
+
+size_t sfo_compress_bound(size_t n, const sfo_params* p);
+
+/* whole pipeline; returns 0 or negative error; *out_len = bytes written */
+int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,
+                 const sfo_params* p);
+
+/* stage n1: per-position best match for one chunk; len16[i] in {0, min_match..258} */
+void sfo_match_chunk(const uint8_t* data, uint32_t n, const sfo_params* p, uint16_t* len16,
+                     uint16_t* dist16);
+
+/* stage parse: tokens per region written at tokens[region_start + k]; ntok[r] counts */
+void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
+                     const uint16_t* len16, const uint16_t* dist16, uint32_t* tokens,
+                     uint32_t* ntok);
+
+/* stage n2: ll[286] + d[30] histogram of a chunk's tokens (EOB counted once) */
+void sfo_histogram(const uint32_t* tokens, const uint32_t* ntok, uint32_t nregions,
+                   uint32_t region_bytes, uint32_t* ll, uint32_t* d);
+
+/* stage n3: length-limited Huffman code lengths (maxbits 15 or 7) */
+void sfo_build_lengths(const uint32_t* freq, uint32_t n, uint32_t maxbits, uint8_t* lens);
+
+/* per-chunk plan (stage n3 + block choice) */
+typedef struct sfo_plan {
+  uint32_t btype;       /* 0 stored, 1 fixed, 2 dynamic */
+  uint32_t out_bytes;   /* bytes this chunk occupies in the stream (incl. alignment) */
+  uint32_t header_bits; /* dynamic header length in bits (after the 3 block-header bits) */
+  uint32_t body_bits;   /* token + EOB bits */
+  uint8_t ll_lens[288];
+  uint8_t d_lens[32];
+  uint8_t header[600]; /* dynamic header bitstream (HLIT.. up to last dist length) */
+} sfo_plan;
+
+void sfo_plan_chunk(const uint32_t* ll, const uint32_t* d, uint32_t n_raw, int is_last,
+                    const sfo_params* p, sfo_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

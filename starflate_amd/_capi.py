@@ -1,0 +1,79 @@
+"""ctypes binding of include/starflate_hip.h (libstarflate_hip.so).
+
+There is no CPU fallback: if the library is missing or no HIP device is present,
+every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+NSTAGES = 4
+STRATEGY = {"auto": 0, "stored": 1, "fixed": 2, "dynamic": 3}
+DBG_NTOK, DBG_TOKENS, DBG_HIST, DBG_PLAN, DBG_LENS, DBG_OFFSETS = range(6)
+
+# every symbol include/starflate_hip.h declares
+EXPORTS = [
+    "sfh_default_options", "sfh_device_count", "sfh_create", "sfh_destroy", "sfh_last_error",
+    "sfh_compress_bound", "sfh_compress", "sfh_compress_device", "sfh_compress_device_async",
+    "sfh_set_profiling", "sfh_last_stage_ms", "sfh_stage_name", "sfh_debug_read",
+]
+
+
+class Options(C.Structure):
+    _fields_ = [("strategy", C.c_uint32), ("final_stream", C.c_uint32), ("lazy", C.c_uint32),
+                ("reserved", C.c_uint32 * 5)]
+
+
+_LIB = None
+
+
+def lib():
+    """Load libstarflate_hip.so (loudly failing if it has not been built)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(path)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.sfh_default_options.argtypes = [C.POINTER(Options)]
+    L.sfh_default_options.restype = None
+    L.sfh_device_count.argtypes = []
+    L.sfh_device_count.restype = C.c_int
+    L.sfh_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.sfh_create.restype = C.c_int
+    L.sfh_destroy.argtypes = [vp]
+    L.sfh_destroy.restype = None
+    L.sfh_last_error.argtypes = [vp]
+    L.sfh_last_error.restype = C.c_char_p
+    L.sfh_compress_bound.argtypes = [sz]
+    L.sfh_compress_bound.restype = sz
+    L.sfh_compress.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Options)]
+    L.sfh_compress.restype = C.c_int
+    L.sfh_compress_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Options), vp]
+    L.sfh_compress_device.restype = C.c_int
+    L.sfh_compress_device_async.argtypes = [vp, vp, sz, vp, sz, vp, C.POINTER(Options), vp]
+    L.sfh_compress_device_async.restype = C.c_int
+    L.sfh_set_profiling.argtypes = [vp, C.c_int]
+    L.sfh_set_profiling.restype = None
+    L.sfh_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float * NSTAGES)]
+    L.sfh_last_stage_ms.restype = C.c_int
+    L.sfh_stage_name.argtypes = [C.c_int]
+    L.sfh_stage_name.restype = C.c_char_p
+    L.sfh_debug_read.argtypes = [vp, C.c_int, vp, sz]
+    L.sfh_debug_read.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def make_options(strategy="auto", final_stream=True, lazy=True):
+    o = Options()
+    lib().sfh_default_options(C.byref(o))
+    o.strategy = STRATEGY[strategy] if isinstance(strategy, str) else int(strategy)
+    o.final_stream = int(bool(final_stream))
+    o.lazy = int(bool(lazy))
+    return o

@@ -1,0 +1,136 @@
+"""Host plumbing over the C-ABI: device memory and streams come from torch, the
+compression itself happens only in libstarflate_hip.so (HIP kernels, gfx950).
+
+`compress()` is the sibling of the reference's
+`starflate::decompress(src, dst) -> status` (/root/reference/src/decompress.hpp:63-71):
+raw RFC 1951 out, caller-owned buffers, integer status turned into an exception.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+CHUNK_BYTES = 32768
+
+
+class StarflateError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"starflate_hip error {code}: {msg}")
+        self.code = code
+
+
+class Compressor:
+    """One sfh_ctx (one GPU). Not thread-safe; use one per thread / per rank."""
+
+    def __init__(self, device=0):
+        self._lib = _capi.lib()
+        n = self._lib.sfh_device_count()
+        if n <= 0:
+            raise StarflateError(-3, "no HIP device visible; the compressor has no CPU fallback")
+        h = C.c_void_p()
+        rc = self._lib.sfh_create(C.byref(h), int(device))
+        if rc:
+            raise StarflateError(rc, f"sfh_create(device={device}) failed")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sfh_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc:
+            raise StarflateError(rc, self._lib.sfh_last_error(self._h).decode())
+
+    @staticmethod
+    def compress_bound(n):
+        return _capi.lib().sfh_compress_bound(int(n))
+
+    # ---- host buffers (PCIe inclusive) ----
+    def compress(self, data, strategy="auto", final_stream=True, lazy=True):
+        src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        cap = self.compress_bound(src.size)
+        dst = np.empty(cap, dtype=np.uint8)
+        out_n = C.c_size_t(0)
+        opt = _capi.make_options(strategy, final_stream, lazy)
+        self._check(self._lib.sfh_compress(self._h, src.ctypes.data if src.size else None, src.size,
+                                           dst.ctypes.data, cap, C.byref(out_n), C.byref(opt)))
+        return dst[: out_n.value].tobytes()
+
+    # ---- device buffers (torch uint8 CUDA tensors) ----
+    def compress_tensor(self, src, out=None, strategy="auto", final_stream=True, lazy=True, stream=None):
+        """src: 1-D uint8 tensor on this device. Returns (out tensor, stream byte count)."""
+        import torch
+
+        self._check_tensor(src)
+        n = src.numel()
+        cap = self.compress_bound(n)
+        if out is None:
+            out = torch.empty(cap, dtype=torch.uint8, device=src.device)
+        self._check_tensor(out)
+        out_n = C.c_size_t(0)
+        opt = _capi.make_options(strategy, final_stream, lazy)
+        s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
+        self._check(self._lib.sfh_compress_device(self._h, src.data_ptr() if n else None, n, out.data_ptr(),
+                                                  out.numel(), C.byref(out_n), C.byref(opt), C.c_void_p(s)))
+        return out, out_n.value
+
+    def compress_tensor_async(self, src, out, size_out, strategy="auto", final_stream=True, lazy=True, stream=None):
+        """Enqueue only. size_out: 1-element int64 CUDA tensor receiving the stream size."""
+        import torch
+
+        self._check_tensor(src)
+        self._check_tensor(out)
+        if size_out.dtype not in (torch.int64, torch.uint64) or not size_out.is_cuda:
+            raise ValueError("size_out must be a 1-element int64 CUDA tensor")
+        opt = _capi.make_options(strategy, final_stream, lazy)
+        s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
+        n = src.numel()
+        self._check(self._lib.sfh_compress_device_async(self._h, src.data_ptr() if n else None, n, out.data_ptr(),
+                                                        out.numel(), size_out.data_ptr(), C.byref(opt), C.c_void_p(s)))
+
+    def _check_tensor(self, t):
+        import torch
+
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.dim() == 1 and t.is_contiguous()):
+            raise ValueError("expected a contiguous 1-D uint8 CUDA tensor")
+        if t.device.index != self.device:
+            raise ValueError(f"tensor is on cuda:{t.device.index}, compressor on cuda:{self.device}")
+
+    # ---- measurement / inspection ----
+    def set_profiling(self, on=True):
+        self._lib.sfh_set_profiling(self._h, int(bool(on)))
+
+    def stage_ms(self):
+        ms = (C.c_float * _capi.NSTAGES)()
+        self._check(self._lib.sfh_last_stage_ms(self._h, C.byref(ms)))
+        return {self._lib.sfh_stage_name(k).decode(): float(ms[k]) for k in range(_capi.NSTAGES)}
+
+    def debug(self, what, nchunks):
+        shapes = {
+            _capi.DBG_NTOK: ((nchunks,), np.uint32),
+            _capi.DBG_TOKENS: ((nchunks, CHUNK_BYTES), np.uint32),
+            _capi.DBG_HIST: ((nchunks, 320), np.uint32),
+            _capi.DBG_PLAN: ((nchunks, 4), np.uint32),
+            _capi.DBG_LENS: ((nchunks, 320), np.uint8),
+            _capi.DBG_OFFSETS: ((nchunks,), np.uint64),
+        }
+        shape, dt = shapes[what]
+        a = np.empty(shape, dtype=dt)
+        self._check(self._lib.sfh_debug_read(self._h, what, a.ctypes.data, a.nbytes))
+        return a
+
+
+_DEFAULT = {}
+
+
+def compress(data, device=0, **kw):
+    """bytes-like -> raw DEFLATE bytes, through the GPU (host buffers, PCIe inclusive)."""
+    c = _DEFAULT.get(device)
+    if c is None:
+        c = _DEFAULT[device] = Compressor(device)
+    return c.compress(data, **kw)

@@ -1,0 +1,260 @@
+// sf_capi.hip -- the C-ABI of include/starflate_hip.h over the kernels of sf_kernels.hip.
+// No torch types, no exceptions across the boundary; a ctx owns its device scratch.
+#include "../../include/starflate_hip.h"
+#include "sf_device.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+struct sfh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;  // used when the caller passes no stream
+  sf::Workspace ws{};
+  uint32_t cap_chunks = 0;       // chunks the workspace can hold
+  uint32_t last_chunks = 0;
+  uint64_t* d_total = nullptr;   // own result slot for the synchronous entry points
+  uint8_t* d_in = nullptr;       // staging for the host-buffer entry point
+  uint8_t* d_out = nullptr;
+  size_t d_in_cap = 0, d_out_cap = 0;
+  int profiling = 0;
+  hipEvent_t ev[SFH_NSTAGES + 1] = {};
+  bool ev_valid = false;
+  char err[256] = {0};
+};
+
+namespace {
+
+int fail(sfh_ctx* c, int code, const char* what, hipError_t e) {
+  if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
+  return code;
+}
+
+#define SF_HIP(call, what)                                   \
+  do {                                                       \
+    hipError_t _e = (call);                                  \
+    if (_e != hipSuccess) return fail(ctx, SFH_E_HIP, what, _e); \
+  } while (0)
+
+void free_ws(sfh_ctx* c) {
+  (void)hipFree(c->ws.tokens);
+  (void)hipFree(c->ws.ntok);
+  (void)hipFree(c->ws.hist);
+  (void)hipFree(c->ws.plan);
+  (void)hipFree(c->ws.codes);
+  (void)hipFree(c->ws.offsets);
+  c->ws = sf::Workspace{};
+  c->cap_chunks = 0;
+}
+
+int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
+  if (nchunks <= ctx->cap_chunks) return SFH_OK;
+  free_ws(ctx);
+  const size_t nc = nchunks;
+  hipError_t e;
+  if ((e = hipMalloc(&ctx->ws.tokens, nc * sf::kChunk * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.ntok, nc * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.hist, nc * sf::kHistStride * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.plan, nc * sizeof(sf::ChunkPlan))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.codes, nc * sizeof(sf::ChunkCodes))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.offsets, nc * sizeof(uint64_t))) != hipSuccess) {
+    free_ws(ctx);
+    return fail(ctx, SFH_E_NOMEM, "workspace hipMalloc", e);
+  }
+  ctx->cap_chunks = nchunks;
+  return SFH_OK;
+}
+
+uint32_t chunks_of(size_t n) { return n ? (uint32_t)((n + sf::kChunk - 1) / sf::kChunk) : 1u; }
+
+int check_opt(const sfh_options* o) {
+  if (!o) return 0;
+  if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 1) return -1;
+  for (int k = 0; k < 5; ++k)
+    if (o->reserved[k]) return -1;
+  return 0;
+}
+
+int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, uint64_t* d_out_n,
+            const sfh_options* opt, hipStream_t s) {
+  if (!ctx || (!d_src && n) || !d_dst || !d_out_n || check_opt(opt)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
+  if (((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 3)) return fail(ctx, SFH_E_INVALID_ARG, "device pointer alignment (src 16, dst 4)", hipSuccess);
+  if (cap < sfh_compress_bound(n)) return fail(ctx, SFH_E_DST_TOO_SMALL, "cap < sfh_compress_bound(n)", hipSuccess);
+  if (n > ((size_t)1 << 44)) return fail(ctx, SFH_E_INVALID_ARG, "input too large", hipSuccess);
+  sfh_options o;
+  if (opt) o = *opt; else sfh_default_options(&o);
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  const uint32_t nchunks = chunks_of(n);
+  int rc = ensure_ws(ctx, nchunks);
+  if (rc) return rc;
+  ctx->last_chunks = nchunks;
+  const sf::Options ko{o.strategy, o.final_stream, o.lazy};
+  const bool prof = ctx->profiling != 0;
+  if (prof) SF_HIP(hipEventRecord(ctx->ev[0], s), "event");
+  SF_HIP(sf::launch_lz77((const uint8_t*)d_src, n, nchunks, ctx->ws, ko, s), "launch k_lz77");
+  if (prof) SF_HIP(hipEventRecord(ctx->ev[1], s), "event");
+  SF_HIP(sf::launch_plan(n, nchunks, ctx->ws, ko, s), "launch k_plan");
+  if (prof) SF_HIP(hipEventRecord(ctx->ev[2], s), "event");
+  SF_HIP(sf::launch_scan(nchunks, ctx->ws, d_out_n, s), "launch k_scan");
+  if (prof) SF_HIP(hipEventRecord(ctx->ev[3], s), "event");
+  SF_HIP(sf::launch_emit((const uint8_t*)d_src, n, nchunks, ctx->ws, (uint8_t*)d_dst, s), "launch k_emit");
+  if (prof) SF_HIP(hipEventRecord(ctx->ev[4], s), "event");
+  ctx->ev_valid = prof;
+  return SFH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void sfh_default_options(sfh_options* o) {
+  memset(o, 0, sizeof *o);
+  o->strategy = SFH_AUTO;
+  o->final_stream = 1;
+  o->lazy = 1;
+}
+
+int sfh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sfh_create(sfh_ctx** out, int device) {
+  if (!out) return SFH_E_INVALID_ARG;
+  *out = nullptr;
+  int n = sfh_device_count();
+  if (n <= 0 || device < 0 || device >= n) return SFH_E_NO_DEVICE;
+  sfh_ctx* ctx = new (std::nothrow) sfh_ctx();
+  if (!ctx) return SFH_E_NOMEM;
+  ctx->device = device;
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+      (e = hipMalloc(&ctx->d_total, sizeof(uint64_t))) != hipSuccess || (e = sf::init_kernels()) != hipSuccess) {
+    sfh_destroy(ctx);
+    return SFH_E_HIP;
+  }
+  for (int k = 0; k <= SFH_NSTAGES; ++k)
+    if (hipEventCreate(&ctx->ev[k]) != hipSuccess) {
+      sfh_destroy(ctx);
+      return SFH_E_HIP;
+    }
+  *out = ctx;
+  return SFH_OK;
+}
+
+void sfh_destroy(sfh_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_ws(ctx);
+  (void)hipFree(ctx->d_total);
+  (void)hipFree(ctx->d_in);
+  (void)hipFree(ctx->d_out);
+  for (int k = 0; k <= SFH_NSTAGES; ++k)
+    if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* sfh_last_error(const sfh_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
+
+size_t sfh_compress_bound(size_t n) {
+  // per chunk: fixed-Huffman worst case (9 bits per literal) + headers + alignment block
+  const size_t nchunks = n ? (n + sf::kChunk - 1) / sf::kChunk : 1;
+  return nchunks * (size_t)(sf::kChunk + sf::kChunk / 8 + 640);
+}
+
+int sfh_compress_device_async(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap,
+                              uint64_t* d_out_n, const sfh_options* opt, void* stream) {
+  if (!ctx) return SFH_E_INVALID_ARG;
+  return enqueue(ctx, d_src, n, d_dst, cap, d_out_n, opt, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int sfh_compress_device(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap,
+                        size_t* out_n, const sfh_options* opt, void* stream) {
+  if (!ctx || !out_n) return SFH_E_INVALID_ARG;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  int rc = enqueue(ctx, d_src, n, d_dst, cap, ctx->d_total, opt, s);
+  if (rc) return rc;
+  uint64_t total = 0;
+  SF_HIP(hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, s), "copy size");
+  SF_HIP(hipStreamSynchronize(s), "stream sync");
+  *out_n = (size_t)total;
+  return SFH_OK;
+}
+
+int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap, size_t* out_n,
+                 const sfh_options* opt) {
+  if (!ctx || (!src && n) || !dst || !out_n) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
+  const size_t bound = sfh_compress_bound(n);
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  const size_t in_need = n ? n : 16;
+  if (ctx->d_in_cap < in_need) {
+    (void)hipFree(ctx->d_in);
+    ctx->d_in = nullptr;
+    ctx->d_in_cap = 0;
+    if (hipMalloc(&ctx->d_in, in_need) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "input staging", hipSuccess);
+    ctx->d_in_cap = in_need;
+  }
+  if (ctx->d_out_cap < bound) {
+    (void)hipFree(ctx->d_out);
+    ctx->d_out = nullptr;
+    ctx->d_out_cap = 0;
+    if (hipMalloc(&ctx->d_out, bound) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "output staging", hipSuccess);
+    ctx->d_out_cap = bound;
+  }
+  hipStream_t s = ctx->stream;
+  if (n) SF_HIP(hipMemcpyAsync(ctx->d_in, src, n, hipMemcpyHostToDevice, s), "H2D");
+  size_t total = 0;
+  int rc = sfh_compress_device(ctx, ctx->d_in, n, ctx->d_out, bound, &total, opt, s);
+  if (rc) return rc;
+  if (total > cap) return fail(ctx, SFH_E_DST_TOO_SMALL, "dst capacity below stream size", hipSuccess);
+  SF_HIP(hipMemcpyAsync(dst, ctx->d_out, total, hipMemcpyDeviceToHost, s), "D2H");
+  SF_HIP(hipStreamSynchronize(s), "stream sync");
+  *out_n = total;
+  return SFH_OK;
+}
+
+void sfh_set_profiling(sfh_ctx* ctx, int on) {
+  if (ctx) ctx->profiling = on;
+}
+
+int sfh_last_stage_ms(sfh_ctx* ctx, float ms[SFH_NSTAGES]) {
+  if (!ctx || !ms || !ctx->ev_valid) return SFH_E_INVALID_ARG;
+  for (int k = 0; k < SFH_NSTAGES; ++k) SF_HIP(hipEventElapsedTime(&ms[k], ctx->ev[k], ctx->ev[k + 1]), "elapsed");
+  return SFH_OK;
+}
+
+const char* sfh_stage_name(int stage) {
+  static const char* names[SFH_NSTAGES] = {"k_lz77", "k_plan", "k_scan", "k_emit"};
+  return (stage >= 0 && stage < SFH_NSTAGES) ? names[stage] : "";
+}
+
+int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes) {
+  if (!ctx || !host_dst || !ctx->last_chunks) return SFH_E_INVALID_ARG;
+  const size_t nc = ctx->last_chunks;
+  const void* p = nullptr;
+  size_t avail = 0;
+  switch (what) {
+    case SFH_DBG_NTOK: p = ctx->ws.ntok; avail = nc * 4; break;
+    case SFH_DBG_TOKENS: p = ctx->ws.tokens; avail = nc * sf::kChunk * 4; break;
+    case SFH_DBG_HIST: p = ctx->ws.hist; avail = nc * sf::kHistStride * 4; break;
+    case SFH_DBG_PLAN: p = ctx->ws.plan; avail = nc * sizeof(sf::ChunkPlan); break;
+    case SFH_DBG_OFFSETS: p = ctx->ws.offsets; avail = nc * 8; break;
+    case SFH_DBG_LENS: {
+      if (bytes > nc * 320) return SFH_E_INVALID_ARG;
+      SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+      SF_HIP(hipMemcpy2D(host_dst, 320, (const uint8_t*)ctx->ws.codes + offsetof(sf::ChunkCodes, lens),
+                         sizeof(sf::ChunkCodes), 320, bytes / 320, hipMemcpyDeviceToHost), "debug copy");
+      return SFH_OK;
+    }
+    default: return SFH_E_INVALID_ARG;
+  }
+  if (bytes > avail) return SFH_E_INVALID_ARG;
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  SF_HIP(hipMemcpy(host_dst, p, bytes, hipMemcpyDeviceToHost), "debug copy");
+  return SFH_OK;
+}
+
+}  // extern "C"

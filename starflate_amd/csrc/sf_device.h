@@ -1,0 +1,68 @@
+// sf_device.h -- device-side data layout shared by the kernels and the C-ABI host.
+//
+// Pipeline (one HIP stream, four launches per call):
+//   K1 k_lz77   one 1024-thread workgroup per 32 KiB chunk: chunk + hash table +
+//               per-position (len,dist) in LDS; step-synchronous hash insertion,
+//               candidate compare, per-wave greedy/lazy parse, token + histogram out
+//   K2 k_plan   one wave per chunk: length-limited Huffman lengths (ll, d, cl),
+//               canonical codes, dynamic header bits, block type, exact byte size
+//   K3 k_scan   exclusive scan of chunk byte sizes -> output offsets, total
+//   K4 k_emit   one workgroup per chunk: bit-pack tokens into LDS, flush to the
+//               chunk's final byte offset (or copy raw bytes for a stored block)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sf {
+
+constexpr uint32_t kChunk = 32768;      // bytes per independently coded DEFLATE block
+constexpr uint32_t kStep = 1024;        // positions per hash-insertion step (= K1 threads)
+constexpr uint32_t kHashBits = 12;
+constexpr uint32_t kRegion = 2048;      // parse region: matches never cross it
+constexpr uint32_t kRegionsPerChunk = kChunk / kRegion;
+constexpr uint32_t kMinMatch = 4;
+constexpr uint32_t kTokMatch = 0x80000000u;  // token: bit31 match, 16..23 len-3, 0..14 dist-1
+
+constexpr uint32_t kHistStride = 320;   // ll[0..285] at 0, d[0..29] at 288
+constexpr uint32_t kHistD = 288;
+constexpr uint32_t kHeaderWords = 152;  // 608 bytes >= 4495-bit worst-case dynamic header + 3
+
+// per-chunk plan record written by K2, read by K3/K4
+struct ChunkPlan {
+  uint32_t btype;        // 0 stored, 1 fixed, 2 dynamic
+  uint32_t out_bytes;    // exact bytes of this chunk in the stream
+  uint32_t header_bits;  // bits in `header` (block header 3 bits + dynamic header)
+  uint32_t body_bits;    // token bits + EOB
+};
+struct ChunkCodes {
+  uint32_t lcode[288];   // bit-reversed code | nbits << 16
+  uint32_t dcode[32];
+  uint32_t header[kHeaderWords];  // LSB-first bitstream: BFINAL,BTYPE, then RFC 1951 3.2.7 header
+  uint8_t lens[320];     // ll lens [0..287], d lens [288..319] (debug / parity)
+};
+
+struct Workspace {
+  uint32_t* tokens;   // [nchunks][kChunk]
+  uint32_t* ntok;     // [nchunks]
+  uint32_t* hist;     // [nchunks][kHistStride]
+  ChunkPlan* plan;    // [nchunks]
+  ChunkCodes* codes;  // [nchunks]
+  uint64_t* offsets;  // [nchunks]
+};
+
+struct Options {
+  uint32_t strategy;
+  uint32_t final_stream;
+  uint32_t lazy;
+};
+
+hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
+                       const Options& opt, hipStream_t s);
+hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,
+                       hipStream_t s);
+hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t* d_total, hipStream_t s);
+hipError_t launch_emit(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
+                       uint8_t* dst, hipStream_t s);
+hipError_t init_kernels();
+
+}  // namespace sf

@@ -1,0 +1,832 @@
+// sf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the DEFLATE encoder.
+// Integer/bit work only: no MFMA.  See sf_device.h for the pipeline and DESIGN.md for
+// the LDS layout and the per-kernel roofline.  The bitstream these kernels emit is the
+// inverse of /root/reference/src/decompress.cpp (contract: SURVEY.md Appendix A).
+#include "sf_device.h"
+
+namespace sf {
+
+// ---------------------------------------------------------------------------
+// symbol arithmetic (inverse of length_infos / distance_infos,
+// /root/reference/src/decompress.cpp:53-84)
+// ---------------------------------------------------------------------------
+// l3 = len-3 in [0,255] -> lit/len symbol, extra-bit count, extra value
+__device__ __forceinline__ uint32_t len_symbol(uint32_t l3, uint32_t& ebits, uint32_t& eval) {
+  if (l3 == 255) { ebits = 0; eval = 0; return 285; }
+  if (l3 < 8) { ebits = 0; eval = 0; return 257 + l3; }
+  const uint32_t e = (31 - __builtin_clz(l3)) - 2;
+  ebits = e;
+  eval = l3 & ((1u << e) - 1);
+  return 257 + 4 * e + 4 + ((l3 >> e) & 3);
+}
+// d1 = dist-1 in [0,32767] -> distance symbol, extra-bit count, extra value
+__device__ __forceinline__ uint32_t dist_symbol(uint32_t d1, uint32_t& ebits, uint32_t& eval) {
+  if (d1 < 4) { ebits = 0; eval = 0; return d1; }
+  const uint32_t hb = 31 - __builtin_clz(d1);
+  const uint32_t e = hb - 1;
+  ebits = e;
+  eval = d1 & ((1u << e) - 1);
+  return 2 * hb + ((d1 >> e) & 1);
+}
+__device__ __forceinline__ uint32_t len_extra_of_sym(uint32_t k /*sym-257*/) {
+  return (k < 8 || k == 28) ? 0 : (k - 4) >> 2;
+}
+__device__ __forceinline__ uint32_t dist_extra_of_sym(uint32_t s) { return s < 4 ? 0 : (s - 2) >> 1; }
+__device__ __forceinline__ uint32_t fixed_ll_len(uint32_t s) {
+  return s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t u = __shfl_up(v, o, 64);
+    if (lane >= (uint32_t)o) v += u;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per chunk.
+// ---------------------------------------------------------------------------
+constexpr uint32_t K1_THREADS = kStep;
+constexpr uint32_t K1_WAVES = K1_THREADS / 64;
+constexpr uint32_t kSegs = kChunk / 64;
+// LDS carve (bytes); every offset is a multiple of 16
+constexpr uint32_t L_DATA = 0;                              // u32[8192+4]
+constexpr uint32_t L_LEN8 = L_DATA + kChunk + 16;           // u8[32768]   len-3, 0 = no match
+constexpr uint32_t L_DIST = L_LEN8 + kChunk;                // u16[32768]
+constexpr uint32_t L_TABLE = L_DIST + 2 * kChunk;           // u32[1<<kHashBits]
+constexpr uint32_t L_HIST = L_TABLE + (4u << kHashBits);    // u32[320]
+constexpr uint32_t L_MARKS = L_HIST + 4 * kHistStride;      // u64[512] chain positions per segment
+constexpr uint32_t L_MM = L_MARKS + 8 * kSegs;              // u64[512] chain positions that are matches
+constexpr uint32_t L_SEGPRE = L_MM + 8 * kSegs;             // u16[512] tokens before segment, in region
+constexpr uint32_t L_REGCNT = L_SEGPRE + 2 * kSegs;         // u32[16]
+constexpr uint32_t K1_LDS = L_REGCNT + 4 * kRegionsPerChunk;
+static_assert(K1_LDS <= 160 * 1024, "K1 LDS budget");
+static_assert(L_MARKS % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0, "LDS alignment");
+
+__device__ __forceinline__ uint32_t lds_load4(const uint32_t* d32, uint32_t a) {
+  const uint32_t w = a >> 2;
+  return __builtin_amdgcn_alignbyte(d32[w + 1], d32[w], a & 3);
+}
+
+// common prefix length of data[i..] and data[c..], capped at maxlen
+__device__ __forceinline__ uint32_t match_len(const uint32_t* d32, uint32_t i, uint32_t c,
+                                              uint32_t maxlen) {
+  uint32_t ia = i >> 2, ca = c >> 2;
+  const uint32_t ish = i & 3, csh = c & 3;
+  uint32_t ilo = d32[ia], clo = d32[ca];
+  uint32_t l = 0;
+  while (l < maxlen) {
+    const uint32_t ihi = d32[++ia], chi = d32[++ca];
+    const uint32_t x =
+        __builtin_amdgcn_alignbyte(ihi, ilo, ish) ^ __builtin_amdgcn_alignbyte(chi, clo, csh);
+    if (x) {
+      l += (uint32_t)__builtin_ctz(x) >> 3;
+      break;
+    }
+    l += 4;
+    ilo = ihi;
+    clo = chi;
+  }
+  return l < maxlen ? l : maxlen;
+}
+
+__global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
+                                                     uint32_t* __restrict__ tokens,
+                                                     uint32_t* __restrict__ ntok_out,
+                                                     uint32_t* __restrict__ hist_out, uint32_t lazy) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* s_data = reinterpret_cast<uint32_t*>(smem + L_DATA);
+  uint8_t* s_bytes = smem + L_DATA;
+  uint8_t* s_len8 = smem + L_LEN8;
+  uint16_t* s_dist = reinterpret_cast<uint16_t*>(smem + L_DIST);
+  uint32_t* s_table = reinterpret_cast<uint32_t*>(smem + L_TABLE);
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + L_HIST);
+  uint64_t* s_marks = reinterpret_cast<uint64_t*>(smem + L_MARKS);
+  uint64_t* s_mm = reinterpret_cast<uint64_t*>(smem + L_MM);
+  uint16_t* s_segpre = reinterpret_cast<uint16_t*>(smem + L_SEGPRE);
+  uint32_t* s_regcnt = reinterpret_cast<uint32_t*>(smem + L_REGCNT);
+
+  const uint32_t t = threadIdx.x;
+  const uint32_t chunk = blockIdx.x;
+  const uint64_t base = (uint64_t)chunk * kChunk;
+  const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kChunk ? (n_total - base) : kChunk);
+
+  // ---- stage the chunk: coalesced 16 B per lane, zero beyond n ----
+  {
+    const uint4* g = reinterpret_cast<const uint4*>(src + base);
+    uint4* s4 = reinterpret_cast<uint4*>(smem + L_DATA);
+#pragma unroll
+    for (uint32_t k = 0; k < kChunk / 16 / K1_THREADS; ++k) {
+      const uint32_t idx = t + k * K1_THREADS;
+      const uint32_t off = idx * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (off + 16 <= n) {
+        v = g[idx];
+      } else if (off < n) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t b = 0; off + b < n; ++b) w[b >> 2] |= (uint32_t)src[base + off + b] << (8 * (b & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      s4[idx] = v;
+    }
+    if (t < 4) s_data[kChunk / 4 + t] = 0;
+    uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
+    for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) t4[idx] = make_uint4(0, 0, 0, 0);
+    if (t < kHistStride) s_hist[t] = (t == 256) ? 1u : 0u;
+  }
+  __syncthreads();
+
+  // ---- match finding: steps of kStep consecutive positions ----
+  const uint32_t nsteps = (n + kStep - 1) / kStep;
+  for (uint32_t s = 0; s < nsteps; ++s) {
+    const uint32_t i = s * kStep + t;
+    const bool elig = i + kMinMatch <= n;
+    const uint32_t v = lds_load4(s_data, i);
+    const uint32_t h = (v * 2654435761u) >> (32 - kHashBits);
+    const uint32_t farv = elig ? s_table[h] : 0u;
+    __syncthreads();  // every far read of this step precedes every insertion of this step
+    if (elig) atomicMax(&s_table[h], ((s + 1) << 12) | (4095u - t));
+    __syncthreads();  // insertions complete before the near reads
+    uint32_t best = 0, bdist = 0;
+    if (elig) {
+      const uint32_t nearv = s_table[h];
+      const uint32_t nearp = ((nearv >> 12) - 1) * kStep + (4095u - (nearv & 4095u));
+      const uint32_t rend = (i & ~(kRegion - 1)) + kRegion;
+      uint32_t maxlen = n - i < 258u ? n - i : 258u;
+      if (rend - i < maxlen) maxlen = rend - i;
+      if (nearp < i) {
+        best = match_len(s_data, i, nearp, maxlen);
+        bdist = i - nearp;
+      }
+      if (farv) {
+        const uint32_t farp = ((farv >> 12) - 1) * kStep + (4095u - (farv & 4095u));
+        const uint32_t l = match_len(s_data, i, farp, maxlen);
+        if (l > best) {
+          best = l;
+          bdist = i - farp;
+        }
+      }
+      if (best < kMinMatch) best = 0;
+    }
+    if (i < n) {
+      s_len8[i] = (uint8_t)(best ? best - 3 : 0);
+      s_dist[i] = (uint16_t)bdist;
+    }
+  }
+  __syncthreads();
+
+  // ---- parse pass 1: one wave per region walks the greedy/lazy chain ----
+  const uint32_t wave = t >> 6, lane = t & 63;
+  const uint64_t lt_mask = (1ull << lane) - 1;
+  const uint32_t nreg = (n + kRegion - 1) / kRegion;
+  for (uint32_t r = wave; r < kRegionsPerChunk; r += K1_WAVES) {
+    const uint32_t rbase = r * kRegion;
+    const uint32_t rend = rbase + kRegion < n ? rbase + kRegion : n;
+    uint32_t entry = 0, count = 0;
+    for (uint32_t seg = rbase; seg < rbase + kRegion; seg += 64) {
+      const uint32_t sg = seg >> 6;
+      if (r >= nreg || seg >= rend) {
+        if (lane == 0) { s_marks[sg] = 0; s_mm[sg] = 0; s_segpre[sg] = (uint16_t)count; }
+        continue;
+      }
+      const uint32_t p = seg + lane;
+      const bool valid = p < rend;
+      const uint32_t l8 = valid ? s_len8[p] : 0u;
+      const uint32_t nl8 = (p + 1 < rend) ? s_len8[p + 1] : 0u;
+      const bool take = l8 != 0 && !(lazy && nl8 > l8);
+      const uint64_t M = __ballot(take);
+      const uint64_t V = __ballot(valid);
+      const uint32_t len = l8 + 3;
+      uint64_t marks = 0;
+      uint32_t pos = entry;
+      while (pos < 64) {
+        const uint64_t ge = ~0ull << pos;
+        const uint64_t rest = M & ge;
+        if (!rest) {
+          marks |= ge;
+          pos = 64;
+          break;
+        }
+        const uint32_t q = (uint32_t)__builtin_ctzll(rest);
+        marks |= ge & ((2ull << q) - 1);
+        pos = q + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)q);
+      }
+      entry = pos - 64;
+      marks &= V;
+      if (lane == 0) {
+        s_marks[sg] = marks;
+        s_mm[sg] = marks & M;
+        s_segpre[sg] = (uint16_t)count;
+      }
+      count += (uint32_t)__popcll(marks);
+    }
+    if (lane == 0) s_regcnt[r] = count;
+  }
+  __syncthreads();
+
+  // ---- parse pass 2: every wave turns its region's chain positions into tokens ----
+  uint32_t total = 0;
+  for (uint32_t r = 0; r < kRegionsPerChunk; ++r) total += s_regcnt[r];
+  for (uint32_t r = wave; r < nreg; r += K1_WAVES) {
+    uint32_t rpre = 0;
+    for (uint32_t q = 0; q < r; ++q) rpre += s_regcnt[q];
+    uint32_t* tk = tokens + (uint64_t)chunk * kChunk + rpre;
+    for (uint32_t sg = r * (kRegion / 64); sg < (r + 1) * (kRegion / 64); ++sg) {
+      const uint64_t marks = s_marks[sg];
+      if (!marks) continue;
+      const uint64_t mm = s_mm[sg];
+      if ((marks >> lane) & 1) {
+        const uint32_t p = sg * 64 + lane;
+        const uint32_t idx = s_segpre[sg] + (uint32_t)__popcll(marks & lt_mask);
+        uint32_t tok;
+        if ((mm >> lane) & 1) {
+          const uint32_t l3 = s_len8[p], d1 = (uint32_t)s_dist[p] - 1;
+          tok = kTokMatch | (l3 << 16) | d1;
+          uint32_t eb, ev;
+          atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
+          atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
+        } else {
+          tok = s_bytes[p];
+          atomicAdd(&s_hist[tok], 1u);
+        }
+        tk[idx] = tok;
+      }
+    }
+  }
+  __syncthreads();
+  if (t < kHistStride) hist_out[(uint64_t)chunk * kHistStride + t] = s_hist[t];
+  if (t == 0) ntok_out[chunk] = total;
+}
+
+// ---------------------------------------------------------------------------
+// K2: per-chunk code plan.  One wave (64-thread workgroup) per chunk.
+// ---------------------------------------------------------------------------
+struct PlanSmem {
+  uint32_t freq[kHistStride];
+  uint32_t ukey[288];
+  uint32_t key[288];
+  uint32_t w[576];
+  uint16_t parent[576];
+  uint32_t cnt[16];
+  uint8_t lens[320];  // ll [0..287], d [288..319]
+  uint8_t cl_lens[32];
+  uint32_t cl_code[32];
+  uint32_t clfreq[32];
+  uint8_t rle_sym[320];
+  uint8_t rle_ext[320];
+  uint32_t header[kHeaderWords];
+  uint32_t misc[8];
+};
+
+// Length-limited Huffman code lengths; all 64 lanes call it.  Specification:
+// oracle/sf_oracle.c sfo_build_lengths (two-queue Huffman, clamp, Kraft repair,
+// lengths dealt longest-first to the rarest symbols).
+__device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uint32_t maxbits,
+                              uint8_t* lens, uint32_t lane) {
+  uint32_t mloc = 0;
+  for (uint32_t s = lane; s < 288; s += 64) {
+    const uint32_t f = s < n ? freq[s] : 0u;
+    S.ukey[s] = f ? ((f << 9) | s) : 0xFFFFFFFFu;
+    if (s < n) lens[s] = 0;
+    mloc += f != 0;
+  }
+  if (lane < 16) S.cnt[lane] = 0;
+  const uint32_t m = wave_sum(mloc);
+  __syncthreads();
+  if (m == 0) return;
+  if (m == 1) {
+    for (uint32_t s = lane; s < n; s += 64)
+      if (S.ukey[s] != 0xFFFFFFFFu) lens[s] = 1;
+    __syncthreads();
+    return;
+  }
+  // rank sort ascending by (freq, symbol)
+  for (uint32_t s = lane; s < n; s += 64) {
+    const uint32_t k = S.ukey[s];
+    if (k != 0xFFFFFFFFu) {
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < n; ++j) r += S.ukey[j] < k;
+      S.key[r] = k;
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = lane; k < m; k += 64) S.w[k] = S.key[k] >> 9;
+  __syncthreads();
+  // two-queue merge (serial; leaves first on ties)
+  if (lane == 0) {
+    const uint32_t INF = 0xFFFFFFFFu;
+    uint32_t i = 0, j = m, k = m;
+    uint32_t wi = S.w[0], wj = INF;
+    while (k < 2 * m - 1) {
+      uint32_t a, b, wa, wb;
+      if (wi <= wj) { a = i++; wa = wi; wi = i < m ? S.w[i] : INF; }
+      else          { a = j++; wa = wj; wj = j < k ? S.w[j] : INF; }
+      if (wi <= wj) { b = i++; wb = wi; wi = i < m ? S.w[i] : INF; }
+      else          { b = j++; wb = wj; wj = j < k ? S.w[j] : INF; }
+      S.w[k] = wa + wb;
+      S.parent[a] = (uint16_t)k;
+      S.parent[b] = (uint16_t)k;
+      if (j == k) wj = wa + wb;
+      ++k;
+    }
+  }
+  __syncthreads();
+  // leaf depths, clamped histogram
+  const uint32_t root = 2 * m - 2;
+  for (uint32_t k = lane; k < m; k += 64) {
+    uint32_t d = 0, v = k;
+    while (v != root) { v = S.parent[v]; ++d; }
+    atomicAdd(&S.cnt[d < maxbits ? d : maxbits], 1u);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int32_t over = -(1 << maxbits);
+    for (uint32_t l = 1; l <= maxbits; ++l) over += (int32_t)(S.cnt[l] << (maxbits - l));
+    while (over > 0) {
+      uint32_t l = maxbits - 1;
+      while (S.cnt[l] == 0) --l;
+      S.cnt[l]--;
+      S.cnt[l + 1]++;
+      over -= 1 << (maxbits - l - 1);
+    }
+    while (over < 0) {
+      S.cnt[maxbits]--;
+      S.cnt[maxbits - 1]++;
+      ++over;
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = lane; k < m; k += 64) {
+    uint32_t c = 0, l = maxbits;
+    for (; l >= 1; --l) {
+      c += S.cnt[l];
+      if (k < c) break;
+    }
+    lens[S.key[k] & 511u] = (uint8_t)l;
+  }
+  __syncthreads();
+}
+
+// canonical codes (RFC 1951 3.2.2 == huffman::table::canonicalize,
+// /root/reference/huffman/src/table.hpp:177-216), stored bit-reversed because the
+// decoder shifts code bits in MSB-first (huffman/src/decode.hpp:90-91).
+// out[s] = reversed code | len << 16.  n <= 320, all lanes call it.
+__device__ void canonical_codes(const uint8_t* lens, uint32_t n, uint32_t* out, uint32_t lane) {
+  uint32_t base[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) base[l] = 0;
+  uint32_t rank[5], mylen[5];
+#pragma unroll
+  for (uint32_t g = 0; g < 5; ++g) {
+    const uint32_t s = g * 64 + lane;
+    const uint32_t len = (g * 64 < n && s < n) ? lens[s] : 0u;
+    mylen[g] = len;
+    rank[g] = 0;
+    if (g * 64 < n) {
+#pragma unroll
+      for (uint32_t l = 1; l < 16; ++l) {
+        const uint64_t mask = __ballot(len == l);
+        if (len == l) rank[g] = base[l] + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+        base[l] += (uint32_t)__popcll(mask);
+      }
+    }
+  }
+  uint32_t next[16];
+  uint32_t code = 0;
+  next[0] = 0;
+#pragma unroll
+  for (int l = 1; l < 16; ++l) {
+    code = (code + (l > 1 ? base[l - 1] : 0u)) << 1;
+    next[l] = code;
+  }
+#pragma unroll
+  for (uint32_t g = 0; g < 5; ++g) {
+    const uint32_t s = g * 64 + lane;
+    if (s < n) {
+      uint32_t v = 0;
+      const uint32_t len = mylen[g];
+      if (len) {
+        uint32_t nx = 0;
+#pragma unroll
+        for (uint32_t l = 1; l < 16; ++l)
+          if (len == l) nx = next[l];
+        const uint32_t c = nx + rank[g];
+        v = (__brev(c) >> (32 - len)) | (len << 16);
+      }
+      out[s] = v;
+    }
+  }
+}
+
+// RLE of one code-length sequence (own state per sequence: the reference decoder
+// reads HLIT and HDIST sequences with separate vectors, src/decompress.cpp:353-360,
+// and never bounds-checks a run, :277-296).
+__device__ uint32_t rle_lengths(const uint8_t* lens, uint32_t n, uint8_t* sym, uint8_t* ext) {
+  uint32_t k = 0, i = 0;
+  while (i < n) {
+    const uint8_t v = lens[i];
+    uint32_t r = 1;
+    while (i + r < n && lens[i + r] == v) ++r;
+    i += r;
+    if (v == 0) {
+      while (r >= 11) { const uint32_t c = r < 138 ? r : 138; sym[k] = 18; ext[k++] = (uint8_t)(c - 11); r -= c; }
+      if (r >= 3) { sym[k] = 17; ext[k++] = (uint8_t)(r - 3); r = 0; }
+      while (r) { sym[k] = 0; ext[k++] = 0; --r; }
+    } else {
+      sym[k] = v; ext[k++] = 0; --r;
+      while (r >= 3) { const uint32_t c = r < 6 ? r : 6; sym[k] = 16; ext[k++] = (uint8_t)(c - 3); r -= c; }
+      while (r) { sym[k] = v; ext[k++] = 0; --r; }
+    }
+  }
+  return k;
+}
+
+__constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
+                                             const uint32_t* __restrict__ hist,
+                                             ChunkPlan* __restrict__ plan, ChunkCodes* __restrict__ codes,
+                                             uint32_t strategy, uint32_t final_stream) {
+  __shared__ PlanSmem S;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t chunk = blockIdx.x;
+  const uint64_t cbase = (uint64_t)chunk * kChunk;
+  const uint32_t n_raw = (uint32_t)((n_total - cbase) < (uint64_t)kChunk ? (n_total - cbase) : kChunk);
+  const bool fin = (chunk + 1 == nchunks) && final_stream;
+
+  for (uint32_t s = lane; s < kHistStride; s += 64) S.freq[s] = hist[(uint64_t)chunk * kHistStride + s];
+  for (uint32_t s = lane; s < 320; s += 64) S.lens[s] = 0;
+  __syncthreads();
+
+  build_lengths(S, S.freq, 286, 15, S.lens, lane);
+  build_lengths(S, S.freq + kHistD, 30, 15, S.lens + 288, lane);
+
+  // body costs
+  uint32_t dyn = 0, fix = 0, extra = 0, nmatch = 0;
+  for (uint32_t s = lane; s < 286; s += 64) {
+    const uint32_t f = S.freq[s];
+    dyn += f * S.lens[s];
+    fix += f * fixed_ll_len(s);
+    if (s >= 257) extra += f * len_extra_of_sym(s - 257);
+  }
+  if (lane < 30) {
+    const uint32_t f = S.freq[kHistD + lane];
+    dyn += f * S.lens[288 + lane];
+    extra += f * dist_extra_of_sym(lane);
+    nmatch += f;
+  }
+  dyn = wave_sum(dyn);
+  fix = wave_sum(fix);
+  extra = wave_sum(extra);
+  nmatch = wave_sum(nmatch);
+  const uint32_t dyn_body = dyn + extra;
+  const uint32_t fix_body = fix + extra + 5 * nmatch;
+
+  // dynamic header: HLIT/HDIST, RLE, code-length code
+  if (lane < 32) S.clfreq[lane] = 0;
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t hlit = 286, hdist = 30;
+    while (hlit > 257 && S.lens[hlit - 1] == 0) --hlit;
+    while (hdist > 1 && S.lens[288 + hdist - 1] == 0) --hdist;
+    const uint32_t nl = rle_lengths(S.lens, hlit, S.rle_sym, S.rle_ext);
+    const uint32_t nd = rle_lengths(S.lens + 288, hdist, S.rle_sym + nl, S.rle_ext + nl);
+    for (uint32_t k = 0; k < nl + nd; ++k) S.clfreq[S.rle_sym[k]]++;
+    S.misc[0] = hlit;
+    S.misc[1] = hdist;
+    S.misc[2] = nl + nd;
+  }
+  __syncthreads();
+  build_lengths(S, S.clfreq, 19, 7, S.cl_lens, lane);
+  canonical_codes(S.cl_lens, 19, S.cl_code, lane);
+  __syncthreads();
+  if (lane == 0) {
+    const uint32_t hlit = S.misc[0], hdist = S.misc[1], nitems = S.misc[2];
+    uint32_t hclen = 19;
+    while (hclen > 4 && S.cl_lens[c_cl_order[hclen - 1]] == 0) --hclen;
+    uint64_t acc = 0;
+    uint32_t nb = 0, wpos = 0;
+    auto put = [&](uint32_t v, uint32_t n) {
+      acc |= (uint64_t)v << nb;
+      nb += n;
+      if (nb >= 32) {
+        S.header[wpos++] = (uint32_t)acc;
+        acc >>= 32;
+        nb -= 32;
+      }
+    };
+    put(fin ? 1u : 0u, 1);
+    put(2, 2);
+    put(hlit - 257, 5);
+    put(hdist - 1, 5);
+    put(hclen - 4, 4);
+    for (uint32_t k = 0; k < hclen; ++k) put(S.cl_lens[c_cl_order[k]], 3);
+    for (uint32_t k = 0; k < nitems; ++k) {
+      const uint32_t sy = S.rle_sym[k];
+      const uint32_t c = S.cl_code[sy];
+      put(c & 0xFFFF, c >> 16);
+      if (sy == 16) put(S.rle_ext[k], 2);
+      else if (sy == 17) put(S.rle_ext[k], 3);
+      else if (sy == 18) put(S.rle_ext[k], 7);
+    }
+    const uint32_t hbits = wpos * 32 + nb;
+    if (nb) S.header[wpos++] = (uint32_t)acc;
+    S.misc[3] = hbits;  // includes the 3 block-header bits
+  }
+  __syncthreads();
+
+  const uint32_t dyn_hbits = S.misc[3];
+  const uint32_t dyn_bits = dyn_hbits + dyn_body;
+  const uint32_t fix_bits = 3 + fix_body;
+  const uint32_t dyn_bytes = fin ? (dyn_bits + 7) / 8 : (dyn_bits + 3 + 7) / 8 + 4;
+  const uint32_t fix_bytes = fin ? (fix_bits + 7) / 8 : (fix_bits + 3 + 7) / 8 + 4;
+  const uint32_t sto_bytes = n_raw + 5;
+  uint32_t bt;
+  if (strategy == 1) bt = 0;
+  else if (strategy == 2) bt = 1;
+  else if (strategy == 3) bt = 2;
+  else {
+    bt = 0;
+    uint32_t best = sto_bytes;
+    if (fix_bytes < best) { bt = 1; best = fix_bytes; }
+    if (dyn_bytes < best) { bt = 2; best = dyn_bytes; }
+  }
+
+  ChunkCodes& C = codes[chunk];
+  for (uint32_t s = lane; s < 320; s += 64) C.lens[s] = S.lens[s];  // dynamic lengths, for parity tests
+  __syncthreads();
+  if (bt == 1) {
+    for (uint32_t s = lane; s < 320; s += 64) S.lens[s] = s < 288 ? (uint8_t)fixed_ll_len(s) : (uint8_t)5;
+    if (lane == 0) S.header[0] = (fin ? 1u : 0u) | (1u << 1);
+    __syncthreads();
+  } else if (bt == 0) {
+    if (lane == 0) S.header[0] = fin ? 1u : 0u;
+    __syncthreads();
+  }
+  canonical_codes(S.lens, 288, C.lcode, lane);
+  canonical_codes(S.lens + 288, 32, C.dcode, lane);
+  const uint32_t hbits = bt == 2 ? dyn_hbits : 3;
+  for (uint32_t k = lane; k < (hbits + 31) / 32; k += 64) C.header[k] = S.header[k];
+  if (lane == 0) {
+    ChunkPlan P;
+    P.btype = bt;
+    P.out_bytes = bt == 0 ? sto_bytes : bt == 1 ? fix_bytes : dyn_bytes;
+    P.header_bits = hbits;
+    P.body_bits = bt == 1 ? fix_body : dyn_body;
+    plan[chunk] = P;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: exclusive scan of chunk sizes (single workgroup).
+// ---------------------------------------------------------------------------
+constexpr uint32_t K3_THREADS = 1024;
+__global__ __launch_bounds__(K3_THREADS) void k_scan(uint32_t nchunks, const ChunkPlan* __restrict__ plan,
+                                                     uint64_t* __restrict__ offsets,
+                                                     uint64_t* __restrict__ total) {
+  __shared__ uint64_t s_part[K3_THREADS];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (nchunks + K3_THREADS - 1) / K3_THREADS;
+  const uint32_t b = t * per, e = (b + per < nchunks) ? b + per : nchunks;
+  uint64_t sum = 0;
+  for (uint32_t c = b; c < e; ++c) sum += plan[c].out_bytes;
+  s_part[t] = sum;
+  __syncthreads();
+  for (uint32_t o = 1; o < K3_THREADS; o <<= 1) {
+    const uint64_t u = t >= o ? s_part[t - o] : 0;
+    __syncthreads();
+    s_part[t] += u;
+    __syncthreads();
+  }
+  uint64_t run = s_part[t] - sum;
+  for (uint32_t c = b; c < e; ++c) {
+    offsets[c] = run;
+    run += plan[c].out_bytes;
+  }
+  if (t == K3_THREADS - 1) *total = s_part[t];
+}
+
+// ---------------------------------------------------------------------------
+// K4: emit.  One workgroup per chunk; bits are OR-ed into an LDS image of the chunk's
+// output whose dword k maps onto the aligned global dword (offset>>2)+k.
+// ---------------------------------------------------------------------------
+constexpr uint32_t K4_THREADS = 512;
+constexpr uint32_t K4_WAVES = K4_THREADS / 64;
+constexpr uint32_t K4_TPT = 4;  // tokens per thread per batch
+constexpr uint32_t K4_STAGE_WORDS = 10240;  // 40 KiB: fixed-Huffman worst case of a 32 KiB chunk + align
+
+__device__ __forceinline__ void or_bits(uint32_t* stage, uint32_t bitpos, uint64_t value) {
+  const uint32_t w = bitpos >> 5, sh = bitpos & 31;
+  const uint64_t v0 = value << sh;
+  const uint32_t v2 = sh ? (uint32_t)(value >> (64 - sh)) : 0u;
+  const uint32_t lo = (uint32_t)v0, mid = (uint32_t)(v0 >> 32);
+  if (lo) atomicOr(&stage[w], lo);
+  if (mid) atomicOr(&stage[w + 1], mid);
+  if (v2) atomicOr(&stage[w + 2], v2);
+}
+
+__device__ __forceinline__ void token_bits(uint32_t tok, const uint32_t* lcode, const uint32_t* dcode,
+                                           uint64_t& value, uint32_t& nb) {
+  if (tok & kTokMatch) {
+    uint32_t le, lv, de, dv;
+    const uint32_t ls = len_symbol((tok >> 16) & 0xFF, le, lv);
+    const uint32_t ds = dist_symbol(tok & 0x7FFF, de, dv);
+    const uint32_t lc = lcode[ls], dc = dcode[ds];
+    uint32_t p = lc >> 16;
+    uint64_t v = lc & 0xFFFF;
+    v |= (uint64_t)lv << p;
+    p += le;
+    v |= (uint64_t)(dc & 0xFFFF) << p;
+    p += dc >> 16;
+    v |= (uint64_t)dv << p;
+    p += de;
+    value = v;
+    nb = p;
+  } else {
+    const uint32_t lc = lcode[tok & 0xFF];
+    value = lc & 0xFFFF;
+    nb = lc >> 16;
+  }
+}
+
+__global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__ src, uint64_t n_total,
+                                                     uint32_t /*nchunks*/, const uint32_t* __restrict__ tokens,
+                                                     const uint32_t* __restrict__ ntok_in,
+                                                     const ChunkPlan* __restrict__ plan,
+                                                     const ChunkCodes* __restrict__ codes,
+                                                     const uint64_t* __restrict__ offsets,
+                                                     uint8_t* __restrict__ dst) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[K4_STAGE_WORDS];
+  __shared__ uint32_t s_lcode[288];
+  __shared__ uint32_t s_dcode[32];
+  __shared__ uint32_t s_wtot[2][K4_WAVES];
+
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t chunk = blockIdx.x;
+  const ChunkPlan P = plan[chunk];
+  const uint64_t off = offsets[chunk];
+  const uint64_t cbase = (uint64_t)chunk * kChunk;
+  const uint32_t n_raw = (uint32_t)((n_total - cbase) < (uint64_t)kChunk ? (n_total - cbase) : kChunk);
+  const ChunkCodes& C = codes[chunk];
+
+  if (P.btype == 0) {
+    // stored block: BFINAL/BTYPE byte, LEN, NLEN, raw bytes (src/decompress.cpp:416-436 inverse)
+    uint8_t* o = dst + off;
+    if (t == 0) {
+      o[0] = (uint8_t)(C.header[0] & 1u);
+      o[1] = (uint8_t)(n_raw & 0xFF);
+      o[2] = (uint8_t)(n_raw >> 8);
+      o[3] = (uint8_t)(~n_raw & 0xFF);
+      o[4] = (uint8_t)((~n_raw >> 8) & 0xFF);
+    }
+    uint8_t* d = o + 5;
+    const uint8_t* sp = src + cbase;  // 32 KiB aligned
+    const uint32_t head = (uint32_t)((4 - ((uintptr_t)d & 3)) & 3);
+    const uint32_t h = head < n_raw ? head : n_raw;
+    if (t < h) d[t] = sp[t];
+    const uint32_t nd = (n_raw - h) / 4;
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(d + h);
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(sp);
+    const uint32_t full_src_words = n_raw / 4;  // dwords entirely inside the chunk
+    for (uint32_t k = t; k < nd; k += K4_THREADS) {
+      const uint32_t ob = h + 4 * k;  // source byte offset; ob & 3 == h & 3
+      const uint32_t w = ob >> 2;
+      uint32_t lo = s32[w], hi = 0;
+      if ((ob & 3) != 0) {
+        if (w + 1 < full_src_words) hi = s32[w + 1];
+        else
+          for (uint32_t b = 0; b < 4 && 4 * (w + 1) + b < n_raw; ++b) hi |= (uint32_t)sp[4 * (w + 1) + b] << (8 * b);
+      }
+      d32[k] = __builtin_amdgcn_alignbyte(hi, lo, ob & 3);
+    }
+    const uint32_t done = h + 4 * nd;
+    if (t < n_raw - done) d[done + t] = sp[done + t];
+    return;
+  }
+
+  const uint32_t sh = (uint32_t)(off & 3);
+  const uint32_t nwords = (sh + P.out_bytes + 3) / 4;
+  for (uint32_t k = t; k < nwords + 2 && k < K4_STAGE_WORDS; k += K4_THREADS) s_stage[k] = 0;
+  if (t < 288) s_lcode[t] = C.lcode[t];
+  if (t < 32) s_dcode[t] = C.dcode[t];
+  __syncthreads();
+  {
+    uint8_t* sb = reinterpret_cast<uint8_t*>(s_stage) + sh;
+    const uint8_t* hb = reinterpret_cast<const uint8_t*>(C.header);
+    const uint32_t hbytes = (P.header_bits + 7) / 8;
+    for (uint32_t k = t; k < hbytes; k += K4_THREADS) sb[k] = hb[k];
+  }
+  __syncthreads();
+
+  const uint32_t ntok = ntok_in[chunk];
+  const uint32_t* tk = tokens + (uint64_t)chunk * kChunk;
+  uint32_t running = 8 * sh + P.header_bits;
+  uint32_t buf = 0;
+  for (uint32_t b0 = 0; b0 < ntok; b0 += K4_THREADS * K4_TPT, buf ^= 1) {
+    const uint32_t i0 = b0 + t * K4_TPT;
+    uint32_t tok[K4_TPT];
+    if (i0 + K4_TPT <= ntok) {
+      const uint4 q = *reinterpret_cast<const uint4*>(tk + i0);
+      tok[0] = q.x; tok[1] = q.y; tok[2] = q.z; tok[3] = q.w;
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < K4_TPT; ++k) tok[k] = i0 + k < ntok ? tk[i0 + k] : 0u;
+    }
+    uint64_t val[K4_TPT];
+    uint32_t nb[K4_TPT], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < K4_TPT; ++k) {
+      if (i0 + k < ntok) token_bits(tok[k], s_lcode, s_dcode, val[k], nb[k]);
+      else { val[k] = 0; nb[k] = 0; }
+      mine += nb[k];
+    }
+    const uint32_t incl = wave_incl_scan(mine, lane);
+    if (lane == 63) s_wtot[buf][wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < K4_WAVES; ++w) {
+      const uint32_t v = s_wtot[buf][w];
+      if (w < wave) pre += v;
+      all += v;
+    }
+    uint32_t pos = running + pre + incl - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < K4_TPT; ++k) {
+      if (nb[k]) or_bits(s_stage, pos, val[k]);
+      pos += nb[k];
+    }
+    running += all;
+  }
+  __syncthreads();
+  if (t == 0) {
+    // end of block, then (unless this is the stream's final block) an empty stored
+    // block 000 / pad / 00 00 FF FF to byte-align the next chunk
+    const uint32_t eob = s_lcode[256];
+    or_bits(s_stage, running, eob & 0xFFFF);
+    const uint32_t endbit = running + (eob >> 16);
+    if (!(C.header[0] & 1u)) {
+      const uint32_t byte = (endbit + 3 + 7) / 8;  // relative to the stage start (sh included)
+      or_bits(s_stage, 8 * (byte + 2), 0xFFFFull);
+    }
+  }
+  __syncthreads();
+
+  // flush: interior dwords coalesced, the two edge dwords bytewise (neighbouring
+  // chunks own the other bytes of those dwords)
+  uint8_t* gbase = dst + (off - sh);
+  uint32_t* g32 = reinterpret_cast<uint32_t*>(gbase);
+  const uint32_t lo_b = sh, hi_b = sh + P.out_bytes;
+  for (uint32_t w = t; w < nwords; w += K4_THREADS) {
+    const uint32_t v = s_stage[w];
+    if (4 * w >= lo_b && 4 * w + 4 <= hi_b) {
+      g32[w] = v;
+    } else {
+#pragma unroll
+      for (uint32_t b = 0; b < 4; ++b) {
+        const uint32_t idx = 4 * w + b;
+        if (idx >= lo_b && idx < hi_b) gbase[idx] = (uint8_t)(v >> (8 * b));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+hipError_t init_kernels() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz77),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS);
+}
+
+hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
+                       const Options& opt, hipStream_t s) {
+  hipLaunchKernelGGL(k_lz77, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
+                     ws.hist, opt.lazy);
+  return hipGetLastError();
+}
+hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(k_plan, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.plan, ws.codes,
+                     opt.strategy, opt.final_stream);
+  return hipGetLastError();
+}
+hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t* d_total, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(K3_THREADS), 0, s, nchunks, ws.plan, ws.offsets, d_total);
+  return hipGetLastError();
+}
+hipError_t launch_emit(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
+                       uint8_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_emit, dim3(nchunks), dim3(K4_THREADS), 0, s, src, n, nchunks, ws.tokens, ws.ntok,
+                     ws.plan, ws.codes, ws.offsets, dst);
+  return hipGetLastError();
+}
+
+}  // namespace sf

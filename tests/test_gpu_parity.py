@@ -1,0 +1,117 @@
+"""GPU parity: the HIP pipeline (through the C-ABI) must be bit-exact equal to the
+CPU oracle's encoder specification, and every stream must round-trip through the
+oracle's restatement of the reference decoder (src/decompress.cpp:402-461) and
+through zlib inflate.  Integer/byte work: the bar is bit-exact."""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from starflate_amd import _capi, synth
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 32768
+
+
+def _params(strategy="auto", final_stream=True, lazy=True):
+    return O.default_params(strategy=_capi.STRATEGY[strategy], final_stream=int(final_stream), lazy=int(lazy))
+
+
+def _inputs(starfleet):
+    rng = np.random.default_rng(7)
+    text = synth.gen_text(200_000, seed=2)
+    return {
+        "empty": np.zeros(0, np.uint8),
+        "one": np.array([65], np.uint8),
+        "three": np.frombuffer(b"abc", np.uint8),
+        "tiny_rep": np.frombuffer(b"abcabcabcabcabcabcabcabcabc", np.uint8),
+        "zeros_1chunk": np.zeros(CHUNK, np.uint8),
+        "zeros_ragged": np.zeros(CHUNK * 2 + 777, np.uint8),
+        "text_1chunk": text[:CHUNK],
+        "text_ragged": text[: CHUNK * 5 + 1234],
+        "text_chunk_minus1": text[: CHUNK - 1],
+        "text_chunk_plus1": text[: CHUNK + 1],
+        "starfleet": np.frombuffer(starfleet, np.uint8),
+        "random": rng.integers(0, 256, CHUNK * 3 + 5, dtype=np.uint8),
+        "low_entropy": rng.integers(0, 4, CHUNK + 99, dtype=np.uint8),
+        "period7": np.tile(np.arange(7, dtype=np.uint8), 9000),
+        "mixed": synth.gen_mixed(3 << 20, seed=4, stripe=1 << 16)[: (1 << 20) + 13],
+    }
+
+
+def _roundtrip(stream, data):
+    st, w, out = O.decompress(stream, data.size)
+    assert st == 0, f"oracle decompress status {st}"
+    assert w == data.size and np.array_equal(out, data)
+    assert zlib.decompress(bytes(stream), -15) == data.tobytes()
+
+
+@pytest.mark.parametrize("strategy", ["auto", "stored", "fixed", "dynamic"])
+def test_bit_exact_vs_oracle(compressor, starfleet, strategy):
+    for name, data in _inputs(starfleet).items():
+        got = np.frombuffer(compressor.compress(data, strategy=strategy), np.uint8)
+        want = O.compress(data, _params(strategy))
+        _roundtrip(got, data)
+        assert got.size == want.size, f"{name}/{strategy}: size {got.size} != {want.size}"
+        assert np.array_equal(got, want), f"{name}/{strategy}: first diff at {np.flatnonzero(got != want)[:4]}"
+
+
+def test_stage_parity(compressor, starfleet):
+    """tokens / histogram / code lengths / plan of every chunk against the oracle stages."""
+    data = np.frombuffer(starfleet, np.uint8)
+    p = _params()
+    compressor.compress(data)
+    nchunks = (data.size + CHUNK - 1) // CHUNK
+    ntok = compressor.debug(_capi.DBG_NTOK, nchunks)
+    toks = compressor.debug(_capi.DBG_TOKENS, nchunks)
+    hist = compressor.debug(_capi.DBG_HIST, nchunks)
+    lens = compressor.debug(_capi.DBG_LENS, nchunks)
+    plan = compressor.debug(_capi.DBG_PLAN, nchunks)
+    for c in range(nchunks):
+        d = data[c * CHUNK:(c + 1) * CHUNK]
+        ln, ds = O.match_chunk(d, p)
+        t, nt = O.parse_chunk(d, p, ln, ds)
+        flat = np.concatenate([t[r * p.region_bytes: r * p.region_bytes + nt[r]] for r in range(nt.size)])
+        assert ntok[c] == flat.size, f"chunk {c}: ntok"
+        assert np.array_equal(toks[c, : flat.size], flat), f"chunk {c}: tokens"
+        ll, dd = O.histogram(t, nt, p.region_bytes)
+        assert np.array_equal(hist[c, :286], ll) and np.array_equal(hist[c, 288:318], dd), f"chunk {c}: hist"
+        pl = O.plan_chunk(ll, dd, d.size, c + 1 == nchunks, p)
+        assert np.array_equal(lens[c, :288], np.frombuffer(pl.ll_lens, np.uint8)), f"chunk {c}: ll lens"
+        assert np.array_equal(lens[c, 288:320], np.frombuffer(pl.d_lens, np.uint8)), f"chunk {c}: d lens"
+        assert plan[c, 0] == pl.btype and plan[c, 1] == pl.out_bytes, f"chunk {c}: plan {plan[c]} vs {pl.btype},{pl.out_bytes}"
+
+
+def test_device_tensor_path_and_shard_concat(compressor):
+    """Device-buffer entry point; two non-final/final shards concatenate into one valid stream."""
+    import torch
+
+    data = synth.gen_text(CHUNK * 6 + 321, seed=9)
+    src = torch.from_numpy(data).cuda()
+    out, n = compressor.compress_tensor(src)
+    whole = out[:n].cpu().numpy()
+    assert np.array_equal(whole, O.compress(data, _params()))
+    cut = CHUNK * 3
+    a, na = compressor.compress_tensor(src[:cut].clone(), final_stream=False)
+    a = a[:na].cpu().numpy()
+    b, nb = compressor.compress_tensor(src[cut:].clone(), final_stream=True)
+    b = b[:nb].cpu().numpy()
+    assert np.array_equal(a, O.compress(data[:cut], _params(final_stream=False)))
+    _roundtrip(np.concatenate([a, b]), data)
+
+
+def test_size_independent_properties_large(compressor):
+    """64 MiB: round trip through zlib inflate + determinism (same bytes on a second run)."""
+    import torch
+
+    data = synth.gen_text(64 << 20, seed=3)
+    src = torch.from_numpy(data).cuda()
+    out, n = compressor.compress_tensor(src)
+    s1 = out[:n].cpu().numpy().copy()
+    out2, n2 = compressor.compress_tensor(src)
+    assert n2 == n and torch.equal(out2[:n2], out[:n])
+    assert zlib.decompress(bytes(s1), -15) == data.tobytes()
+    offs = compressor.debug(_capi.DBG_OFFSETS, (data.size + CHUNK - 1) // CHUNK)
+    assert np.all(np.diff(offs.astype(np.int64)) > 0) and offs[0] == 0
