@@ -38,6 +38,14 @@ def lib():
         raise RuntimeError(
             f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
+    # process cannot both see the GPU.  Import torch first so that the DT_NEEDED
+    # libamdhip64.so.7 of our library binds to the copy torch has already loaded (a pure
+    # C/C++ host without torch gets /opt/rocm's through the library's RUNPATH).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp, sz = C.c_void_p, C.c_size_t
     L.sfh_default_options.argtypes = [C.POINTER(Options)]

@@ -1,0 +1,58 @@
+"""Multi-GPU: one process per GPU, contiguous shard per rank, streams concatenated
+on rank 0.  DEFLATE blocks are independent units (the reference decoder only
+requires distance <= bytes already written, /root/reference/src/decompress.cpp:178),
+so there is no data-path collective: the only exchange is the concatenation --
+an all_gather of one int64 size per rank, then one point-to-point send per rank
+into rank 0's output at its prefix offset (a gather-v; each transfer rides one
+xGMI link, no ring).  Works with backend "nccl" (= RCCL on ROCm) on CUDA tensors
+and with "gloo" on CPU tensors (tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world, chunk=32768):
+    """Contiguous shard [lo, hi) per rank, every boundary a multiple of the chunk size."""
+    nchunks = (n + chunk - 1) // chunk
+    per = (nchunks + world - 1) // world
+    return [(min(r * per * chunk, n), min((r + 1) * per * chunk, n)) for r in range(world)]
+
+
+def concat_streams(local, local_n, group=None, out=None):
+    """local: uint8 tensor holding this rank's byte-aligned stream in [0, local_n).
+    Returns (out, total) on rank 0 -- the rank-ordered concatenation -- and (None, total)
+    elsewhere.  `out` (rank 0) may be preallocated with >= total bytes."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local.device
+    mine = torch.tensor([int(local_n)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    total = sum(sizes)
+    if world == 1:
+        return local[:local_n], total
+    if rank == 0:
+        if out is None or out.numel() < total:
+            out = torch.empty(total, dtype=torch.uint8, device=dev)
+        out[: sizes[0]] = local[: sizes[0]]
+        ops, off = [], sizes[0]
+        for r in range(1, world):
+            if sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, out[off: off + sizes[r]], r, group=group))
+            off += sizes[r]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return out, total
+    if local_n:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:local_n].contiguous(), 0, group=group)]):
+            w.wait()
+    return None, total
+
+
+def compress_sharded(compressor, shard, group=None, out=None, scratch=None, **kw):
+    """Compress this rank's shard (BFINAL only on the last rank) and concatenate on rank 0."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    local, n = compressor.compress_tensor(shard, out=scratch, final_stream=(rank == world - 1), **kw)
+    return concat_streams(local, n, group=group, out=out)
