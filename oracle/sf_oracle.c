@@ -326,7 +326,7 @@ void sfo_default_params(sfo_params* p) {
   p->chunk_bytes = 32768;
   p->step = 1024;
   p->hash_bits = 12;
-  p->region_bytes = 2048;
+  p->region_bytes = 512;
   p->min_match = 4;
   p->lazy = 1;
   p->final_stream = 1;
@@ -335,6 +335,7 @@ void sfo_default_params(sfo_params* p) {
   p->use_near = 1;
   p->long_hash_bytes = 0;
   p->chain_depth = 0;
+  p->cap = 16;
 }
 
 static inline uint32_t load32(const uint8_t* p) {
@@ -446,6 +447,7 @@ void sfo_match_chunk(const uint8_t* src, uint32_t n, const sfo_params* p, uint16
       uint32_t rend = (i / R + 1) * R;
       uint32_t maxlen = n - i < 258 ? n - i : 258;
       if (rend - i < maxlen) maxlen = rend - i;
+      uint32_t cmplen = (p->cap && p->cap < maxlen) ? p->cap : maxlen;
       uint32_t best = 0, bdist = 0;
       for (uint32_t t = 0; t < NT; t++) {
         uint32_t need = t ? LB : MM;
@@ -461,7 +463,7 @@ void sfo_match_chunk(const uint8_t* src, uint32_t n, const sfo_params* p, uint16
           if (v) cand[nc++] = ent_pos(v, W);
         }
         for (uint32_t k = 0; k < nc; k++) {
-          uint32_t l = match_len(d, i, cand[k], maxlen), dist = i - cand[k];
+          uint32_t l = match_len(d, i, cand[k], cmplen), dist = i - cand[k];
           if (l > best || (l == best && l && dist < bdist)) { best = l; bdist = dist; }
         }
       }
@@ -487,6 +489,11 @@ void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
       int take = l >= MM;
       if (take && p->lazy && pos + 1 < end && len16[pos + 1] > l) take = 0;
       if (take) {
+        if (p->cap && l >= p->cap) { /* capped at match time: extend at the chain position */
+          uint32_t maxlen = end - pos < 258 ? end - pos : 258;
+          uint32_t c = pos - dist16[pos];
+          while (l < maxlen && data[pos + l] == data[c + l]) l++;
+        }
         out[k++] = SFO_TOK_MATCH | ((l - 3) << 16) | (uint32_t)(dist16[pos] - 1);
         pos += l;
       } else {

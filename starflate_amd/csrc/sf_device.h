@@ -18,8 +18,8 @@ namespace sf {
 constexpr uint32_t kChunk = 32768;      // bytes per independently coded DEFLATE block
 constexpr uint32_t kStep = 1024;        // positions per hash-insertion step (= K1 threads)
 constexpr uint32_t kHashBits = 12;
-constexpr uint32_t kRegion = 2048;      // parse region: matches never cross it
-constexpr uint32_t kRegionsPerChunk = kChunk / kRegion;
+constexpr uint32_t kRegion = 512;       // parse region: matches never cross it
+constexpr uint32_t kCap = 16;           // match-time compare width; longer matches are extended by the parse
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kTokMatch = 0x80000000u;  // token: bit31 match, 16..23 len-3, 0..14 dist-1
 

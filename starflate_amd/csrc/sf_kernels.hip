@@ -51,23 +51,32 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 }
 
 // ---------------------------------------------------------------------------
-// K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per chunk.
+// K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per chunk,
+// two workgroups per CU (LDS <= 80 KiB): the chunk stays in LDS, per-position results
+// only for the 8 KiB quarter in flight.
+//   match:  step-synchronous hash insertion (kStep positions between two barriers),
+//           branch-free compare of kCap bytes against the far and near candidates
+//   parse:  one wave per 512-byte region walks the greedy/lazy chain with scalar
+//           jumps over ballot masks; a capped match is extended to its full length
+//           by the whole wave (64 lanes x 4 bytes) only when the chain takes it
 // ---------------------------------------------------------------------------
 constexpr uint32_t K1_THREADS = kStep;
 constexpr uint32_t K1_WAVES = K1_THREADS / 64;
-constexpr uint32_t kSegs = kChunk / 64;
+constexpr uint32_t kQuarter = 8192;                          // positions per match->parse round
+constexpr uint32_t kQSegs = kQuarter / 64;                   // 128
+static_assert(kQuarter / kRegion == K1_WAVES, "one region per wave per quarter");
 // LDS carve (bytes); every offset is a multiple of 16
-constexpr uint32_t L_DATA = 0;                              // u32[8192+4]
-constexpr uint32_t L_LEN8 = L_DATA + kChunk + 16;           // u8[32768]   len-3, 0 = no match
-constexpr uint32_t L_DIST = L_LEN8 + kChunk;                // u16[32768]
-constexpr uint32_t L_TABLE = L_DIST + 2 * kChunk;           // u32[1<<kHashBits]
-constexpr uint32_t L_HIST = L_TABLE + (4u << kHashBits);    // u32[320]
-constexpr uint32_t L_MARKS = L_HIST + 4 * kHistStride;      // u64[512] chain positions per segment
-constexpr uint32_t L_MM = L_MARKS + 8 * kSegs;              // u64[512] chain positions that are matches
-constexpr uint32_t L_SEGPRE = L_MM + 8 * kSegs;             // u16[512] tokens before segment, in region
-constexpr uint32_t L_REGCNT = L_SEGPRE + 2 * kSegs;         // u32[16]
-constexpr uint32_t K1_LDS = L_REGCNT + 4 * kRegionsPerChunk;
-static_assert(K1_LDS <= 160 * 1024, "K1 LDS budget");
+constexpr uint32_t L_DATA = 0;                               // u32[8192+4]
+constexpr uint32_t L_LEN8 = L_DATA + kChunk + 16;            // u8[kQuarter]  len-3 (capped), 0 = none
+constexpr uint32_t L_DIST = L_LEN8 + kQuarter;               // u16[kQuarter]
+constexpr uint32_t L_TABLE = L_DIST + 2 * kQuarter;          // u32[1<<kHashBits]
+constexpr uint32_t L_HIST = L_TABLE + (4u << kHashBits);     // u32[320]
+constexpr uint32_t L_MARKS = L_HIST + 4 * kHistStride;       // u64[128] chain positions per segment
+constexpr uint32_t L_MM = L_MARKS + 8 * kQSegs;              // u64[128] chain positions that are matches
+constexpr uint32_t L_SEGPRE = L_MM + 8 * kQSegs;             // u16[128] tokens before segment, in region
+constexpr uint32_t L_REGCNT = L_SEGPRE + 2 * kQSegs;         // u32[16]
+constexpr uint32_t K1_LDS = L_REGCNT + 4 * K1_WAVES;
+static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
 static_assert(L_MARKS % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0, "LDS alignment");
 
 __device__ __forceinline__ uint32_t lds_load4(const uint32_t* d32, uint32_t a) {
@@ -75,32 +84,26 @@ __device__ __forceinline__ uint32_t lds_load4(const uint32_t* d32, uint32_t a) {
   return __builtin_amdgcn_alignbyte(d32[w + 1], d32[w], a & 3);
 }
 
-// common prefix length of data[i..] and data[c..], capped at maxlen
-__device__ __forceinline__ uint32_t match_len(const uint32_t* d32, uint32_t i, uint32_t c,
-                                              uint32_t maxlen) {
-  uint32_t ia = i >> 2, ca = c >> 2;
-  const uint32_t ish = i & 3, csh = c & 3;
-  uint32_t ilo = d32[ia], clo = d32[ca];
-  uint32_t l = 0;
-  while (l < maxlen) {
-    const uint32_t ihi = d32[++ia], chi = d32[++ca];
-    const uint32_t x =
-        __builtin_amdgcn_alignbyte(ihi, ilo, ish) ^ __builtin_amdgcn_alignbyte(chi, clo, csh);
-    if (x) {
-      l += (uint32_t)__builtin_ctz(x) >> 3;
-      break;
-    }
-    l += 4;
-    ilo = ihi;
-    clo = chi;
-  }
-  return l < maxlen ? l : maxlen;
+// first mismatching byte (0..16) between the 16 bytes in a[0..3] and those at data[c..]
+__device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, const uint32_t a[4], uint32_t c) {
+  const uint32_t cw = c >> 2, csh = c & 3;
+  const uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2], c3 = d32[cw + 3], c4 = d32[cw + 4];
+  const uint32_t x0 = a[0] ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
+  const uint32_t x1 = a[1] ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
+  const uint32_t x2 = a[2] ^ __builtin_amdgcn_alignbyte(c3, c2, csh);
+  const uint32_t x3 = a[3] ^ __builtin_amdgcn_alignbyte(c4, c3, csh);
+  uint32_t l = 16;
+  l = x3 ? 12 + ((uint32_t)__builtin_ctz(x3) >> 3) : l;
+  l = x2 ? 8 + ((uint32_t)__builtin_ctz(x2) >> 3) : l;
+  l = x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : l;
+  l = x0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : l;
+  return l;
 }
 
-__global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
-                                                     uint32_t* __restrict__ tokens,
-                                                     uint32_t* __restrict__ ntok_out,
-                                                     uint32_t* __restrict__ hist_out, uint32_t lazy) {
+__global__ __launch_bounds__(K1_THREADS, 8) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
+                                                        uint32_t* __restrict__ tokens,
+                                                        uint32_t* __restrict__ ntok_out,
+                                                        uint32_t* __restrict__ hist_out, uint32_t lazy) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* s_data = reinterpret_cast<uint32_t*>(smem + L_DATA);
   uint8_t* s_bytes = smem + L_DATA;
@@ -114,9 +117,12 @@ __global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__
   uint32_t* s_regcnt = reinterpret_cast<uint32_t*>(smem + L_REGCNT);
 
   const uint32_t t = threadIdx.x;
+  const uint32_t wave = t >> 6, lane = t & 63;
+  const uint64_t lt_mask = (1ull << lane) - 1;
   const uint32_t chunk = blockIdx.x;
   const uint64_t base = (uint64_t)chunk * kChunk;
   const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kChunk ? (n_total - base) : kChunk);
+  uint32_t* const tk = tokens + (uint64_t)chunk * kChunk;
 
   // ---- stage the chunk: coalesced 16 B per lane, zero beyond n ----
   {
@@ -143,122 +149,162 @@ __global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__
   }
   __syncthreads();
 
-  // ---- match finding: steps of kStep consecutive positions ----
   const uint32_t nsteps = (n + kStep - 1) / kStep;
-  for (uint32_t s = 0; s < nsteps; ++s) {
-    const uint32_t i = s * kStep + t;
-    const bool elig = i + kMinMatch <= n;
-    const uint32_t v = lds_load4(s_data, i);
-    const uint32_t h = (v * 2654435761u) >> (32 - kHashBits);
-    const uint32_t farv = elig ? s_table[h] : 0u;
-    __syncthreads();  // every far read of this step precedes every insertion of this step
-    if (elig) atomicMax(&s_table[h], ((s + 1) << 12) | (4095u - t));
-    __syncthreads();  // insertions complete before the near reads
-    uint32_t best = 0, bdist = 0;
-    if (elig) {
-      const uint32_t nearv = s_table[h];
-      const uint32_t nearp = ((nearv >> 12) - 1) * kStep + (4095u - (nearv & 4095u));
-      const uint32_t rend = (i & ~(kRegion - 1)) + kRegion;
-      uint32_t maxlen = n - i < 258u ? n - i : 258u;
-      if (rend - i < maxlen) maxlen = rend - i;
-      if (nearp < i) {
-        best = match_len(s_data, i, nearp, maxlen);
-        bdist = i - nearp;
-      }
+  uint32_t total = 0;  // tokens of the quarters done so far (uniform)
+
+  for (uint32_t qb = 0; qb < n; qb += kQuarter) {
+    // ---- match finding over this quarter: steps of kStep consecutive positions ----
+    const uint32_t s_end = (qb / kStep + kQuarter / kStep) < nsteps ? (qb / kStep + kQuarter / kStep) : nsteps;
+    for (uint32_t s = qb / kStep; s < s_end; ++s) {
+      const uint32_t i = s * kStep + t;
+      const bool elig = i + kMinMatch <= n;
+      const uint32_t iw = i >> 2, ish = i & 3;
+      const uint32_t i0 = s_data[iw], i1 = s_data[iw + 1], i2 = s_data[iw + 2], i3 = s_data[iw + 3],
+                     i4 = s_data[iw + 4];
+      uint32_t a[4];
+      a[0] = __builtin_amdgcn_alignbyte(i1, i0, ish);
+      a[1] = __builtin_amdgcn_alignbyte(i2, i1, ish);
+      a[2] = __builtin_amdgcn_alignbyte(i3, i2, ish);
+      a[3] = __builtin_amdgcn_alignbyte(i4, i3, ish);
+      const uint32_t h = (a[0] * 2654435761u) >> (32 - kHashBits);
+      const uint32_t farv = elig ? s_table[h] : 0u;
+      // the far candidate only needs the (immutable) chunk: compare it ahead of the barrier
+      uint32_t lfar = 0, farp = 0;
       if (farv) {
-        const uint32_t farp = ((farv >> 12) - 1) * kStep + (4095u - (farv & 4095u));
-        const uint32_t l = match_len(s_data, i, farp, maxlen);
-        if (l > best) {
-          best = l;
-          bdist = i - farp;
-        }
+        farp = ((farv >> 12) - 1) * kStep + (4095u - (farv & 4095u));
+        lfar = cmp16(s_data, a, farp);
       }
-      if (best < kMinMatch) best = 0;
+      __syncthreads();  // every far read of this step precedes every insertion of this step
+      if (elig) atomicMax(&s_table[h], ((s + 1) << 12) | (4095u - t));
+      __syncthreads();  // insertions complete before the near reads
+      uint32_t best = 0, bdist = 0;
+      if (elig) {
+        const uint32_t nearv = s_table[h];
+        const uint32_t nearp = ((nearv >> 12) - 1) * kStep + (4095u - (nearv & 4095u));
+        const uint32_t rend = (i & ~(kRegion - 1)) + kRegion;
+        uint32_t maxlen = n - i < kCap ? n - i : kCap;
+        if (rend - i < maxlen) maxlen = rend - i;
+        if (nearp < i) {
+          const uint32_t l = cmp16(s_data, a, nearp);
+          best = l < maxlen ? l : maxlen;
+          bdist = i - nearp;
+        }
+        if (farv) {
+          const uint32_t l = lfar < maxlen ? lfar : maxlen;
+          if (l > best) {
+            best = l;
+            bdist = i - farp;
+          }
+        }
+        if (best < kMinMatch) best = 0;
+      }
+      if (i < n) {
+        s_len8[i - qb] = (uint8_t)(best ? best - 3 : 0);
+        s_dist[i - qb] = (uint16_t)bdist;
+      }
     }
-    if (i < n) {
-      s_len8[i] = (uint8_t)(best ? best - 3 : 0);
-      s_dist[i] = (uint16_t)bdist;
-    }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ---- parse pass 1: one wave per region walks the greedy/lazy chain ----
-  const uint32_t wave = t >> 6, lane = t & 63;
-  const uint64_t lt_mask = (1ull << lane) - 1;
-  const uint32_t nreg = (n + kRegion - 1) / kRegion;
-  for (uint32_t r = wave; r < kRegionsPerChunk; r += K1_WAVES) {
-    const uint32_t rbase = r * kRegion;
-    const uint32_t rend = rbase + kRegion < n ? rbase + kRegion : n;
-    uint32_t entry = 0, count = 0;
-    for (uint32_t seg = rbase; seg < rbase + kRegion; seg += 64) {
-      const uint32_t sg = seg >> 6;
-      if (r >= nreg || seg >= rend) {
-        if (lane == 0) { s_marks[sg] = 0; s_mm[sg] = 0; s_segpre[sg] = (uint16_t)count; }
-        continue;
-      }
-      const uint32_t p = seg + lane;
-      const bool valid = p < rend;
-      const uint32_t l8 = valid ? s_len8[p] : 0u;
-      const uint32_t nl8 = (p + 1 < rend) ? s_len8[p + 1] : 0u;
-      const bool take = l8 != 0 && !(lazy && nl8 > l8);
-      const uint64_t M = __ballot(take);
-      const uint64_t V = __ballot(valid);
-      const uint32_t len = l8 + 3;
-      uint64_t marks = 0;
-      uint32_t pos = entry;
-      while (pos < 64) {
-        const uint64_t ge = ~0ull << pos;
-        const uint64_t rest = M & ge;
-        if (!rest) {
-          marks |= ge;
-          pos = 64;
-          break;
+    // ---- parse pass 1: wave w walks the chain of region w of this quarter ----
+    {
+      const uint32_t rbase = qb + wave * kRegion;                       // absolute
+      const uint32_t rend = rbase + kRegion < n ? rbase + kRegion : n;  // absolute
+      uint32_t entry = 0, count = 0;
+      for (uint32_t k = 0; k < kRegion / 64; ++k) {
+        const uint32_t seg = rbase + 64 * k;
+        const uint32_t sg = wave * (kRegion / 64) + k;  // segment index within the quarter
+        if (seg >= rend) {
+          if (lane == 0) { s_marks[sg] = 0; s_mm[sg] = 0; s_segpre[sg] = (uint16_t)count; }
+          continue;
         }
-        const uint32_t q = (uint32_t)__builtin_ctzll(rest);
-        marks |= ge & ((2ull << q) - 1);
-        pos = q + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)q);
+        const uint32_t p = seg + lane;
+        const bool valid = p < rend;
+        const uint32_t l8 = valid ? s_len8[p - qb] : 0u;
+        const uint32_t nl8 = (p + 1 < rend) ? s_len8[p + 1 - qb] : 0u;
+        const uint32_t dist = valid ? s_dist[p - qb] : 0u;
+        const bool take = l8 != 0 && !(lazy && nl8 > l8);
+        const uint64_t M = __ballot(take);
+        const uint64_t V = __ballot(valid);
+        uint64_t marks = 0;
+        uint32_t pos = entry;
+        while (pos < 64) {
+          const uint64_t ge = ~0ull << pos;
+          const uint64_t rest = M & ge;
+          if (!rest) {
+            marks |= ge;
+            pos = 64;
+            break;
+          }
+          const uint32_t q = (uint32_t)__builtin_ctzll(rest);
+          marks |= ge & ((2ull << q) - 1);
+          uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)l8, (int)q) + 3;
+          if (len == kCap) {
+            // capped at match time: the whole wave extends it, 4 bytes per lane
+            const uint32_t pq = seg + q;
+            const uint32_t cq = pq - (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)q);
+            const uint32_t maxlen = rend - pq < 258u ? rend - pq : 258u;
+            const uint32_t off = kCap + 4 * lane;
+            uint32_t x = 0;
+            if (off < maxlen) x = lds_load4(s_data, pq + off) ^ lds_load4(s_data, cq + off);
+            const uint64_t nz = __ballot(x != 0);
+            uint32_t full = maxlen;
+            if (nz) {
+              const uint32_t k0 = (uint32_t)__builtin_ctzll(nz);
+              const uint32_t xb = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)k0);
+              full = kCap + 4 * k0 + ((uint32_t)__builtin_ctz(xb) >> 3);
+              full = full < maxlen ? full : maxlen;
+            }
+            len = full;
+            if (lane == 0) s_len8[pq - qb] = (uint8_t)(full - 3);
+          }
+          pos = q + len;
+        }
+        entry = pos - 64;
+        marks &= V;
+        if (lane == 0) {
+          s_marks[sg] = marks;
+          s_mm[sg] = marks & M;
+          s_segpre[sg] = (uint16_t)count;
+        }
+        count += (uint32_t)__popcll(marks);
       }
-      entry = pos - 64;
-      marks &= V;
-      if (lane == 0) {
-        s_marks[sg] = marks;
-        s_mm[sg] = marks & M;
-        s_segpre[sg] = (uint16_t)count;
-      }
-      count += (uint32_t)__popcll(marks);
+      if (lane == 0) s_regcnt[wave] = count;
     }
-    if (lane == 0) s_regcnt[r] = count;
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ---- parse pass 2: every wave turns its region's chain positions into tokens ----
-  uint32_t total = 0;
-  for (uint32_t r = 0; r < kRegionsPerChunk; ++r) total += s_regcnt[r];
-  for (uint32_t r = wave; r < nreg; r += K1_WAVES) {
-    uint32_t rpre = 0;
-    for (uint32_t q = 0; q < r; ++q) rpre += s_regcnt[q];
-    uint32_t* tk = tokens + (uint64_t)chunk * kChunk + rpre;
-    for (uint32_t sg = r * (kRegion / 64); sg < (r + 1) * (kRegion / 64); ++sg) {
-      const uint64_t marks = s_marks[sg];
-      if (!marks) continue;
-      const uint64_t mm = s_mm[sg];
-      if ((marks >> lane) & 1) {
-        const uint32_t p = sg * 64 + lane;
-        const uint32_t idx = s_segpre[sg] + (uint32_t)__popcll(marks & lt_mask);
-        uint32_t tok;
-        if ((mm >> lane) & 1) {
-          const uint32_t l3 = s_len8[p], d1 = (uint32_t)s_dist[p] - 1;
-          tok = kTokMatch | (l3 << 16) | d1;
-          uint32_t eb, ev;
-          atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
-          atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
-        } else {
-          tok = s_bytes[p];
-          atomicAdd(&s_hist[tok], 1u);
-        }
-        tk[idx] = tok;
+    // ---- parse pass 2: chain positions -> tokens (compact, chunk order) + histogram ----
+    {
+      uint32_t rpre = total, qtot = 0;
+      for (uint32_t r = 0; r < K1_WAVES; ++r) {
+        const uint32_t c = s_regcnt[r];
+        if (r < wave) rpre += c;
+        qtot += c;
       }
+      for (uint32_t k = 0; k < kRegion / 64; ++k) {
+        const uint32_t sg = wave * (kRegion / 64) + k;
+        const uint64_t marks = s_marks[sg];
+        if (!marks) continue;
+        const uint64_t mm = s_mm[sg];
+        if ((marks >> lane) & 1) {
+          const uint32_t p = qb + sg * 64 + lane;
+          const uint32_t idx = rpre + s_segpre[sg] + (uint32_t)__popcll(marks & lt_mask);
+          uint32_t tok;
+          if ((mm >> lane) & 1) {
+            const uint32_t l3 = s_len8[p - qb], d1 = (uint32_t)s_dist[p - qb] - 1;
+            tok = kTokMatch | (l3 << 16) | d1;
+            uint32_t eb, ev;
+            atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
+            atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
+          } else {
+            tok = s_bytes[p];
+            atomicAdd(&s_hist[tok], 1u);
+          }
+          tk[idx] = tok;
+        }
+      }
+      total += qtot;
     }
+    // the next quarter's first barrier orders these reads before its result writes
   }
   __syncthreads();
   if (t < kHistStride) hist_out[(uint64_t)chunk * kHistStride + t] = s_hist[t];

@@ -28,6 +28,7 @@ class Params(C.Structure):
         ("use_near", C.c_uint32),
         ("long_hash_bytes", C.c_uint32),
         ("chain_depth", C.c_uint32),
+        ("cap", C.c_uint32),
     ]
 
 
