@@ -326,7 +326,7 @@ void sfo_default_params(sfo_params* p) {
   p->chunk_bytes = 32768;
   p->step = 1024;
   p->hash_bits = 12;
-  p->region_bytes = 512;
+  p->region_bytes = 128;
   p->min_match = 4;
   p->lazy = 1;
   p->final_stream = 1;
@@ -775,11 +775,11 @@ int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t*
   uint16_t* len16 = (uint16_t*)malloc(cb * 2 + 2);
   uint16_t* dist16 = (uint16_t*)malloc(cb * 2 + 2);
   uint32_t* tokens = (uint32_t*)malloc((cb + p->region_bytes) * 4);
-  uint32_t ntok[64];
+  uint32_t ntok[4096];
   uint8_t* tmp = (uint8_t*)malloc(cb + cb / 8 + 1024);
   size_t off = 0;
   int rc = 0;
-  if ((cb + p->region_bytes - 1) / p->region_bytes > 64) { rc = -1; goto out; }
+  if ((cb + p->region_bytes - 1) / p->region_bytes > 4096) { rc = -1; goto out; }
   for (size_t c = 0; c < nchunks; c++) {
     const uint8_t* data = src + c * cb;
     uint32_t cn = (uint32_t)(n - c * cb < cb ? n - c * cb : cb);

@@ -10,7 +10,7 @@ from . import build as _build
 
 NSTAGES = 4
 STRATEGY = {"auto": 0, "stored": 1, "fixed": 2, "dynamic": 3}
-DBG_NTOK, DBG_TOKENS, DBG_HIST, DBG_PLAN, DBG_LENS, DBG_OFFSETS = range(6)
+DBG_NTOK, DBG_TOKENS, DBG_HIST, DBG_PLAN, DBG_LENS, DBG_OFFSETS, DBG_STAMPS = range(7)
 
 # every symbol include/starflate_hip.h declares
 EXPORTS = [

@@ -31,6 +31,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-Wall", "-Wextra", "-Werror"]
+    cmd += os.environ.get("SF_HIPCC_FLAGS", "").split()
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH + ".tmp"]
     if verbose:

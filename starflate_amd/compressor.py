@@ -118,6 +118,7 @@ class Compressor:
             _capi.DBG_PLAN: ((nchunks, 4), np.uint32),
             _capi.DBG_LENS: ((nchunks, 320), np.uint8),
             _capi.DBG_OFFSETS: ((nchunks,), np.uint64),
+            _capi.DBG_STAMPS: ((nchunks, 8), np.uint64),
         }
         shape, dt = shapes[what]
         a = np.empty(shape, dtype=dt)

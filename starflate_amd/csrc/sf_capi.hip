@@ -4,6 +4,7 @@
 #include "sf_device.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 
@@ -18,6 +19,7 @@ struct sfh_ctx {
   uint8_t* d_out = nullptr;
   size_t d_in_cap = 0, d_out_cap = 0;
   int profiling = 0;
+  int k1_stamps = 0;  // SFH_K1_STAMPS=1: diagnostic k_lz77 build with s_memtime stamps
   hipEvent_t ev[SFH_NSTAGES + 1] = {};
   bool ev_valid = false;
   char err[256] = {0};
@@ -43,6 +45,7 @@ void free_ws(sfh_ctx* c) {
   (void)hipFree(c->ws.plan);
   (void)hipFree(c->ws.codes);
   (void)hipFree(c->ws.offsets);
+  (void)hipFree(c->ws.stamps);
   c->ws = sf::Workspace{};
   c->cap_chunks = 0;
 }
@@ -60,6 +63,10 @@ int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
       (e = hipMalloc(&ctx->ws.offsets, nc * sizeof(uint64_t))) != hipSuccess) {
     free_ws(ctx);
     return fail(ctx, SFH_E_NOMEM, "workspace hipMalloc", e);
+  }
+  if (ctx->k1_stamps && (e = hipMalloc(&ctx->ws.stamps, nc * 8 * sizeof(uint64_t))) != hipSuccess) {
+    free_ws(ctx);
+    return fail(ctx, SFH_E_NOMEM, "stamps hipMalloc", e);
   }
   ctx->cap_chunks = nchunks;
   return SFH_OK;
@@ -128,6 +135,10 @@ int sfh_create(sfh_ctx** out, int device) {
   sfh_ctx* ctx = new (std::nothrow) sfh_ctx();
   if (!ctx) return SFH_E_NOMEM;
   ctx->device = device;
+  {
+    const char* e = getenv("SFH_K1_STAMPS");
+    ctx->k1_stamps = (e && e[0] == '1');
+  }
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
       (e = hipMalloc(&ctx->d_total, sizeof(uint64_t))) != hipSuccess || (e = sf::init_kernels()) != hipSuccess) {
@@ -242,6 +253,7 @@ int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes) {
     case SFH_DBG_HIST: p = ctx->ws.hist; avail = nc * sf::kHistStride * 4; break;
     case SFH_DBG_PLAN: p = ctx->ws.plan; avail = nc * sizeof(sf::ChunkPlan); break;
     case SFH_DBG_OFFSETS: p = ctx->ws.offsets; avail = nc * 8; break;
+    case SFH_DBG_STAMPS: p = ctx->ws.stamps; avail = p ? nc * 64 : 0; break;
     case SFH_DBG_LENS: {
       if (bytes > nc * 320) return SFH_E_INVALID_ARG;
       SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");

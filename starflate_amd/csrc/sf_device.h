@@ -18,7 +18,7 @@ namespace sf {
 constexpr uint32_t kChunk = 32768;      // bytes per independently coded DEFLATE block
 constexpr uint32_t kStep = 1024;        // positions per hash-insertion step (= K1 threads)
 constexpr uint32_t kHashBits = 12;
-constexpr uint32_t kRegion = 512;       // parse region: matches never cross it
+constexpr uint32_t kRegion = 128;       // parse region: matches never cross it
 constexpr uint32_t kCap = 16;           // match-time compare width; longer matches are extended by the parse
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kTokMatch = 0x80000000u;  // token: bit31 match, 16..23 len-3, 0..14 dist-1
@@ -48,6 +48,7 @@ struct Workspace {
   ChunkPlan* plan;    // [nchunks]
   ChunkCodes* codes;  // [nchunks]
   uint64_t* offsets;  // [nchunks]
+  uint64_t* stamps;   // [nchunks][8], diagnostic build only (SFH_K1_STAMPS=1), else null
 };
 
 struct Options {

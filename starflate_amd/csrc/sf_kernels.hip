@@ -51,47 +51,58 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 }
 
 // ---------------------------------------------------------------------------
-// K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per chunk,
-// two workgroups per CU (LDS <= 80 KiB): the chunk stays in LDS, per-position results
-// only for the 8 KiB quarter in flight.
-//   match:  step-synchronous hash insertion (kStep positions between two barriers),
-//           branch-free compare of kCap bytes against the far and near candidates
-//   parse:  one wave per 512-byte region walks the greedy/lazy chain with scalar
-//           jumps over ballot masks; a capped match is extended to its full length
-//           by the whole wave (64 lanes x 4 bytes) only when the chain takes it
+// K1: LZ77 match finding + parse + histogram.  One 256-thread workgroup per chunk, two
+// workgroups per CU (LDS <= 80 KiB): the chunk stays in LDS, per-position results only
+// for the 8 KiB quarter in flight.  The CU has ONE scalar unit for all its waves, so the
+// hot loops are straight-line vector code: few waves, 4 positions per thread.
+//   match : step-synchronous hash insertion (kStep positions between two barriers), each
+//           thread owns 4 adjacent positions; branch-free compare of kCap bytes against
+//           the far candidate (before the barriers) and the near candidate (after)
+//   take  : SWAR pass flags positions whose match the greedy/lazy rule would take
+//   walk  : one LANE per kRegion-byte region follows the chain serially (regions are
+//           independent: matches never cross them), setting chain/match bit masks and
+//           extending capped matches to full length
+//   emit  : position-parallel: chain positions -> compact tokens + LDS histogram
 // ---------------------------------------------------------------------------
-constexpr uint32_t K1_THREADS = kStep;
+#ifndef SF_K1_PPT
+#define SF_K1_PPT 1
+#endif
+constexpr uint32_t kPPT = SF_K1_PPT;                         // adjacent positions per thread per step
+static_assert(kPPT == 1 || kPPT == 2 || kPPT == 4, "positions per thread");
+constexpr uint32_t K1_THREADS = kStep / kPPT;
 constexpr uint32_t K1_WAVES = K1_THREADS / 64;
 constexpr uint32_t kQuarter = 8192;                          // positions per match->parse round
-constexpr uint32_t kQSegs = kQuarter / 64;                   // 128
-static_assert(kQuarter / kRegion == K1_WAVES, "one region per wave per quarter");
+constexpr uint32_t kQSegs = kQuarter / 64;                   // 128 mask words per quarter
+constexpr uint32_t kQRegions = kQuarter / kRegion;
+static_assert(kQRegions <= 64, "one walker wave per quarter");
 // LDS carve (bytes); every offset is a multiple of 16
 constexpr uint32_t L_DATA = 0;                               // u32[8192+4]
-constexpr uint32_t L_LEN8 = L_DATA + kChunk + 16;            // u8[kQuarter]  len-3 (capped), 0 = none
-constexpr uint32_t L_DIST = L_LEN8 + kQuarter;               // u16[kQuarter]
+constexpr uint32_t L_LEN8 = L_DATA + kChunk + 16;            // u8[kQuarter+16] bit7 take, low bits len-3
+constexpr uint32_t L_DIST = L_LEN8 + kQuarter + 16;          // u16[kQuarter]
 constexpr uint32_t L_TABLE = L_DIST + 2 * kQuarter;          // u32[1<<kHashBits]
 constexpr uint32_t L_HIST = L_TABLE + (4u << kHashBits);     // u32[320]
-constexpr uint32_t L_MARKS = L_HIST + 4 * kHistStride;       // u64[128] chain positions per segment
+constexpr uint32_t L_MARKS = L_HIST + 4 * kHistStride;       // u64[128] chain positions per 64-segment
 constexpr uint32_t L_MM = L_MARKS + 8 * kQSegs;              // u64[128] chain positions that are matches
-constexpr uint32_t L_SEGPRE = L_MM + 8 * kQSegs;             // u16[128] tokens before segment, in region
-constexpr uint32_t L_REGCNT = L_SEGPRE + 2 * kQSegs;         // u32[16]
-constexpr uint32_t K1_LDS = L_REGCNT + 4 * K1_WAVES;
+constexpr uint32_t L_SEGPRE = L_MM + 8 * kQSegs;             // u32[128] tokens before the segment
+constexpr uint32_t L_MISC = L_SEGPRE + 4 * kQSegs;           // u32[4]
+constexpr uint32_t K1_LDS = L_MISC + 16;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
-static_assert(L_MARKS % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0, "LDS alignment");
+static_assert(L_MARKS % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0 && L_LEN8 % 16 == 0, "LDS alignment");
 
 __device__ __forceinline__ uint32_t lds_load4(const uint32_t* d32, uint32_t a) {
   const uint32_t w = a >> 2;
   return __builtin_amdgcn_alignbyte(d32[w + 1], d32[w], a & 3);
 }
 
-// first mismatching byte (0..16) between the 16 bytes in a[0..3] and those at data[c..]
-__device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, const uint32_t a[4], uint32_t c) {
+// first mismatching byte (0..16) between the 16 bytes in a0..a3 and those at data[c..]
+__device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t a2,
+                                          uint32_t a3, uint32_t c) {
   const uint32_t cw = c >> 2, csh = c & 3;
   const uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2], c3 = d32[cw + 3], c4 = d32[cw + 4];
-  const uint32_t x0 = a[0] ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
-  const uint32_t x1 = a[1] ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
-  const uint32_t x2 = a[2] ^ __builtin_amdgcn_alignbyte(c3, c2, csh);
-  const uint32_t x3 = a[3] ^ __builtin_amdgcn_alignbyte(c4, c3, csh);
+  const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
+  const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
+  const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(c3, c2, csh);
+  const uint32_t x3 = a3 ^ __builtin_amdgcn_alignbyte(c4, c3, csh);
   uint32_t l = 16;
   l = x3 ? 12 + ((uint32_t)__builtin_ctz(x3) >> 3) : l;
   l = x2 ? 8 + ((uint32_t)__builtin_ctz(x2) >> 3) : l;
@@ -100,24 +111,46 @@ __device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, const uint32_t a[
   return l;
 }
 
-__global__ __launch_bounds__(K1_THREADS, 8) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
-                                                        uint32_t* __restrict__ tokens,
-                                                        uint32_t* __restrict__ ntok_out,
-                                                        uint32_t* __restrict__ hist_out, uint32_t lazy) {
+__device__ __forceinline__ uint32_t entry_pos(uint32_t v) {
+  return ((v >> 12) - 1) * kStep + (4095u - (v & 4095u));
+}
+
+// STAMPS: diagnostic build only (sfh debug), s_memtime at phase boundaries into `stamps`
+// [chunk][8] = cycles in {stage, match, take+walk, emit, tail}; never used for timing claims.
+template <bool STAMPS>
+__global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
+                                                     uint32_t* __restrict__ tokens,
+                                                     uint32_t* __restrict__ ntok_out,
+                                                     uint32_t* __restrict__ hist_out, uint32_t lazy,
+                                                     uint64_t* __restrict__ stamps) {
+  uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t st_t = 0;
+  auto stamp = [&](int slot) {
+    if constexpr (STAMPS) {
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      st_acc[slot] += now - st_t;
+      st_t = now;
+    }
+  };
+  if constexpr (STAMPS) st_t = __builtin_amdgcn_s_memtime();
+
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* s_data = reinterpret_cast<uint32_t*>(smem + L_DATA);
   uint8_t* s_bytes = smem + L_DATA;
   uint8_t* s_len8 = smem + L_LEN8;
+  uint32_t* s_len32 = reinterpret_cast<uint32_t*>(smem + L_LEN8);
   uint16_t* s_dist = reinterpret_cast<uint16_t*>(smem + L_DIST);
   uint32_t* s_table = reinterpret_cast<uint32_t*>(smem + L_TABLE);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + L_HIST);
+  uint32_t* s_marks32 = reinterpret_cast<uint32_t*>(smem + L_MARKS);
   uint64_t* s_marks = reinterpret_cast<uint64_t*>(smem + L_MARKS);
   uint64_t* s_mm = reinterpret_cast<uint64_t*>(smem + L_MM);
-  uint16_t* s_segpre = reinterpret_cast<uint16_t*>(smem + L_SEGPRE);
-  uint32_t* s_regcnt = reinterpret_cast<uint32_t*>(smem + L_REGCNT);
+  uint32_t* s_segpre = reinterpret_cast<uint32_t*>(smem + L_SEGPRE);
+  uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + L_MISC);
 
   const uint32_t t = threadIdx.x;
-  const uint32_t wave = t >> 6, lane = t & 63;
+  // t >> 6 is wave-uniform, but only readfirstlane tells the compiler so
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), lane = t & 63;
   const uint64_t lt_mask = (1ull << lane) - 1;
   const uint32_t chunk = blockIdx.x;
   const uint64_t base = (uint64_t)chunk * kChunk;
@@ -143,172 +176,242 @@ __global__ __launch_bounds__(K1_THREADS, 8) void k_lz77(const uint8_t* __restric
       s4[idx] = v;
     }
     if (t < 4) s_data[kChunk / 4 + t] = 0;
+    if (t < 4) s_len32[kQuarter / 4 + t] = 0;  // pad read by the take pass
     uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
     for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) t4[idx] = make_uint4(0, 0, 0, 0);
-    if (t < kHistStride) s_hist[t] = (t == 256) ? 1u : 0u;
+    for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) s_hist[idx] = (idx == 256) ? 1u : 0u;
   }
   __syncthreads();
+  stamp(0);
 
   const uint32_t nsteps = (n + kStep - 1) / kStep;
   uint32_t total = 0;  // tokens of the quarters done so far (uniform)
 
   for (uint32_t qb = 0; qb < n; qb += kQuarter) {
-    // ---- match finding over this quarter: steps of kStep consecutive positions ----
+    // ---- match finding over this quarter ----
     const uint32_t s_end = (qb / kStep + kQuarter / kStep) < nsteps ? (qb / kStep + kQuarter / kStep) : nsteps;
     for (uint32_t s = qb / kStep; s < s_end; ++s) {
-      const uint32_t i = s * kStep + t;
-      const bool elig = i + kMinMatch <= n;
-      const uint32_t iw = i >> 2, ish = i & 3;
-      const uint32_t i0 = s_data[iw], i1 = s_data[iw + 1], i2 = s_data[iw + 2], i3 = s_data[iw + 3],
-                     i4 = s_data[iw + 4];
-      uint32_t a[4];
-      a[0] = __builtin_amdgcn_alignbyte(i1, i0, ish);
-      a[1] = __builtin_amdgcn_alignbyte(i2, i1, ish);
-      a[2] = __builtin_amdgcn_alignbyte(i3, i2, ish);
-      a[3] = __builtin_amdgcn_alignbyte(i4, i3, ish);
-      const uint32_t h = (a[0] * 2654435761u) >> (32 - kHashBits);
-      const uint32_t farv = elig ? s_table[h] : 0u;
-      // the far candidate only needs the (immutable) chunk: compare it ahead of the barrier
-      uint32_t lfar = 0, farp = 0;
-      if (farv) {
-        farp = ((farv >> 12) - 1) * kStep + (4095u - (farv & 4095u));
-        lfar = cmp16(s_data, a, farp);
+      const uint32_t p0 = s * kStep + kPPT * t;  // first of this thread's kPPT adjacent positions
+      const uint32_t dw = p0 >> 2, sh0 = p0 & 3;  // sh0 + kPPT - 1 <= 3
+      const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2], d3 = s_data[dw + 3],
+                     d4 = s_data[dw + 4];
+      uint32_t a[kPPT][4], h[kPPT], farv[kPPT], lfar[kPPT];
+#pragma unroll
+      for (uint32_t k = 0; k < kPPT; ++k) {
+        a[k][0] = __builtin_amdgcn_alignbyte(d1, d0, sh0 + k);
+        a[k][1] = __builtin_amdgcn_alignbyte(d2, d1, sh0 + k);
+        a[k][2] = __builtin_amdgcn_alignbyte(d3, d2, sh0 + k);
+        a[k][3] = __builtin_amdgcn_alignbyte(d4, d3, sh0 + k);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kPPT; ++k) {
+        h[k] = (a[k][0] * 2654435761u) >> (32 - kHashBits);
+        farv[k] = s_table[h[k]];
+      }
+      // the far candidate only needs the (immutable) chunk: compare it ahead of the barriers
+#pragma unroll
+      for (uint32_t k = 0; k < kPPT; ++k) {
+        const uint32_t p = p0 + k;
+        const uint32_t farp = farv[k] ? entry_pos(farv[k]) : p;
+        const uint32_t l = cmp16(s_data, a[k][0], a[k][1], a[k][2], a[k][3], farp);
+        lfar[k] = farv[k] ? l : 0u;
       }
       __syncthreads();  // every far read of this step precedes every insertion of this step
-      if (elig) atomicMax(&s_table[h], ((s + 1) << 12) | (4095u - t));
+#pragma unroll
+      for (uint32_t k = 0; k < kPPT; ++k) {
+        const uint32_t p = p0 + k;
+        // positions without kMinMatch bytes left insert 0, which MAX ignores
+        const uint32_t v = (p + kMinMatch <= n) ? (((s + 1) << 12) | (4095u - (kPPT * t + k))) : 0u;
+        atomicMax(&s_table[h[k]], v);
+      }
       __syncthreads();  // insertions complete before the near reads
-      uint32_t best = 0, bdist = 0;
-      if (elig) {
-        const uint32_t nearv = s_table[h];
-        const uint32_t nearp = ((nearv >> 12) - 1) * kStep + (4095u - (nearv & 4095u));
-        const uint32_t rend = (i & ~(kRegion - 1)) + kRegion;
-        uint32_t maxlen = n - i < kCap ? n - i : kCap;
-        if (rend - i < maxlen) maxlen = rend - i;
-        if (nearp < i) {
-          const uint32_t l = cmp16(s_data, a, nearp);
-          best = l < maxlen ? l : maxlen;
-          bdist = i - nearp;
+      uint32_t len4 = 0;
+      uint32_t dist[kPPT];
+#pragma unroll
+      for (uint32_t k = 0; k < kPPT; ++k) {
+        const uint32_t p = p0 + k;
+        const uint32_t nearv = s_table[h[k]];
+        const uint32_t nearp = nearv ? entry_pos(nearv) : p;
+        const uint32_t np = nearp < p ? nearp : p;
+        const uint32_t ln = cmp16(s_data, a[k][0], a[k][1], a[k][2], a[k][3], np);
+        const uint32_t rend = (p & ~(kRegion - 1)) + kRegion;
+        uint32_t maxlen = (p < n) ? (n - p < kCap ? n - p : kCap) : 0u;
+        maxlen = rend - p < maxlen ? rend - p : maxlen;
+        uint32_t best = nearp < p ? (ln < maxlen ? ln : maxlen) : 0u;
+        uint32_t bd = p - np;
+        const uint32_t lf = lfar[k] < maxlen ? lfar[k] : maxlen;
+        const uint32_t farp = farv[k] ? entry_pos(farv[k]) : p;
+        if (lf > best) {
+          best = lf;
+          bd = p - farp;
         }
-        if (farv) {
-          const uint32_t l = lfar < maxlen ? lfar : maxlen;
-          if (l > best) {
-            best = l;
-            bdist = i - farp;
-          }
-        }
-        if (best < kMinMatch) best = 0;
+        const bool ok = best >= kMinMatch && (p + kMinMatch <= n);
+        len4 |= (ok ? best - 3 : 0u) << (8 * k);
+        dist[k] = ok ? bd : 0u;
       }
-      if (i < n) {
-        s_len8[i - qb] = (uint8_t)(best ? best - 3 : 0);
-        s_dist[i - qb] = (uint16_t)bdist;
+      const uint32_t rel = p0 - qb;  // multiple of kPPT
+      if constexpr (kPPT == 4) {
+        s_len32[rel >> 2] = len4;
+        *reinterpret_cast<uint2*>(&s_dist[rel]) = make_uint2(dist[0] | (dist[1] << 16), dist[2] | (dist[3] << 16));
+      } else if constexpr (kPPT == 2) {
+        *reinterpret_cast<uint16_t*>(&s_len8[rel]) = (uint16_t)len4;
+        *reinterpret_cast<uint32_t*>(&s_dist[rel]) = dist[0] | (dist[1] << 16);
+      } else {
+        s_len8[rel] = (uint8_t)len4;
+        s_dist[rel] = (uint16_t)dist[0];
       }
     }
     __syncthreads();
+    stamp(1);
 
-    // ---- parse pass 1: wave w walks the chain of region w of this quarter ----
+    // ---- take pass (position-parallel): which positions would the greedy/lazy rule take,
+    // and for every position p the packed byte (k << 4) | l3: k = distance to the next take
+    // position in p's region (15 = none within 14), l3 = its capped len-3.  One dependent
+    // LDS byte read per match is then all the serial walker needs.
     {
-      const uint32_t rbase = qb + wave * kRegion;                       // absolute
-      const uint32_t rend = rbase + kRegion < n ? rbase + kRegion : n;  // absolute
-      uint32_t entry = 0, count = 0;
-      for (uint32_t k = 0; k < kRegion / 64; ++k) {
-        const uint32_t seg = rbase + 64 * k;
-        const uint32_t sg = wave * (kRegion / 64) + k;  // segment index within the quarter
-        if (seg >= rend) {
-          if (lane == 0) { s_marks[sg] = 0; s_mm[sg] = 0; s_segpre[sg] = (uint16_t)count; }
-          continue;
-        }
-        const uint32_t p = seg + lane;
-        const bool valid = p < rend;
-        const uint32_t l8 = valid ? s_len8[p - qb] : 0u;
-        const uint32_t nl8 = (p + 1 < rend) ? s_len8[p + 1 - qb] : 0u;
-        const uint32_t dist = valid ? s_dist[p - qb] : 0u;
-        const bool take = l8 != 0 && !(lazy && nl8 > l8);
-        const uint64_t M = __ballot(take);
-        const uint64_t V = __ballot(valid);
-        uint64_t marks = 0;
-        uint32_t pos = entry;
-        while (pos < 64) {
-          const uint64_t ge = ~0ull << pos;
-          const uint64_t rest = M & ge;
-          if (!rest) {
-            marks |= ge;
-            pos = 64;
-            break;
-          }
-          const uint32_t q = (uint32_t)__builtin_ctzll(rest);
-          marks |= ge & ((2ull << q) - 1);
-          uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)l8, (int)q) + 3;
-          if (len == kCap) {
-            // capped at match time: the whole wave extends it, 4 bytes per lane
-            const uint32_t pq = seg + q;
-            const uint32_t cq = pq - (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)q);
-            const uint32_t maxlen = rend - pq < 258u ? rend - pq : 258u;
-            const uint32_t off = kCap + 4 * lane;
-            uint32_t x = 0;
-            if (off < maxlen) x = lds_load4(s_data, pq + off) ^ lds_load4(s_data, cq + off);
-            const uint64_t nz = __ballot(x != 0);
-            uint32_t full = maxlen;
-            if (nz) {
-              const uint32_t k0 = (uint32_t)__builtin_ctzll(nz);
-              const uint32_t xb = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)k0);
-              full = kCap + 4 * k0 + ((uint32_t)__builtin_ctz(xb) >> 3);
-              full = full < maxlen ? full : maxlen;
-            }
-            len = full;
-            if (lane == 0) s_len8[pq - qb] = (uint8_t)(full - 3);
-          }
-          pos = q + len;
-        }
-        entry = pos - 64;
-        marks &= V;
-        if (lane == 0) {
-          s_marks[sg] = marks;
-          s_mm[sg] = marks & M;
-          s_segpre[sg] = (uint16_t)count;
-        }
-        count += (uint32_t)__popcll(marks);
+      const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;  // valid positions in this quarter
+      constexpr uint32_t kIter = kQSegs / K1_WAVES;  // 64-position segments per wave
+#pragma unroll 4
+      for (uint32_t j = 0; j < kIter; ++j) {
+        const uint32_t sg = wave + j * K1_WAVES;
+        const uint32_t rel = sg * 64 + lane;
+        const uint32_t l3 = rel < qn ? s_len8[rel] : 0u;
+        const uint32_t n3 = (rel + 1 < qn && ((rel + 1) & (kRegion - 1)) != 0) ? s_len8[rel + 1] : 0u;
+        const bool take = l3 != 0 && !(lazy && n3 > l3);
+        const uint64_t T = __ballot(take);
+        if (lane == 0) s_mm[sg] = T;  // take mask; the emit pass ANDs it with the chain mask
       }
-      if (lane == 0) s_regcnt[wave] = count;
+      __syncthreads();  // take masks complete
+      uint32_t pkw[kIter / 4];  // packed bytes, 4 per register (fully unrolled: static indices)
+#pragma unroll
+      for (uint32_t j = 0; j < kIter; ++j) {
+        const uint32_t sg = wave + j * K1_WAVES;
+        const uint32_t rel = sg * 64 + lane;
+        const uint64_t up = s_mm[sg] >> lane;
+        uint32_t k = up ? (uint32_t)__builtin_ctzll(up) : 64u;
+        if (k == 64u && ((sg + 1) * 64) % kRegion != 0) {  // region continues in the next segment
+          const uint64_t Tn = s_mm[sg + 1];
+          k = Tn ? (64u - lane) + (uint32_t)__builtin_ctzll(Tn) : 64u;
+        }
+        k = k < 15u ? k : 15u;
+        const uint32_t l3 = k < 15u ? (uint32_t)s_len8[rel + k] : 0u;
+        const uint32_t byte = (k << 4) | (l3 & 15u);
+        if ((j & 3) == 0) pkw[j >> 2] = byte;
+        else pkw[j >> 2] |= byte << (8 * (j & 3));
+      }
+      __syncthreads();  // every len8 read above precedes the overwrite below
+#pragma unroll
+      for (uint32_t j = 0; j < kIter; ++j)
+        s_len8[(wave + j * K1_WAVES) * 64 + lane] = (uint8_t)(pkw[j >> 2] >> (8 * (j & 3)));
+      for (uint32_t idx = t; idx < 2 * kQSegs; idx += K1_THREADS) s_marks32[idx] = 0;
     }
     __syncthreads();
+    stamp(2);
 
-    // ---- parse pass 2: chain positions -> tokens (compact, chunk order) + histogram ----
-    {
-      uint32_t rpre = total, qtot = 0;
-      for (uint32_t r = 0; r < K1_WAVES; ++r) {
-        const uint32_t c = s_regcnt[r];
-        if (r < wave) rpre += c;
-        qtot += c;
-      }
-      for (uint32_t k = 0; k < kRegion / 64; ++k) {
-        const uint32_t sg = wave * (kRegion / 64) + k;
-        const uint64_t marks = s_marks[sg];
-        if (!marks) continue;
-        const uint64_t mm = s_mm[sg];
-        if ((marks >> lane) & 1) {
-          const uint32_t p = qb + sg * 64 + lane;
-          const uint32_t idx = rpre + s_segpre[sg] + (uint32_t)__popcll(marks & lt_mask);
-          uint32_t tok;
-          if ((mm >> lane) & 1) {
-            const uint32_t l3 = s_len8[p - qb], d1 = (uint32_t)s_dist[p - qb] - 1;
-            tok = kTokMatch | (l3 << 16) | d1;
-            uint32_t eb, ev;
-            atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
-            atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
+    // ---- walk: lane r of wave 0 follows the chain of region r of this quarter ----
+    // One loop iteration is either a chain step (one dependent LDS byte read) or one
+    // 8-byte step of extending a capped match, so a lane that extends never stalls the others.
+    if (wave == 0 && lane < kQRegions) {
+      const uint32_t rb = lane * kRegion;                        // quarter-relative
+      const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;
+      const uint32_t re = rb + kRegion < qn ? rb + kRegion : qn;  // quarter-relative end (may be <= rb)
+      uint32_t pos = rb;
+      uint32_t xl = 0, xmp = 0, xpa = 0, xca = 0, xmax = 0;      // extension state (xl = 0: none)
+      while (pos < re) {
+        if (xl == 0) {
+          const uint32_t b = s_len8[pos];
+          const uint32_t k = b >> 4;
+          const bool hit = k < 15u;
+          uint32_t nb = hit ? k + 1 : 15u;             // chain bits: k literals (+ the match position)
+          nb = pos + nb <= re ? nb : re - pos;         // a no-hit run may overshoot the region end
+          const uint64_t bits = ((1ull << nb) - 1) << (pos & 31);
+          atomicOr(&s_marks32[pos >> 5], (uint32_t)bits);
+          if (bits >> 32) atomicOr(&s_marks32[(pos >> 5) + 1], (uint32_t)(bits >> 32));
+          const uint32_t mp = pos + k;                 // match position (quarter-relative) on a hit
+          const uint32_t len = (b & 15u) + 3;
+          if (hit && len == kCap) {                    // capped at match time: extend from here
+            xmp = mp;
+            xpa = qb + mp;
+            xca = xpa - s_dist[mp];
+            xmax = re - mp < 258u ? re - mp : 258u;
+            xl = kCap;
           } else {
-            tok = s_bytes[p];
-            atomicAdd(&s_hist[tok], 1u);
+            pos = hit ? mp + len : pos + 15u;
           }
-          tk[idx] = tok;
+        } else {
+          uint32_t l = xl;
+          bool done = l >= xmax;
+          if (!done) {
+            const uint32_t ia = xpa + l, ja = xca + l;
+            const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
+            const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
+            const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, ia & 3) ^ __builtin_amdgcn_alignbyte(j1, j0, ja & 3);
+            const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, ia & 3) ^ __builtin_amdgcn_alignbyte(j2, j1, ja & 3);
+            if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; done = true; }
+            else if (x1) { l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3); done = true; }
+            else l += 8;
+          }
+          if (done) {
+            l = l < xmax ? l : xmax;
+            s_len8[xmp + 1] = (uint8_t)(l - 3);  // xmp+1 is covered by this match: nobody walks it
+            pos = xmp + l;
+            xl = 0;
+          } else {
+            xl = l;
+          }
         }
       }
-      total += qtot;
     }
+    __syncthreads();
+    stamp(3);
+    // ---- tokens before each 64-position segment (wave 0: two segments per lane) ----
+    if (wave == 0) {
+      const uint32_t c0 = (uint32_t)__popcll(s_marks[2 * lane]), c1 = (uint32_t)__popcll(s_marks[2 * lane + 1]);
+      const uint32_t incl = wave_incl_scan(c0 + c1, lane);
+      s_segpre[2 * lane] = incl - c0 - c1;
+      s_segpre[2 * lane + 1] = incl - c1;
+      if (lane == 63) s_misc[0] = incl;
+    }
+    __syncthreads();
+    stamp(4);
+
+    // ---- emit: chain positions -> tokens (compact, chunk order) + histogram ----
+    for (uint32_t sg = wave; sg < kQSegs; sg += K1_WAVES) {
+      const uint64_t marks = s_marks[sg];
+      const uint64_t mm = s_mm[sg] & marks;
+      const uint32_t pre = s_segpre[sg];
+      if ((marks >> lane) & 1) {
+        const uint32_t rel = sg * 64 + lane;
+        const uint32_t idx = total + pre + (uint32_t)__popcll(marks & lt_mask);
+        uint32_t tok;
+        if ((mm >> lane) & 1) {
+          uint32_t l3 = s_len8[rel] & 15u;           // a take position packs k = 0 and its own len-3
+          if (l3 == kCap - 3) l3 = s_len8[rel + 1];  // capped match: the walker left the full length next door
+          const uint32_t d1 = (uint32_t)s_dist[rel] - 1;
+          tok = kTokMatch | (l3 << 16) | d1;
+          uint32_t eb, ev;
+          atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
+          atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
+        } else {
+          tok = s_bytes[qb + rel];
+          atomicAdd(&s_hist[tok], 1u);
+        }
+        tk[idx] = tok;
+      }
+    }
+    total += s_misc[0];
+    if constexpr (STAMPS) __syncthreads();
+    stamp(5);
     // the next quarter's first barrier orders these reads before its result writes
   }
   __syncthreads();
-  if (t < kHistStride) hist_out[(uint64_t)chunk * kHistStride + t] = s_hist[t];
+  for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) hist_out[(uint64_t)chunk * kHistStride + idx] = s_hist[idx];
   if (t == 0) ntok_out[chunk] = total;
+  stamp(6);
+  if constexpr (STAMPS) {
+    if (t == 0)
+      for (int k = 0; k < 8; ++k) stamps[(uint64_t)chunk * 8 + k] = st_acc[k];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -714,7 +817,8 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
   __shared__ uint32_t s_dcode[32];
   __shared__ uint32_t s_wtot[2][K4_WAVES];
 
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t t = threadIdx.x, lane = t & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
   const uint32_t chunk = blockIdx.x;
   const ChunkPlan P = plan[chunk];
   const uint64_t off = offsets[chunk];
@@ -848,14 +952,21 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
 // launchers
 // ---------------------------------------------------------------------------
 hipError_t init_kernels() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz77),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz77<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz77<true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS);
 }
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
                        const Options& opt, hipStream_t s) {
-  hipLaunchKernelGGL(k_lz77, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
-                     ws.hist, opt.lazy);
+  if (ws.stamps)
+    hipLaunchKernelGGL(k_lz77<true>, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
+                       ws.hist, opt.lazy, ws.stamps);
+  else
+    hipLaunchKernelGGL(k_lz77<false>, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
+                       ws.hist, opt.lazy, (uint64_t*)nullptr);
   return hipGetLastError();
 }
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of k_lz77 (SFH_K1_STAMPS=1 build; shares only, not a timing claim)."""
+import os
+import sys
+
+os.environ["SFH_K1_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from starflate_amd import Compressor, _capi, synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256 << 20
+data = synth.gen_text_torch(n, seed=3, device="cuda")
+c = Compressor(0)
+for _ in range(2):
+    c.compress_tensor(data)
+st = c.debug(_capi.DBG_STAMPS, n // 32768).astype(np.float64)
+names = ["stage", "match", "take", "walk", "segpre", "emit", "tail"]
+med = np.median(st[:, :7], axis=0)
+print("median cycles per chunk:", {k: int(v) for k, v in zip(names, med)}, "sum", int(med.sum()))
+print("shares:", {k: round(v / med.sum(), 3) for k, v in zip(names, med)})
