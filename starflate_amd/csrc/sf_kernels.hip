@@ -434,9 +434,9 @@ struct PlanSmem {
   uint32_t misc[8];
 };
 
-// Length-limited Huffman code lengths; all 64 lanes call it.  Specification:
-// oracle/sf_oracle.c sfo_build_lengths (two-queue Huffman, clamp, Kraft repair,
-// lengths dealt longest-first to the rarest symbols).
+// Length-limited Huffman code lengths; all 64 lanes call it.  Specification (DESIGN.md,
+// "code lengths"): two-queue Huffman, clamp, Kraft repair, lengths dealt longest-first
+// to the rarest symbols.
 __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uint32_t maxbits,
                               uint8_t* lens, uint32_t lane) {
   uint32_t mloc = 0;

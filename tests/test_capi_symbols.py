@@ -1,0 +1,62 @@
+"""CPU-side checks of the drop-in boundary: libstarflate_hip.so builds for gfx950, loads, and
+exports every symbol include/starflate_hip.h declares; no compute call is made (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from starflate_amd import _capi, build
+
+
+def _declared():
+    with open(os.path.join(ROOT, "include", "starflate_hip.h")) as f:
+        src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(sfh_[a-z_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    build.build()
+    lib = _capi.lib()
+    declared = _declared()
+    assert declared, "no declarations parsed"
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(_capi.EXPORTS) == declared
+
+
+def test_host_side_entry_points_without_gpu():
+    lib = _capi.lib()
+    o = _capi.Options()
+    lib.sfh_default_options(C.byref(o))
+    assert (o.strategy, o.final_stream, o.lazy) == (0, 1, 1) and all(v == 0 for v in o.reserved)
+    assert lib.sfh_compress_bound(0) == 32768 + 4096 + 640
+    assert lib.sfh_compress_bound(32768) == 32768 + 4096 + 640
+    assert lib.sfh_compress_bound(32769) == 2 * (32768 + 4096 + 640)
+    assert lib.sfh_stage_name(0) == b"k_lz77" and lib.sfh_stage_name(3) == b"k_emit" and lib.sfh_stage_name(9) == b""
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product raises; it never routes to the oracle or any CPU path."""
+    lib = _capi.lib()
+    if lib.sfh_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from starflate_amd import Compressor, StarflateError, compress
+
+    with pytest.raises(StarflateError):
+        Compressor(0)
+    with pytest.raises(StarflateError):
+        compress(b"abc")
+    h = C.c_void_p()
+    assert lib.sfh_create(C.byref(h), 0) == -3 and not h.value
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "starflate_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                with open(os.path.join(dirpath, fn), errors="ignore") as f:
+                    txt = f.read()
+                assert "oracle_lib" not in txt and "sf_oracle" not in txt and "sfo_" not in txt, fn

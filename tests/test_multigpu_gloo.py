@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes run the same shard/concat code the GPU ranks
+run over RCCL (starflate_amd/multigpu.py); the per-rank streams are made by the oracle encoder
+(non-final for rank 0, final for rank 1) and the concatenation must decode to the whole input."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_lib as O
+    from starflate_amd import multigpu, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = synth.gen_text(n, seed=8)
+    lo, hi = multigpu.shard_bounds(n, world)[rank]
+    stream = O.compress(data[lo:hi], O.default_params(final_stream=int(rank == world - 1)))
+    local = torch.zeros(stream.size + 100, dtype=torch.uint8)
+    local[: stream.size] = torch.from_numpy(stream)
+    out, total = multigpu.concat_streams(local, stream.size)
+    if rank == 0:
+        st, w, back = O.decompress(out[:total].numpy(), n)
+        q.put((st, w, bool(np.array_equal(back, data)), total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 5 * 32768 + 777), (2, 1000), (3, 7 * 32768)])
+def test_shard_concat_gloo(world, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    st, w, same, total = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert st == 0 and w == n and same and total > 0
+
+
+def test_shard_bounds():
+    from starflate_amd.multigpu import shard_bounds
+
+    for n in (0, 1, 32768, 32769, 10 * 32768 + 5, 1 << 30):
+        for world in (1, 2, 3, 8):
+            b = shard_bounds(n, world)
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            assert all(lo % 32768 == 0 for lo, _ in b if lo < n)

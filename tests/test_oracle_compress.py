@@ -1,0 +1,160 @@
+"""The encoder specification (oracle/sf_oracle.c part 2) on CPU: every stream it emits must
+pass the oracle's restatement of the reference decoder AND zlib inflate, for every strategy,
+edge-case input and parameter set; plus the emitter-contract properties of SURVEY.md
+Appendix A (complete length-limited codes, per-sequence RLE, byte-aligned non-final shards)."""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from starflate_amd import synth
+
+CHUNK = 32768
+
+
+def _cases(starfleet):
+    rng = np.random.default_rng(11)
+    text = synth.gen_text(150_000, seed=2)
+    return {
+        "empty": np.zeros(0, np.uint8),
+        "one": np.array([0], np.uint8),
+        "two": np.frombuffer(b"ab", np.uint8),
+        "four_same": np.frombuffer(b"aaaa", np.uint8),
+        "run_300": np.full(300, 7, np.uint8),
+        "zeros_chunk": np.zeros(CHUNK, np.uint8),
+        "zeros_ragged": np.zeros(2 * CHUNK + 5, np.uint8),
+        "text": text,
+        "text_chunk_pm1": text[: CHUNK + 1],
+        "html": np.frombuffer(starfleet, np.uint8),
+        "random": rng.integers(0, 256, CHUNK + 17, dtype=np.uint8),
+        "all_bytes": np.tile(np.arange(256, dtype=np.uint8), 200),
+        "two_symbols": rng.integers(0, 2, 50_000, dtype=np.uint8),
+        "fib_freqs": np.repeat(np.arange(24, dtype=np.uint8), [1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987, 1597, 2584, 4181, 6765, 10946, 17711, 28657, 46368])[:CHUNK],
+        "mixed": synth.gen_mixed(600_000, seed=4, stripe=1 << 15),
+    }
+
+
+def _check(stream, data):
+    st, w, out = O.decompress(stream, data.size)
+    assert st == 0 and w == data.size and np.array_equal(out, data)
+    assert zlib.decompress(bytes(stream), -15) == data.tobytes()
+
+
+@pytest.mark.parametrize("strategy", [0, 1, 2, 3])
+def test_roundtrip_every_strategy(starfleet, strategy):
+    for name, data in _cases(starfleet).items():
+        s = O.compress(data, O.default_params(strategy=strategy))
+        _check(s, data)
+        assert s.size <= O.lib().sfo_compress_bound(data.size, O.default_params()), name
+
+
+@pytest.mark.parametrize("kw", [
+    dict(lazy=0), dict(step=256), dict(step=4096), dict(hash_bits=10), dict(hash_bits=15),
+    dict(region_bytes=64), dict(region_bytes=2048), dict(region_bytes=32768), dict(cap=0), dict(cap=8),
+    dict(min_match=3), dict(depth=2), dict(depth=3, long_hash_bytes=7), dict(use_near=0),
+    dict(chunk_bytes=4096, region_bytes=512), dict(chain_depth=8),
+])
+def test_roundtrip_parameter_space(starfleet, kw):
+    for name in ("text", "html", "zeros_ragged", "mixed"):
+        data = _cases(starfleet)[name]
+        _check(O.compress(data, O.default_params(**kw)), data)
+
+
+def test_auto_never_exceeds_stored(starfleet):
+    for name, data in _cases(starfleet).items():
+        auto = O.compress(data, O.default_params(strategy=0))
+        stored = O.compress(data, O.default_params(strategy=1))
+        assert auto.size <= stored.size, name
+    nchunks = 3
+    rnd = np.random.default_rng(3).integers(0, 256, nchunks * CHUNK, dtype=np.uint8)
+    assert O.compress(rnd).size == rnd.size + 5 * nchunks  # stored fast path: 5 bytes per block
+
+
+def test_non_final_shards_concatenate(starfleet):
+    """Every shard but the last ends byte-aligned and non-final (final_stream=0), so plain
+    concatenation is one valid stream -- the multi-GPU contract."""
+    data = np.frombuffer(starfleet, np.uint8)
+    cuts = [0, CHUNK, 3 * CHUNK, data.size]
+    parts = [O.compress(data[a:b], O.default_params(final_stream=int(b == data.size))) for a, b in zip(cuts, cuts[1:])]
+    _check(np.concatenate(parts), data)
+    whole = O.compress(data)
+    assert sum(p.size for p in parts) == whole.size and np.array_equal(np.concatenate(parts), whole)
+
+
+def test_build_lengths_properties():
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        n = int(rng.choice([19, 30, 286]))
+        maxbits = 7 if n == 19 else 15
+        kind = trial % 4
+        if kind == 0:
+            f = rng.integers(0, 50, n)
+        elif kind == 1:
+            f = (rng.pareto(0.7, n) * 3).astype(np.int64).clip(0, 32768)
+        elif kind == 2:
+            f = np.zeros(n, np.int64)
+            f[rng.choice(n, size=int(rng.integers(0, 4)), replace=False)] = rng.integers(1, 100)
+        else:
+            fib = [1, 1]
+            while len(fib) < n:
+                fib.append(min(fib[-1] + fib[-2], 32768))
+            f = np.array(fib[:n]) * (rng.random(n) < 0.9)
+        lens = O.build_lengths(f, maxbits)
+        used = f > 0
+        assert np.all(lens[~used] == 0) and np.all(lens[used] >= 1) and lens.max(initial=0) <= maxbits
+        m = int(used.sum())
+        kraft = sum(2.0 ** -int(l) for l in lens[used])
+        if m >= 2:
+            assert abs(kraft - 1.0) < 1e-12, (trial, kraft)  # complete: zlib rejects incomplete CL codes
+        elif m == 1:
+            assert lens[used][0] == 1
+        # rarer symbols never get shorter codes
+        order = np.argsort(f[used], kind="stable")
+        assert np.all(np.diff(lens[used][order].astype(int)) <= 0)
+
+
+def test_huffman_cost_is_optimal_when_unconstrained():
+    """Without the length limit biting, the code must cost exactly what a textbook Huffman code costs."""
+    import heapq
+
+    rng = np.random.default_rng(9)
+    for _ in range(50):
+        f = rng.integers(1, 200, 40)
+        lens = O.build_lengths(np.concatenate([f, np.zeros(246, np.int64)]), 15)
+        h = [(int(x), i) for i, x in enumerate(f)]
+        heapq.heapify(h)
+        cost, k = 0, len(f)
+        while len(h) > 1:
+            a, b = heapq.heappop(h), heapq.heappop(h)
+            cost += a[0] + b[0]
+            heapq.heappush(h, (a[0] + b[0], k))
+            k += 1
+        assert int((lens[:40].astype(np.int64) * f).sum()) == cost
+
+
+def test_dynamic_header_obeys_decoder_hazards(starfleet):
+    """Parse the dynamic header of every chunk the spec emits: the HLIT and HDIST length
+    sequences must each decode on their own (no run crossing over, no leading 16, no overshoot).
+    sfo_decompress returns SFO_ERROR(1) on exactly those, so a clean status 0 is the check;
+    here the RLE items are additionally counted from the plan."""
+    data = np.frombuffer(starfleet, np.uint8)
+    p = O.default_params(strategy=3)
+    for c in range(0, data.size, CHUNK):
+        d = data[c:c + CHUNK]
+        ln, ds = O.match_chunk(d, p)
+        t, nt = O.parse_chunk(d, p, ln, ds)
+        ll, dd = O.histogram(t, nt, p.region_bytes)
+        pl = O.plan_chunk(ll, dd, d.size, False, p)
+        assert pl.btype == 2 and 17 <= pl.header_bits <= 4492
+        assert max(pl.ll_lens) <= 15 and max(pl.d_lens) <= 15
+        assert pl.ll_lens[256] >= 1 and pl.ll_lens[286] == 0 and pl.ll_lens[287] == 0
+        assert pl.d_lens[30] == 0 and pl.d_lens[31] == 0
+
+
+def test_ratio_floor_vs_zlib6(starfleet):
+    """Guard rail on match quality: the block-parallel parse must stay within 25 % of zlib -6."""
+    for data in (synth.gen_text(1 << 20, seed=3), np.frombuffer(starfleet, np.uint8)):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        z = len(co.compress(data.tobytes())) + len(co.flush())
+        assert O.compress(data).size <= 1.33 * z

@@ -1,0 +1,318 @@
+"""Pins the oracle's restatement of the reference decoder (oracle/sf_oracle.c part 1)
+against the reference's own test vectors, restated as data:
+
+  /root/reference/src/test/decompress_test.cpp:62-181   header / stored / fixed / dynamic / copy
+  /root/reference/huffman/test/table_from_symbol_bitsize_test.cpp:19-149  canonical codes
+  /root/reference/huffman/test/decode_test.cpp:13-266   per-bit decode
+  /root/reference/huffman/test/bit_span_test.cpp:22-32,159-178  bit and byte order
+
+plus the SURVEY.md 8(c) probe streams (A, B, F, G, H) rebuilt bit by bit, and zlib-made
+streams of every block type as a third-party cross-check.  The reference itself cannot be
+built here (<expected> is missing from the image), so these vectors are the pin."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN
+
+OK, ERROR, BAD_HEADER, LEN_MISMATCH, DST_SMALL, SRC_SMALL, BAD_LITLEN, BAD_DIST = range(8)
+
+
+class BitWriter:
+    """LSB-first bit packer (inverse of huffman/src/bit_span.hpp:46-53)."""
+
+    def __init__(self):
+        self.bits = []
+
+    def put(self, value, n):  # plain integer, LSB first (src/decompress.cpp:108-111)
+        for i in range(n):
+            self.bits.append((value >> i) & 1)
+
+    def code(self, value, n):  # Huffman code, MSB first (huffman/src/decode.hpp:90-91)
+        for i in reversed(range(n)):
+            self.bits.append((value >> i) & 1)
+
+    def align(self):
+        while len(self.bits) % 8:
+            self.bits.append(0)
+
+    def bytes(self):
+        b = self.bits + [0] * (-len(self.bits) % 8)
+        return bytes(sum(b[i + k] << k for k in range(8)) for i in range(0, len(b), 8))
+
+
+def fixed_lit(w, sym):  # RFC 1951 3.2.6 / src/decompress.cpp:16-34
+    if sym < 144:
+        w.code(0x30 + sym, 8)
+    elif sym < 256:
+        w.code(0x190 + sym - 144, 9)
+    elif sym < 280:
+        w.code(sym - 256, 7)
+    else:
+        w.code(0xC0 + sym - 280, 8)
+
+
+# ---- src/test/decompress_test.cpp:62-89 read_header ----
+def test_read_header_kats():
+    import ctypes as C
+
+    L = O.lib()
+    fin, typ = C.c_int(), C.c_int()
+    assert L.sfo_read_header(None, 0, C.byref(fin), C.byref(typ)) == BAD_HEADER
+    for byte, want in ((0b111, None), (0b010, (0, 1)), (0b001, (1, 0))):
+        buf = np.array([byte], np.uint8)
+        st = L.sfo_read_header(buf.ctypes.data, 8, C.byref(fin), C.byref(typ))
+        if want is None:
+            assert st == BAD_HEADER
+        else:
+            assert st == OK and (fin.value, typ.value) == want
+
+
+# ---- :91-95 ----
+def test_empty_input_is_invalid_block_header():
+    st, w, _ = O.decompress(b"", 0)
+    assert st == BAD_HEADER and w == 0
+
+
+# ---- :97-134 stored two-block stream ----
+ROSEBUD = bytes([0b000, 4, 0, 0xFB, 0xFF]) + b"rose" + bytes([0b001, 3, 0, 0xFC, 0xFF]) + b"bud"
+
+
+def test_stored_rose_bud():
+    st, w, out = O.decompress(ROSEBUD, 7)
+    assert st == OK and w == 7 and out.tobytes() == b"rosebud"
+    assert O.decompress(ROSEBUD, 6)[0] == DST_SMALL
+    assert O.decompress(ROSEBUD[:5], 7)[0] == SRC_SMALL
+
+
+def test_stored_len_mismatch():
+    bad = bytearray(ROSEBUD)
+    bad[3] ^= 1
+    assert O.decompress(bytes(bad), 7)[0] == LEN_MISMATCH
+
+
+# ---- :136-174 fixtures made by the reference's tools/deflate_compress.py ----
+@pytest.mark.parametrize("name,btype", [("starfleet.html.fixed", 1), ("starfleet.html.dynamic", 2)])
+def test_reference_fixtures(starfleet, name, btype):
+    import ctypes as C
+
+    with open(os.path.join(GOLDEN, name), "rb") as f:
+        comp = f.read()
+    fin, typ = C.c_int(), C.c_int()
+    buf = np.frombuffer(comp, np.uint8)
+    assert O.lib().sfo_read_header(buf.ctypes.data, 8 * buf.size, C.byref(fin), C.byref(typ)) == OK
+    assert typ.value == btype
+    st, w, out = O.decompress(comp, len(starfleet))
+    assert st == OK and w == len(starfleet) and out.tobytes() == starfleet
+    assert O.decompress(comp, len(starfleet) - 1)[0] == DST_SMALL
+    assert zlib.decompress(comp, -15) == starfleet
+
+
+# ---- :176-181 ----
+def test_copy_from_before():
+    buf = np.array([1, 2, 0, 0, 0, 0], np.uint8)
+    O.lib().sfo_copy_from_before(2, buf.ctypes.data + 2, 3)
+    assert buf.tolist() == [1, 2, 1, 2, 1, 0]
+
+
+# ---- table_from_symbol_bitsize_test.cpp:19-149 ----
+def test_canonical_rfc_example_1():
+    lens = np.zeros(128, np.uint8)
+    lens[ord("A")], lens[ord("B")], lens[ord("C")], lens[ord("D")] = 2, 1, 3, 3
+    c = O.canonical_codes(lens)
+    assert [c[ord(x)] for x in "BACD"] == [0b0, 0b10, 0b110, 0b111]
+
+
+def test_canonical_rfc_example_2():
+    lens = np.zeros(128, np.uint8)
+    for ch, n in zip("ABCDEFGH", (3, 3, 3, 3, 3, 2, 4, 4)):
+        lens[ord(ch)] = n
+    c = O.canonical_codes(lens)
+    assert [c[ord(x)] for x in "FABCDEGH"] == [0b00, 0b010, 0b011, 0b100, 0b101, 0b110, 0b1110, 0b1111]
+
+
+def test_fixed_table_code_ranges():
+    lens = np.array([8] * 144 + [9] * 112 + [7] * 24 + [8] * 8, np.uint8)
+    c = O.canonical_codes(lens)
+    assert (c[0], c[143]) == (0x30, 0xBF)
+    assert (c[144], c[255]) == (0x190, 0x1FF)
+    assert (c[256], c[279]) == (0x00, 0x17)
+    assert (c[280], c[287]) == (0xC0, 0xC7)
+
+
+# ---- decode_test.cpp: table e=0 i=10 n=110 q=1110 eot=11110 x=11111 ----
+DEC_LENS = np.zeros(128, np.uint8)
+for _ch, _n in (("e", 1), ("i", 2), ("n", 3), ("q", 4), ("\4", 5), ("x", 5)):
+    DEC_LENS[ord(_ch)] = _n
+
+
+def _dec(data, nbits):
+    return "".join(chr(s) for s in O.huffman_decode(DEC_LENS, bytes(data), nbits))
+
+
+def test_decode_kats():
+    assert _dec([0], 0) == ""
+    assert _dec([0b11111011], 8) == "nx"
+    assert _dec([0b11111011, 0b00010111], 16) == "nxqiee"
+    assert _dec([0b11111011, 0b00010111], 14) == "nxqi"
+    assert _dec([0b10111110, 0b11000001, 0b01011111], 24) == "exeneeeexni"
+    assert _dec([0b10111110, 0b11000001, 0b01011111, 0b00110111, 0b01101001, 0b00111101], 47) == "exeneeeexniqneieini\4"
+
+
+def test_bit_and_byte_order():
+    # bit_span_test.cpp:22-32: bytes 0b10101010, 0xff iterate as 0101010111111111
+    lens = np.zeros(2, np.uint8)
+    lens[0] = lens[1] = 1  # code '0' -> symbol 0, '1' -> symbol 1: decoding yields the raw bits
+    bits = O.huffman_decode(lens, bytes([0b10101010, 0xFF]), 16)
+    assert "".join(map(str, bits)) == "0101010111111111"
+    # bit_span_test.cpp:159-178: pop_16 of {0xAA,0x55} is 0x55AA -> stored LEN is little-endian
+    blk = bytes([1, 0xAA, 0x55, 0x55, 0xAA])
+    assert O.decompress(blk, 0x55AA)[0] == SRC_SMALL  # len parsed as 0x55AA, payload missing
+
+
+# ---- SURVEY.md 8(c) probes, rebuilt bit by bit ----
+def _dyn_header(w, ll_lens, d_lens):
+    """Dynamic header with every code length sent literally through a flat 5-bit... no:
+    uses a code-length code where symbols 0..15 all have 4 bits (complete code)."""
+    hlit, hdist = len(ll_lens), len(d_lens)
+    w.put(hlit - 257, 5)
+    w.put(hdist - 1, 5)
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    cl = {s: 4 for s in range(16)}
+    w.put(19 - 4, 4)
+    for s in order:
+        w.put(cl.get(s, 0), 3)
+    for v in list(ll_lens) + list(d_lens):
+        w.code(v, 4)  # canonical: symbol s of 16 four-bit codes has code value s
+
+
+def test_probe_A_literals_only_no_distance_code():
+    w = BitWriter()
+    w.put(1, 1)
+    w.put(2, 2)
+    ll = [0] * 257
+    ll[ord("a")], ll[ord("b")], ll[256] = 1, 2, 2
+    _dyn_header(w, ll, [0])
+    for ch in "abba":
+        w.code({"a": 0b0, "b": 0b10}[ch], {"a": 1, "b": 2}[ch])
+    w.code(0b11, 2)
+    s = w.bytes()
+    st, n, out = O.decompress(s, 4)
+    assert st == OK and out.tobytes() == b"abba"
+    assert zlib.decompress(s, -15) == b"abba"
+
+
+def test_probe_B_single_one_bit_distance_code_overlap():
+    w = BitWriter()
+    w.put(1, 1)
+    w.put(2, 2)
+    ll = [0] * 258
+    ll[ord("x")], ll[256], ll[257] = 1, 2, 2  # x=0, EOB=10, len3=11
+    _dyn_header(w, ll, [1])
+    w.code(0, 1)          # 'x'
+    w.code(0b11, 2)       # length symbol 257 = len 3
+    w.code(0, 1)          # distance code 0 = dist 1
+    w.code(0b10, 2)       # EOB
+    s = w.bytes()
+    st, n, out = O.decompress(s, 4)
+    assert st == OK and out.tobytes() == b"xxxx"
+    assert zlib.decompress(s, -15) == b"xxxx"
+
+
+def test_probe_F_empty_stored_then_fixed_eob():
+    w = BitWriter()
+    w.put(0, 3)
+    w.align()
+    w.put(0, 16)
+    w.put(0xFFFF, 16)
+    w.put(1, 1)
+    w.put(1, 2)
+    fixed_lit(w, 256)
+    st, n, _ = O.decompress(w.bytes(), 0)
+    assert st == OK and n == 0
+
+
+def test_probe_G_stored_len_65535():
+    payload = np.random.default_rng(1).integers(0, 256, 65535, dtype=np.uint8).tobytes()
+    s = bytes([1, 0xFF, 0xFF, 0x00, 0x00]) + payload
+    st, n, out = O.decompress(s, 65535)
+    assert st == OK and n == 65535 and out.tobytes() == payload
+
+
+def test_probe_H_fixed_len258_dist1():
+    w = BitWriter()
+    w.put(1, 1)
+    w.put(1, 2)
+    fixed_lit(w, ord("z"))
+    fixed_lit(w, 285)
+    w.code(0, 5)
+    fixed_lit(w, 256)
+    st, n, out = O.decompress(w.bytes(), 259)
+    assert st == OK and out.tobytes() == b"z" * 259
+
+
+def test_status_codes_of_bad_symbols():
+    # lit/len 286 in a fixed block -> InvalidLitOrLen (src/decompress.cpp:131-133)
+    w = BitWriter()
+    w.put(1, 1); w.put(1, 2); fixed_lit(w, 286)
+    assert O.decompress(w.bytes(), 10)[0] == BAD_LITLEN
+    # distance code 30 -> InvalidLitOrLen (:170-172)
+    w = BitWriter()
+    w.put(1, 1); w.put(1, 2); fixed_lit(w, ord("a")); fixed_lit(w, 257); w.code(30, 5)
+    assert O.decompress(w.bytes(), 10)[0] == BAD_LITLEN
+    # distance beyond the bytes written -> InvalidDistance (:177-179)
+    w = BitWriter()
+    w.put(1, 1); w.put(1, 2); fixed_lit(w, ord("a")); fixed_lit(w, 257); w.code(1, 5); fixed_lit(w, 256)
+    assert O.decompress(w.bytes(), 10)[0] == BAD_DIST
+    # output too small inside a Huffman block -> DstTooSmall (:149-151, :180-182)
+    w = BitWriter()
+    w.put(1, 1); w.put(1, 2); fixed_lit(w, ord("a")); fixed_lit(w, ord("b")); fixed_lit(w, 256)
+    assert O.decompress(w.bytes(), 1)[0] == DST_SMALL
+
+
+def test_hazard_inputs_are_flagged():
+    """RFC-legal streams on which the reference has undefined behaviour:
+    the oracle reports SFO_ERROR so an encoder emitting them can never pass the gate."""
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    # hazard B: distance sequence starting with symbol 16
+    w = BitWriter()
+    w.put(1, 1); w.put(2, 2); w.put(0, 5); w.put(0, 5); w.put(15, 4)
+    cl = {16: 2, 0: 2, 1: 2, 2: 2}  # complete: four 2-bit codes; canonical order 0,1,2,16
+    for s in order:
+        w.put(cl.get(s, 0), 3)
+    codes = {0: 0b00, 1: 0b01, 2: 0b10, 16: 0b11}
+    for v in [1] * 2 + [0] * 254 + [2]:  # 257 lit/len lengths, literal symbols only
+        w.code(codes[v], 2)
+    w.code(codes[16], 2); w.put(0, 2)    # distance lengths begin with "repeat previous"
+    assert O.decompress(w.bytes(), 10)[0] == ERROR
+
+
+@pytest.mark.parametrize("level,strategy", [(0, 0), (1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)])
+def test_zlib_streams_all_block_types(starfleet, level, strategy):
+    data = starfleet * 3
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    s = co.compress(data) + co.flush()
+    st, n, out = O.decompress(s, len(data))
+    assert st == OK and n == len(data) and out.tobytes() == data
+
+
+def test_zlib_flush_points_and_concatenated_shards(starfleet):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    s = b""
+    step = len(starfleet) // 8
+    for k in range(8):
+        s += co.compress(starfleet[k * step:(k + 1) * step]) + co.flush(zlib.Z_SYNC_FLUSH)
+    s += co.compress(starfleet[8 * step:]) + co.flush()
+    st, n, out = O.decompress(s, len(starfleet))
+    assert st == OK and out.tobytes() == starfleet
+    # independently compressed shards, all but the last ended by a full flush (non-final, aligned)
+    parts = []
+    for k in range(4):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        chunk = starfleet[k * 40000:(k + 1) * 40000] if k < 3 else starfleet[120000:]
+        parts.append(c.compress(chunk) + (c.flush(zlib.Z_FULL_FLUSH) if k < 3 else c.flush()))
+    st, n, out = O.decompress(b"".join(parts), len(starfleet))
+    assert st == OK and out.tobytes() == starfleet
