@@ -1,0 +1,100 @@
+// starflate::compress -- the sibling of decompress(): raw RFC 1951 out of the MI355X kernels.
+// Thin C++23 wrapper over the C-ABI (include/starflate_hip.h); link with libstarflate_hip.so.
+// Same conventions as the reference's one public function
+// (/root/reference/src/decompress.hpp:63-71): non-owning spans, caller-owned buffers, no
+// exceptions, a uint8_t status enum; the size comes back through expected<>.
+#pragma once
+#include "starflate/compat/expected.hpp"
+#include "starflate_hip.h"
+
+#include <cstddef>
+#include <cstdint>
+#include <span>
+#include <utility>
+
+namespace starflate {
+
+enum class CompressStatus : std::uint8_t {
+  Success,
+  InvalidArgument,
+  DstTooSmall,  // dst.size() < compress_bound(src.size())
+  NoDevice,     // no MI355X visible: there is no CPU fallback
+  DeviceError,
+  OutOfMemory,
+};
+
+enum class BlockStrategy : std::uint8_t { Auto, Stored, Fixed, Dynamic };
+
+struct compress_options {
+  BlockStrategy strategy{BlockStrategy::Auto};
+  bool final_stream{true};  // false: byte-aligned, non-final stream (a shard that is not the last)
+  bool lazy{true};
+  int device{0};
+};
+
+inline auto compress_bound(std::size_t n) -> std::size_t { return sfh_compress_bound(n); }
+
+namespace detail {
+inline auto to_status(int rc) -> CompressStatus {
+  switch (rc) {
+    case SFH_OK: return CompressStatus::Success;
+    case SFH_E_DST_TOO_SMALL: return CompressStatus::DstTooSmall;
+    case SFH_E_NO_DEVICE: return CompressStatus::NoDevice;
+    case SFH_E_HIP: return CompressStatus::DeviceError;
+    case SFH_E_NOMEM: return CompressStatus::OutOfMemory;
+    default: return CompressStatus::InvalidArgument;
+  }
+}
+inline auto to_c(const compress_options& o) -> sfh_options {
+  sfh_options c;
+  sfh_default_options(&c);
+  c.strategy = static_cast<std::uint32_t>(o.strategy);
+  c.final_stream = o.final_stream ? 1U : 0U;
+  c.lazy = o.lazy ? 1U : 0U;
+  return c;
+}
+}  // namespace detail
+
+/// One GPU context (device scratch, stream).  Not thread-safe; distinct objects are independent.
+class compressor {
+  sfh_ctx* ctx_{nullptr};
+  CompressStatus init_{CompressStatus::Success};
+
+ public:
+  explicit compressor(int device = 0) { init_ = detail::to_status(sfh_create(&ctx_, device)); }
+  compressor(const compressor&) = delete;
+  auto operator=(const compressor&) -> compressor& = delete;
+  compressor(compressor&& o) noexcept : ctx_{std::exchange(o.ctx_, nullptr)}, init_{o.init_} {}
+  ~compressor() { sfh_destroy(ctx_); }
+  [[nodiscard]] auto status() const -> CompressStatus { return init_; }
+
+  /// host spans: H2D, compress, D2H
+  auto compress(std::span<const std::byte> src, std::span<std::byte> dst, const compress_options& opt = {})
+      -> compat::expected<std::size_t, CompressStatus> {
+    if (!ctx_) return compat::unexpected{init_};
+    const auto c = detail::to_c(opt);
+    std::size_t n = 0;
+    const int rc = sfh_compress(ctx_, src.data(), src.size(), dst.data(), dst.size(), &n, &c);
+    if (rc != SFH_OK) return compat::unexpected{detail::to_status(rc)};
+    return n;
+  }
+  /// device pointers (src 16-byte aligned), optional hipStream_t
+  auto compress_device(const void* d_src, std::size_t n, void* d_dst, std::size_t cap, const compress_options& opt = {},
+                       void* stream = nullptr) -> compat::expected<std::size_t, CompressStatus> {
+    if (!ctx_) return compat::unexpected{init_};
+    const auto c = detail::to_c(opt);
+    std::size_t out = 0;
+    const int rc = sfh_compress_device(ctx_, d_src, n, d_dst, cap, &out, &c, stream);
+    if (rc != SFH_OK) return compat::unexpected{detail::to_status(rc)};
+    return out;
+  }
+};
+
+/// Compresses `src` into `dst` (dst.size() >= compress_bound(src.size())); returns the stream size.
+inline auto compress(std::span<const std::byte> src, std::span<std::byte> dst, const compress_options& opt = {})
+    -> compat::expected<std::size_t, CompressStatus> {
+  compressor c{opt.device};
+  return c.compress(src, dst, opt);
+}
+
+}  // namespace starflate

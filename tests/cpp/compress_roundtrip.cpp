@@ -1,0 +1,58 @@
+// GPU test of the C++23 API: starflate::compress() (HIP kernels through the C-ABI) followed by
+// starflate::decompress() must reproduce the input -- the slot the reference's
+// src/test/decompress_test.cpp:136-174 fills with zlib-made fixtures.  argv[1] = tests/golden.
+#include "starflate/compress.hpp"
+#include "starflate/decompress.hpp"
+
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+static auto read_file(const std::string& path) -> std::vector<std::byte> {
+  std::ifstream f{path, std::ios::binary};
+  std::vector<char> c((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::vector<std::byte> b(c.size());
+  for (std::size_t i = 0; i < c.size(); ++i) b[i] = static_cast<std::byte>(c[i]);
+  return b;
+}
+
+auto main(int argc, char** argv) -> int {
+  using namespace starflate;
+  const std::string golden = argc > 1 ? argv[1] : "tests/golden";
+  const auto html = read_file(golden + "/starfleet.html");
+  int fail = 0;
+  compressor gpu{0};
+  if (gpu.status() != CompressStatus::Success) {
+    std::printf("no device: status %d\n", static_cast<int>(gpu.status()));
+    return 2;
+  }
+  const std::vector<std::vector<std::byte>> inputs{{}, {std::byte{'x'}}, html, std::vector<std::byte>(100000, std::byte{0})};
+  for (const auto strategy : {BlockStrategy::Auto, BlockStrategy::Stored, BlockStrategy::Fixed, BlockStrategy::Dynamic}) {
+    for (const auto& in : inputs) {
+      std::vector<std::byte> comp(compress_bound(in.size()));
+      compress_options opt;
+      opt.strategy = strategy;
+      const auto n = gpu.compress(in, comp, opt);
+      if (!n) { std::printf("compress failed: %d\n", static_cast<int>(n.error())); ++fail; continue; }
+      comp.resize(*n);
+      std::vector<std::byte> back(in.size());
+      const auto st = decompress(comp, back);
+      if (st != DecompressStatus::Success || back != in) {
+        std::printf("round trip failed: strategy %d size %zu status %d\n", static_cast<int>(strategy), in.size(), static_cast<int>(st));
+        ++fail;
+      }
+    }
+  }
+  // too-small destination: status, no exception
+  std::vector<std::byte> tiny(8);
+  const auto r = gpu.compress(html, tiny);
+  if (r || r.error() != CompressStatus::DstTooSmall) { std::printf("expected DstTooSmall\n"); ++fail; }
+  // free function
+  std::vector<std::byte> comp(compress_bound(html.size()));
+  const auto n = compress(html, comp);
+  if (!n || *n == 0 || *n >= html.size()) { std::printf("free compress() failed\n"); ++fail; }
+  std::printf("compress_roundtrip: %d failures\n", fail);
+  return fail ? 1 : 0;
+}

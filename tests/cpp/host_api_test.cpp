@@ -1,0 +1,238 @@
+// Host C++23 API checks, CPU only.  The cases restate, as data, what the reference's own
+// tests assert (boost.ut is not available, so a 10-line checker stands in):
+//   huffman/test/{bit,code,bit_span,table_from_*,table_find_code,decode}_test.cpp
+//   src/test/decompress_test.cpp
+// argv[1] = tests/golden directory.
+#include "starflate/decompress.hpp"
+#include "starflate/huffman/huffman.hpp"
+
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace huffman = starflate::huffman;
+using namespace huffman::literals;
+using starflate::DecompressStatus;
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                   \
+  do {                                                                \
+    ++g_checks;                                                       \
+    if (!(cond)) {                                                    \
+      ++g_fail;                                                       \
+      std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);     \
+    }                                                                 \
+  } while (0)
+
+static auto read_file(const std::string& path) -> std::vector<std::byte> {
+  std::ifstream f{path, std::ios::binary};
+  std::vector<char> c((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::vector<std::byte> b(c.size());
+  for (std::size_t i = 0; i < c.size(); ++i) b[i] = static_cast<std::byte>(c[i]);
+  return b;
+}
+
+template <class T>
+static auto str(const T& v) -> std::string {
+  std::ostringstream ss;
+  ss << v;
+  return ss.str();
+}
+
+static void test_bit_and_code() {
+  CHECK(bool(huffman::bit{1}) && !bool(huffman::bit{0}) && bool(huffman::bit{'1'}) && bool(1_b) && !bool(0_b));
+  CHECK(str(huffman::bit{true}) == "1");
+  constexpr auto c = 110_c;
+  static_assert(c.bitsize() == 3 && c.value() == 6);
+  CHECK(str(c) == "110" && str(00101_c) == "00101");
+  auto d = huffman::code{};
+  d << 1_b << 0_b << 1_b;  // right pad
+  CHECK(d == 101_c);
+  1_b >> d;                // left pad
+  CHECK(d == 1101_c);
+  CHECK((1_c < 00_c) && (01_c < 10_c));  // ordered by (bitsize, value)
+  CHECK(sizeof(huffman::code) == 16);
+}
+
+static void test_bit_span() {
+  constexpr auto data = huffman::byte_array(0b10101010, 0xff);
+  std::string s;
+  for (auto b : huffman::bit_span{data}) s += static_cast<char>(b);
+  CHECK(s == "0101010111111111");
+  huffman::bit_span sp{data};
+  sp.consume(3);
+  CHECK(std::ranges::size(sp) == 13 && bool(*sp.begin()) == true);
+  sp.consume_to_byte_boundary();
+  CHECK(std::ranges::size(sp) == 8 && sp.byte_data() == data.data() + 1);
+  constexpr auto le = huffman::byte_array(0xAA, 0x55, 0x01);
+  huffman::bit_span p{le};
+  CHECK(p.pop_16() == 0x55AA && p.pop_8() == 0x01 && p.empty());
+  huffman::bit_span off{data.data(), 5, 2};
+  std::string t;
+  for (auto b : off) t += static_cast<char>(b);
+  CHECK(t == "01010");
+}
+
+static void test_table_from_frequencies() {
+  const auto freq = std::vector<std::pair<char, std::size_t>>{{'e', 100}, {'n', 20}, {'x', 1}, {'i', 40}, {'q', 3}};
+  const auto with_eot = huffman::table{freq, char{4}};
+  CHECK(str(with_eot) ==
+        "Bits\tCode\tValue\tSymbol\n1\t0\t0\t`e`\n2\t10\t2\t`i`\n3\t110\t6\t`n`\n4\t1110\t14\t`q`\n"
+        "5\t11110\t30\t`\4`\n5\t11111\t31\t`x`\n");
+  const auto no_eot = huffman::table{freq};
+  CHECK(str(no_eot) ==
+        "Bits\tCode\tValue\tSymbol\n1\t0\t0\t`e`\n2\t10\t2\t`i`\n3\t110\t6\t`n`\n4\t1110\t14\t`q`\n4\t1111\t15\t`x`\n");
+  // five equal weights: a,b three bits; c,d,e two bits (SURVEY.md 3.3 probe)
+  const auto eq = huffman::table{std::vector<std::pair<char, std::size_t>>{{'a', 1}, {'b', 1}, {'c', 1}, {'d', 1}, {'e', 1}}};
+  std::string lens;
+  for (const auto& e : eq) lens += std::string(1, e.symbol) + std::to_string(e.bitsize());
+  CHECK(lens == "c2d2e2a3b3");
+  // 24 Fibonacci weights: no length limit in this constructor
+  std::vector<std::pair<int, std::size_t>> fib;
+  std::size_t a = 1, b = 1;
+  for (int i = 0; i < 24; ++i) { fib.emplace_back(i, a); const auto n = a + b; a = b; b = n; }
+  std::uint8_t longest = 0;
+  for (const auto& e : huffman::table{fib}) longest = std::max(longest, e.bitsize());
+  CHECK(longest == 23);
+}
+
+static void test_table_from_data_and_edges() {
+  const auto t = huffman::table{std::string_view{"eeeeeeeeiiiinnq"}, char{4}};
+  CHECK(t.begin()->symbol == 'e' && t.begin()->bitsize() == 1 && t.size() == 5);
+  const auto one = huffman::table{std::string_view{"aaaa"}};
+  CHECK(one.size() == 1 && one.begin()->bitsize() == 1 && one.begin()->value() == 0);
+  const huffman::table<char> empty{};
+  CHECK(empty.begin() == empty.end());
+}
+
+static void test_table_from_symbol_bitsize() {
+  // RFC 1951 3.2.2 example 1
+  static constexpr auto t1 = huffman::table<char, 4>{huffman::symbol_bitsize, {{'A', 2}, {'B', 1}, {{'C', 'D'}, 3}}};
+  static constexpr auto e1 = huffman::table{huffman::table_contents,
+                                            {std::pair{0_c, 'B'}, {10_c, 'A'}, {110_c, 'C'}, {111_c, 'D'}}};
+  static_assert(std::ranges::equal(t1, e1));
+  // example 2
+  static constexpr auto t2 = huffman::table<char, 8>{huffman::symbol_bitsize, {{{'A', 'E'}, 3}, {'F', 2}, {{'G', 'H'}, 4}}};
+  static constexpr auto e2 = huffman::table{huffman::table_contents,
+      {std::pair{00_c, 'F'}, {010_c, 'A'}, {011_c, 'B'}, {100_c, 'C'}, {101_c, 'D'}, {110_c, 'E'}, {1110_c, 'G'}, {1111_c, 'H'}}};
+  static_assert(std::ranges::equal(t2, e2));
+  CHECK(std::ranges::equal(t1, e1) && std::ranges::equal(t2, e2));
+  // RFC 1951 3.2.6 fixed literal/length code
+  using span = huffman::symbol_span<std::uint16_t>;
+  const auto fixed = huffman::table<std::uint16_t, 288>{
+      huffman::symbol_bitsize, {{span{0, 143}, 8}, {span{144, 255}, 9}, {span{256, 279}, 7}, {span{280, 287}, 8}}};
+  auto code_of = [&](std::uint16_t s) {
+    for (const auto& e : fixed)
+      if (e.symbol == s) return static_cast<const huffman::code&>(e);
+    return huffman::code{};
+  };
+  CHECK(code_of(0) == huffman::code(8, 0x30) && code_of(143) == huffman::code(8, 0xBF));
+  CHECK(code_of(144) == huffman::code(9, 0x190) && code_of(255) == huffman::code(9, 0x1FF));
+  CHECK(code_of(256) == huffman::code(7, 0x00) && code_of(279) == huffman::code(7, 0x17));
+  CHECK(code_of(280) == huffman::code(8, 0xC0) && code_of(287) == huffman::code(8, 0xC7));
+}
+
+static constexpr auto kTable = huffman::table{
+    huffman::table_contents,
+    {std::pair{0_c, 'e'}, {10_c, 'i'}, {110_c, 'n'}, {1110_c, 'q'}, {11110_c, '\4'}, {11111_c, 'x'}}};
+
+static void test_find() {
+  static_assert(kTable.find(0_c).value()->symbol == 'e');
+  static_assert(kTable.find(11111_c).value()->symbol == 'x');
+  CHECK(kTable.find(10_c).value()->symbol == 'i' && kTable.find(1110_c).value()->symbol == 'q');
+  // a prefix of longer codes: error = first entry with a longer bitsize
+  const auto r1 = kTable.find(1_c);
+  CHECK(!r1 && r1.error()->symbol == 'i' && r1.error()->bitsize() == 2);
+  const auto r2 = kTable.find(11_c);
+  CHECK(!r2 && r2.error()->symbol == 'n');
+  const auto r3 = kTable.find(111_c, r2.error());
+  CHECK(!r3 && r3.error()->symbol == 'q');
+  // beyond the longest code: end()
+  CHECK(kTable.find(111111_c).error() == kTable.end());
+  CHECK(kTable.find(11110_c, kTable.find(1111_c).error()).value()->symbol == '\4');
+}
+
+template <std::size_t N>
+static auto dec(const std::array<std::byte, N>& bytes, std::size_t drop_bits = 0) -> std::string {
+  std::string out;
+  huffman::decode(kTable, huffman::bit_span{bytes.data(), N * CHAR_BIT - drop_bits}, std::back_inserter(out));
+  return out;
+}
+
+static void test_decode() {
+  std::string none;
+  huffman::decode(kTable, huffman::bit_span{}, std::back_inserter(none));
+  CHECK(none.empty());
+  CHECK(dec(huffman::byte_array(0b11111011)) == "nx");
+  CHECK(dec(huffman::byte_array(0b11111011, 0b00010111)) == "nxqiee");
+  CHECK(dec(huffman::byte_array(0b11111011, 0b00010111), 2) == "nxqi");
+  CHECK(dec(huffman::byte_array(0b10111110, 0b11000001, 0b01011111)) == "exeneeeexni");
+  CHECK(dec(huffman::byte_array(0b10111110, 0b11000001, 0b01011111, 0b00110111, 0b01101001, 0b00111101), 1) ==
+        "exeneeeexniqneieini\4");
+  constexpr auto one_e = huffman::byte_array(0);
+  const auto r = huffman::decode_one(kTable, huffman::bit_span{one_e.data(), 1, 7});
+  CHECK(r.has_value() && r.symbol() == 'e' && r.encoded_size() == 1);
+}
+
+static void test_decompress(const std::string& golden) {
+  using starflate::decompress;
+  namespace detail = starflate::detail;
+  {
+    huffman::bit_span empty{nullptr, 0, 0};
+    CHECK(detail::read_header(empty).error() == DecompressStatus::InvalidBlockHeader);
+    constexpr auto bad = huffman::byte_array(0b111);
+    huffman::bit_span b{bad};
+    CHECK(detail::read_header(b).error() == DecompressStatus::InvalidBlockHeader);
+    constexpr auto fixed = huffman::byte_array(0b010);
+    huffman::bit_span f{fixed};
+    const auto h = detail::read_header(f);
+    CHECK(h && !h->final && h->type == detail::BlockType::FixedHuffman);
+    constexpr auto stored = huffman::byte_array(0b001);
+    huffman::bit_span s{stored};
+    const auto g = detail::read_header(s);
+    CHECK(g && g->final && g->type == detail::BlockType::NoCompression);
+  }
+  CHECK(decompress(std::span<const std::byte>{}, std::span<std::byte>{}) == DecompressStatus::InvalidBlockHeader);
+  {
+    constexpr auto comp = huffman::byte_array(0b000, 4, 0, ~4, ~0, 'r', 'o', 's', 'e', 0b001, 3, 0, ~3, ~0, 'b', 'u', 'd');
+    constexpr auto want = huffman::byte_array('r', 'o', 's', 'e', 'b', 'u', 'd');
+    std::array<std::byte, want.size()> dst{};
+    const std::span<const std::byte> src{comp};
+    CHECK(decompress(src, std::span<std::byte>{dst.data(), dst.size() - 1}) == DecompressStatus::DstTooSmall);
+    CHECK(decompress(src.subspan(0, 5), std::span<std::byte>{dst}) == DecompressStatus::SrcTooSmall);
+    CHECK(decompress(src, std::span<std::byte>{dst}) == DecompressStatus::Success && std::ranges::equal(dst, want));
+    CHECK(decompress(comp, std::span<std::byte>{dst}) == DecompressStatus::Success);  // range overload
+  }
+  {
+    const auto want = read_file(golden + "/starfleet.html");
+    for (const char* name : {"/starfleet.html.fixed", "/starfleet.html.dynamic"}) {
+      const auto comp = read_file(golden + name);
+      std::vector<std::byte> dst(want.size());
+      CHECK(!comp.empty() && decompress(comp, dst) == DecompressStatus::Success && dst == want);
+    }
+  }
+  {
+    auto buf = huffman::byte_array(1, 2, 0, 0, 0, 0);
+    const auto d = std::span<std::byte>{buf}.subspan(2);
+    detail::copy_from_before(2, d.begin(), 3);
+    CHECK(buf == huffman::byte_array(1, 2, 1, 2, 1, 0));
+  }
+  static_assert(static_cast<int>(DecompressStatus::InvalidDistance) == 7 && static_cast<int>(DecompressStatus::DstTooSmall) == 4);
+}
+
+auto main(int argc, char** argv) -> int {
+  const std::string golden = argc > 1 ? argv[1] : "tests/golden";
+  test_bit_and_code();
+  test_bit_span();
+  test_table_from_frequencies();
+  test_table_from_data_and_edges();
+  test_table_from_symbol_bitsize();
+  test_find();
+  test_decode();
+  test_decompress(golden);
+  std::printf("%d checks, %d failed\n", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -1,0 +1,44 @@
+"""Compiles and runs the C++23 host-API tests (tests/cpp/*.cpp) with AMD clang -std=c++23:
+the CPU one restates the reference's huffman/decompress unit tests, with and without
+AddressSanitizer + UBSan (the reference's CI matrix, .github/workflows/check.yml:13-16);
+the GPU one round-trips starflate::compress() through starflate::decompress()."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+CLANG = "/opt/rocm/llvm/bin/clang++"
+FLAGS = ["-std=c++23", "-fno-exceptions", "-Wall", "-Wextra", "-Wpedantic", "-Wconversion", "-Werror",
+         "-I" + os.path.join(ROOT, "include")]
+
+
+def _have_clang():
+    return os.path.exists(CLANG) or shutil.which("clang++")
+
+
+@pytest.mark.parametrize("san", [[], ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"]])
+def test_host_api_cpu(tmp_path, san):
+    if not _have_clang():
+        pytest.skip("no clang++")
+    exe = tmp_path / "host_api_test"
+    subprocess.check_call([CLANG, "-O1", "-g"] + FLAGS + san + [os.path.join(ROOT, "tests", "cpp", "host_api_test.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe), GOLDEN], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 failed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_compress_roundtrip_cpp(tmp_path):
+    from starflate_amd import build
+
+    lib = build.build()
+    exe = tmp_path / "compress_roundtrip"
+    libdir = os.path.dirname(lib)
+    # bind to the same HIP runtime torch ships, as the Python plumbing does, unless /opt/rocm is complete
+    subprocess.check_call([CLANG, "-O2"] + FLAGS + [os.path.join(ROOT, "tests", "cpp", "compress_roundtrip.cpp"),
+                                                   "-L" + libdir, "-lstarflate_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.run([str(exe), GOLDEN], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
