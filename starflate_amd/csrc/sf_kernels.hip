@@ -4,6 +4,8 @@
 // inverse of /root/reference/src/decompress.cpp (contract: SURVEY.md Appendix A).
 #include "sf_device.h"
 
+#include <stdlib.h>
+
 namespace sf {
 
 // ---------------------------------------------------------------------------
@@ -103,22 +105,24 @@ __device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, uint32_t a0, uint
   const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
   const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(c3, c2, csh);
   const uint32_t x3 = a3 ^ __builtin_amdgcn_alignbyte(c4, c3, csh);
-  uint32_t l = 16;
-  l = x3 ? 12 + ((uint32_t)__builtin_ctz(x3) >> 3) : l;
-  l = x2 ? 8 + ((uint32_t)__builtin_ctz(x2) >> 3) : l;
-  l = x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : l;
-  l = x0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : l;
-  return l;
+  // v_ffbl_b32 of 0 is 0xFFFFFFFF, so an all-equal dword contributes a huge value to the min
+  const uint32_t f0 = (uint32_t)(__builtin_ffs((int)x0) - 1), f1 = (uint32_t)(__builtin_ffs((int)x1) - 1);
+  const uint32_t f2 = (uint32_t)(__builtin_ffs((int)x2) - 1), f3 = (uint32_t)(__builtin_ffs((int)x3) - 1);
+  const uint32_t m01 = min(f0 >> 3, (f1 >> 3) + 4);
+  const uint32_t m23 = min((f2 >> 3) + 8, (f3 >> 3) + 12);
+  return min(min(m01, m23), 16u);
 }
 
-__device__ __forceinline__ uint32_t entry_pos(uint32_t v) {
-  return ((v >> 12) - 1) * kStep + (4095u - (v & 4095u));
-}
+// Table entry = ((step+1) << 10) | (1023 - t), t = position - step*1024.  Ordered exactly like
+// the specification's ((step+1) << 12) | (4095 - t), so MAX keeps the same winner (the first
+// position of the latest step); it decodes in three operations: pos = v - 1 - 2*(v & 1023).
+static_assert(kStep == 1024, "entry encoding");
+__device__ __forceinline__ uint32_t entry_pos(uint32_t v) { return v - 1u - 2u * (v & 1023u); }
 
 // STAMPS: diagnostic build only (sfh debug), s_memtime at phase boundaries into `stamps`
 // [chunk][8] = cycles in {stage, match, take+walk, emit, tail}; never used for timing claims.
 template <bool STAMPS>
-__global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
+__global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
                                                      uint32_t* __restrict__ tokens,
                                                      uint32_t* __restrict__ ntok_out,
                                                      uint32_t* __restrict__ hist_out, uint32_t lazy,
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__
       const uint32_t dw = p0 >> 2, sh0 = p0 & 3;  // sh0 + kPPT - 1 <= 3
       const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2], d3 = s_data[dw + 3],
                      d4 = s_data[dw + 4];
-      uint32_t a[kPPT][4], h[kPPT], farv[kPPT], lfar[kPPT];
+      uint32_t a[kPPT][4], h[kPPT], farv[kPPT], lfar[kPPT], farpos[kPPT];
 #pragma unroll
       for (uint32_t k = 0; k < kPPT; ++k) {
         a[k][0] = __builtin_amdgcn_alignbyte(d1, d0, sh0 + k);
@@ -215,13 +219,14 @@ __global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__
         const uint32_t farp = farv[k] ? entry_pos(farv[k]) : p;
         const uint32_t l = cmp16(s_data, a[k][0], a[k][1], a[k][2], a[k][3], farp);
         lfar[k] = farv[k] ? l : 0u;
+        farpos[k] = farp;
       }
       __syncthreads();  // every far read of this step precedes every insertion of this step
 #pragma unroll
       for (uint32_t k = 0; k < kPPT; ++k) {
         const uint32_t p = p0 + k;
         // positions without kMinMatch bytes left insert 0, which MAX ignores
-        const uint32_t v = (p + kMinMatch <= n) ? (((s + 1) << 12) | (4095u - (kPPT * t + k))) : 0u;
+        const uint32_t v = (p + kMinMatch <= n) ? (((s + 1) << 10) | (1023u - (kPPT * t + k))) : 0u;
         atomicMax(&s_table[h[k]], v);
       }
       __syncthreads();  // insertions complete before the near reads
@@ -240,10 +245,9 @@ __global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__
         uint32_t best = nearp < p ? (ln < maxlen ? ln : maxlen) : 0u;
         uint32_t bd = p - np;
         const uint32_t lf = lfar[k] < maxlen ? lfar[k] : maxlen;
-        const uint32_t farp = farv[k] ? entry_pos(farv[k]) : p;
         if (lf > best) {
           best = lf;
-          bd = p - farp;
+          bd = p - farpos[k];
         }
         const bool ok = best >= kMinMatch && (p + kMinMatch <= n);
         len4 |= (ok ? best - 3 : 0u) << (8 * k);
@@ -268,41 +272,48 @@ __global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__
     // and for every position p the packed byte (k << 4) | l3: k = distance to the next take
     // position in p's region (15 = none within 14), l3 = its capped len-3.  One dependent
     // LDS byte read per match is then all the serial walker needs.
+    // Each wave owns kIter CONSECUTIVE segments (whole regions), so nothing here crosses waves:
+    // three batched LDS round trips, no barrier.
     {
       const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;  // valid positions in this quarter
       constexpr uint32_t kIter = kQSegs / K1_WAVES;  // 64-position segments per wave
-#pragma unroll 4
-      for (uint32_t j = 0; j < kIter; ++j) {
-        const uint32_t sg = wave + j * K1_WAVES;
-        const uint32_t rel = sg * 64 + lane;
-        const uint32_t l3 = rel < qn ? s_len8[rel] : 0u;
-        const uint32_t n3 = (rel + 1 < qn && ((rel + 1) & (kRegion - 1)) != 0) ? s_len8[rel + 1] : 0u;
-        const bool take = l3 != 0 && !(lazy && n3 > l3);
-        const uint64_t T = __ballot(take);
-        if (lane == 0) s_mm[sg] = T;  // take mask; the emit pass ANDs it with the chain mask
-      }
-      __syncthreads();  // take masks complete
-      uint32_t pkw[kIter / 4];  // packed bytes, 4 per register (fully unrolled: static indices)
+      static_assert((kIter * 64) % kRegion == 0, "a wave's segments cover whole regions");
+      const uint32_t sg0 = wave * kIter;
+      uint32_t l3[kIter], n3[kIter];
 #pragma unroll
       for (uint32_t j = 0; j < kIter; ++j) {
-        const uint32_t sg = wave + j * K1_WAVES;
-        const uint32_t rel = sg * 64 + lane;
-        const uint64_t up = s_mm[sg] >> lane;
+        const uint32_t rel = (sg0 + j) * 64 + lane;
+        l3[j] = s_len8[rel];
+        n3[j] = s_len8[rel + 1];
+      }
+      uint64_t T[kIter];
+#pragma unroll
+      for (uint32_t j = 0; j < kIter; ++j) {
+        const uint32_t rel = (sg0 + j) * 64 + lane;
+        const uint32_t cur = rel < qn ? l3[j] : 0u;  // beyond n: stale results of an earlier quarter
+        const uint32_t nxt = (rel + 1 < qn && ((rel + 1) & (kRegion - 1)) != 0) ? n3[j] : 0u;
+        T[j] = __ballot(cur != 0 && !(lazy && nxt > cur));
+      }
+      uint32_t kk[kIter], lk[kIter];
+#pragma unroll
+      for (uint32_t j = 0; j < kIter; ++j) {
+        const uint32_t sg = sg0 + j;
+        const uint64_t up = T[j] >> lane;
         uint32_t k = up ? (uint32_t)__builtin_ctzll(up) : 64u;
-        if (k == 64u && ((sg + 1) * 64) % kRegion != 0) {  // region continues in the next segment
-          const uint64_t Tn = s_mm[sg + 1];
-          k = Tn ? (64u - lane) + (uint32_t)__builtin_ctzll(Tn) : 64u;
+        if (j + 1 < kIter && ((sg + 1) * 64) % kRegion != 0) {  // region continues in the next segment
+          const uint64_t Tn = T[j + 1 < kIter ? j + 1 : j];
+          const uint32_t k2 = Tn ? (64u - lane) + (uint32_t)__builtin_ctzll(Tn) : 64u;
+          k = k == 64u ? k2 : k;
         }
-        k = k < 15u ? k : 15u;
-        const uint32_t l3 = k < 15u ? (uint32_t)s_len8[rel + k] : 0u;
-        const uint32_t byte = (k << 4) | (l3 & 15u);
-        if ((j & 3) == 0) pkw[j >> 2] = byte;
-        else pkw[j >> 2] |= byte << (8 * (j & 3));
+        kk[j] = k < 15u ? k : 15u;
+        lk[j] = s_len8[sg * 64 + lane + (kk[j] < 15u ? kk[j] : 0u)];
       }
-      __syncthreads();  // every len8 read above precedes the overwrite below
 #pragma unroll
-      for (uint32_t j = 0; j < kIter; ++j)
-        s_len8[(wave + j * K1_WAVES) * 64 + lane] = (uint8_t)(pkw[j >> 2] >> (8 * (j & 3)));
+      for (uint32_t j = 0; j < kIter; ++j) {
+        const uint32_t sg = sg0 + j;
+        s_len8[sg * 64 + lane] = (uint8_t)((kk[j] << 4) | (kk[j] < 15u ? (lk[j] & 15u) : 0u));
+        if (lane == 0) s_mm[sg] = T[j];  // take mask; the emit pass ANDs it with the chain mask
+      }
       for (uint32_t idx = t; idx < 2 * kQSegs; idx += K1_THREADS) s_marks32[idx] = 0;
     }
     __syncthreads();
@@ -311,7 +322,9 @@ __global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__
     // ---- walk: lane r of wave 0 follows the chain of region r of this quarter ----
     // One loop iteration is either a chain step (one dependent LDS byte read) or one
     // 8-byte step of extending a capped match, so a lane that extends never stalls the others.
-    if (wave == 0 && lane < kQRegions) {
+    // the walking wave rotates with the quarter so the serial work lands on different SIMDs
+    const uint32_t walker = (qb / kQuarter) % K1_WAVES;
+    if (wave == walker && lane < kQRegions) {
       const uint32_t rb = lane * kRegion;                        // quarter-relative
       const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;
       const uint32_t re = rb + kRegion < qn ? rb + kRegion : qn;  // quarter-relative end (may be <= rb)
@@ -376,27 +389,47 @@ __global__ __launch_bounds__(K1_THREADS) void k_lz77(const uint8_t* __restrict__
     stamp(4);
 
     // ---- emit: chain positions -> tokens (compact, chunk order) + histogram ----
-    for (uint32_t sg = wave; sg < kQSegs; sg += K1_WAVES) {
-      const uint64_t marks = s_marks[sg];
-      const uint64_t mm = s_mm[sg] & marks;
-      const uint32_t pre = s_segpre[sg];
-      if ((marks >> lane) & 1) {
-        const uint32_t rel = sg * 64 + lane;
-        const uint32_t idx = total + pre + (uint32_t)__popcll(marks & lt_mask);
-        uint32_t tok;
-        if ((mm >> lane) & 1) {
-          uint32_t l3 = s_len8[rel] & 15u;           // a take position packs k = 0 and its own len-3
-          if (l3 == kCap - 3) l3 = s_len8[rel + 1];  // capped match: the walker left the full length next door
-          const uint32_t d1 = (uint32_t)s_dist[rel] - 1;
-          tok = kTokMatch | (l3 << 16) | d1;
-          uint32_t eb, ev;
-          atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
-          atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
-        } else {
-          tok = s_bytes[qb + rel];
-          atomicAdd(&s_hist[tok], 1u);
+    // kIter consecutive segments per wave, loads batched four segments at a time
+    {
+      constexpr uint32_t kIter = kQSegs / K1_WAVES;
+      constexpr uint32_t kB = 4;
+      static_assert(kIter % kB == 0, "emit batch");
+#pragma unroll
+      for (uint32_t j0 = 0; j0 < kIter; j0 += kB) {
+        uint64_t marks[kB], mm[kB];
+        uint32_t pre[kB], b0[kB], b1[kB], dd[kB], lit[kB];
+#pragma unroll
+        for (uint32_t j = 0; j < kB; ++j) {
+          const uint32_t sg = wave * kIter + j0 + j;
+          marks[j] = s_marks[sg];
+          mm[j] = s_mm[sg];
+          pre[j] = s_segpre[sg];
+          const uint32_t rel = sg * 64 + lane;
+          b0[j] = s_len8[rel];
+          b1[j] = s_len8[rel + 1];
+          dd[j] = s_dist[rel];
+          lit[j] = s_bytes[qb + rel];
         }
-        tk[idx] = tok;
+#pragma unroll
+        for (uint32_t j = 0; j < kB; ++j) {
+          if ((marks[j] >> lane) & 1) {
+            const uint32_t idx = total + pre[j] + (uint32_t)__popcll(marks[j] & lt_mask);
+            uint32_t tok;
+            if ((mm[j] >> lane) & 1) {
+              uint32_t l3 = b0[j] & 15u;           // a take position packs k = 0 and its own len-3
+              if (l3 == kCap - 3) l3 = b1[j];      // capped match: the walker left the full length next door
+              const uint32_t d1 = dd[j] - 1;
+              tok = kTokMatch | (l3 << 16) | d1;
+              uint32_t eb, ev;
+              atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
+              atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
+            } else {
+              tok = lit[j];
+              atomicAdd(&s_hist[tok], 1u);
+            }
+            tk[idx] = tok;
+          }
+        }
       }
     }
     total += s_misc[0];
@@ -953,14 +986,20 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
 // ---------------------------------------------------------------------------
 hipError_t init_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz77<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz77<true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS);
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
                        const Options& opt, hipStream_t s) {
+  // diagnostic: SFH_K1_EXTRA_LDS=<bytes> inflates the LDS request (e.g. 8192 -> one workgroup per CU)
+  static const uint32_t extra = [] {
+    const char* e = getenv("SFH_K1_EXTRA_LDS");
+    return e ? (uint32_t)atoi(e) : 0u;
+  }();
+  const uint32_t K1_LDS = sf::K1_LDS + extra;
   if (ws.stamps)
     hipLaunchKernelGGL(k_lz77<true>, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
                        ws.hist, opt.lazy, ws.stamps);
