@@ -314,66 +314,135 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
         s_len8[sg * 64 + lane] = (uint8_t)((kk[j] << 4) | (kk[j] < 15u ? (lk[j] & 15u) : 0u));
         if (lane == 0) s_mm[sg] = T[j];  // take mask; the emit pass ANDs it with the chain mask
       }
-      for (uint32_t idx = t; idx < 2 * kQSegs; idx += K1_THREADS) s_marks32[idx] = 0;
     }
     __syncthreads();
     stamp(2);
 
-    // ---- walk: lane r of wave 0 follows the chain of region r of this quarter ----
-    // One loop iteration is either a chain step (one dependent LDS byte read) or one
-    // 8-byte step of extending a capped match, so a lane that extends never stalls the others.
-    // the walking wave rotates with the quarter so the serial work lands on different SIMDs
-    const uint32_t walker = (qb / kQuarter) % K1_WAVES;
-    if (wave == walker && lane < kQRegions) {
-      const uint32_t rb = lane * kRegion;                        // quarter-relative
+    // ---- walk: the chain of every 128-byte region, four lanes per region ----
+    // Lane (r, s) walks the 32-position sub-region s of region r: first speculatively from
+    // the sub-region's start (exact for s = 0), chain bits kept in a register (one dword per
+    // lane).  Then each lane re-walks from its predecessor's exit until it meets its own
+    // speculative chain (greedy chains that meet stay together) or leaves the sub-region;
+    // at most three rounds make every entry equal the predecessor's final exit, i.e. the
+    // exact serial chain.  One loop iteration is a chain step (one dependent LDS byte read)
+    // or one 8-byte step of extending a capped match (lane-local state machine).
+#ifndef SF_K1_SUB
+#define SF_K1_SUB 32
+#endif
+    constexpr uint32_t kSub = SF_K1_SUB, kSubPerRegion = kRegion / kSub, kWalkWaves = kQuarter / kSub / 64;
+    static_assert((kSub == 16 || kSub == 32 || kSub == 64) && kWalkWaves >= 1 && K1_WAVES % kWalkWaves == 0, "walker geometry");
+    const uint32_t w0 = ((qb / kQuarter) * kWalkWaves) % K1_WAVES;  // walking waves rotate over the SIMDs
+    if (wave >= w0 && wave < w0 + kWalkWaves) {
+      const uint32_t L = (wave - w0) * 64 + lane;                  // sub-region index in the quarter
       const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;
-      const uint32_t re = rb + kRegion < qn ? rb + kRegion : qn;  // quarter-relative end (may be <= rb)
-      uint32_t pos = rb;
-      uint32_t xl = 0, xmp = 0, xpa = 0, xca = 0, xmax = 0;      // extension state (xl = 0: none)
-      while (pos < re) {
-        if (xl == 0) {
-          const uint32_t b = s_len8[pos];
-          const uint32_t k = b >> 4;
-          const bool hit = k < 15u;
-          uint32_t nb = hit ? k + 1 : 15u;             // chain bits: k literals (+ the match position)
-          nb = pos + nb <= re ? nb : re - pos;         // a no-hit run may overshoot the region end
-          const uint64_t bits = ((1ull << nb) - 1) << (pos & 31);
-          atomicOr(&s_marks32[pos >> 5], (uint32_t)bits);
-          if (bits >> 32) atomicOr(&s_marks32[(pos >> 5) + 1], (uint32_t)(bits >> 32));
-          const uint32_t mp = pos + k;                 // match position (quarter-relative) on a hit
-          const uint32_t len = (b & 15u) + 3;
-          if (hit && len == kCap) {                    // capped at match time: extend from here
-            xmp = mp;
-            xpa = qb + mp;
-            xca = xpa - s_dist[mp];
-            xmax = re - mp < 258u ? re - mp : 258u;
-            xl = kCap;
+      const uint32_t sb = L * kSub;
+      const uint32_t rb = sb & ~(kRegion - 1);
+      const uint32_t re = rb + kRegion < qn ? rb + kRegion : qn;   // region end (quarter-relative)
+      const uint32_t se = sb + kSub < re ? sb + kSub : re;         // sub-region end (may be <= sb)
+      const uint32_t sub = L & (kSubPerRegion - 1);
+      constexpr uint32_t kNone = 0xFFFFFFFFu;
+      // walk from `pos` while inside [sb, se); stops early on a position of `conv`
+      using mask_t = uint64_t;
+      auto sub_walk = [&](uint32_t pos, mask_t conv, mask_t& marks, uint32_t& exitp, uint32_t& e0, uint32_t& e1,
+                          uint32_t& cpos) {
+        marks = 0; e0 = 0; e1 = 0; cpos = kNone;
+        uint32_t xl = 0, xmp = 0, xpa = 0, xca = 0, xmax = 0;      // extension state (xl = 0: none)
+        while (pos < se) {
+          if (xl == 0) {
+            const uint32_t b = s_len8[pos];
+            const uint32_t k = b >> 4;
+            const bool hit = k < 15u;
+            uint32_t nb = hit ? k + 1 : 15u;           // chain run: k literals (+ the match position)
+            nb = pos + nb <= se ? nb : se - pos;
+            const uint64_t run = ((1ull << nb) - 1ull) << (pos - sb);
+            const uint64_t c = conv & run;
+            if (c) {                                   // met the speculative chain: from here on it is ours
+              const uint32_t q = (uint32_t)__builtin_ctzll(c);
+              marks |= run & ((1ull << q) - 1ull);
+              cpos = sb + q;
+              break;
+            }
+            marks |= run;
+            const uint32_t mp = pos + k;               // match position on a hit
+            const uint32_t len = (b & 15u) + 3;
+            if (hit && mp < se) {
+              if (len == kCap) {                       // capped at match time: extend from here
+                xmp = mp;
+                xpa = qb + mp;
+                xca = xpa - s_dist[mp];
+                xmax = re - mp < 258u ? re - mp : 258u;
+                xl = kCap;
+              } else {
+                pos = mp + len;
+              }
+            } else {
+              pos = pos + nb;                          // literals up to the run's (clipped) end
+            }
           } else {
-            pos = hit ? mp + len : pos + 15u;
+            uint32_t l = xl;
+            bool done = l >= xmax;
+            if (!done) {
+              const uint32_t ia = xpa + l, ja = xca + l;
+              const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
+              const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
+              const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, ia & 3) ^ __builtin_amdgcn_alignbyte(j1, j0, ja & 3);
+              const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, ia & 3) ^ __builtin_amdgcn_alignbyte(j2, j1, ja & 3);
+              if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; done = true; }
+              else if (x1) { l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3); done = true; }
+              else l += 8;
+            }
+            if (done) {
+              l = l < xmax ? l : xmax;
+              const uint32_t e = 0x10000u | ((xmp - sb) << 9) | l;  // full length of a capped chain match (pos: 6 bits)
+              if (e0 == 0) e0 = e; else e1 = e;
+              pos = xmp + l;
+              xl = 0;
+            } else {
+              xl = l;
+            }
           }
-        } else {
-          uint32_t l = xl;
-          bool done = l >= xmax;
-          if (!done) {
-            const uint32_t ia = xpa + l, ja = xca + l;
-            const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
-            const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
-            const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, ia & 3) ^ __builtin_amdgcn_alignbyte(j1, j0, ja & 3);
-            const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, ia & 3) ^ __builtin_amdgcn_alignbyte(j2, j1, ja & 3);
-            if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; done = true; }
-            else if (x1) { l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3); done = true; }
-            else l += 8;
-          }
-          if (done) {
-            l = l < xmax ? l : xmax;
-            s_len8[xmp + 1] = (uint8_t)(l - 3);  // xmp+1 is covered by this match: nobody walks it
-            pos = xmp + l;
-            xl = 0;
+        }
+        exitp = pos;
+      };
+      mask_t mS;
+      uint32_t xS, eS0, eS1, cdummy;
+      sub_walk(sb, 0u, mS, xS, eS0, eS1, cdummy);
+      if (se <= sb) xS = sb;
+      mask_t marks = mS;
+      uint32_t exitc = xS, f0 = eS0, f1 = eS1, entry_used = sb;
+      for (uint32_t round = 0; round < kSubPerRegion - 1; ++round) {
+        const uint32_t pe = (uint32_t)__shfl_up((int)exitc, 1, 64);
+        const bool redo = sub != 0 && pe != entry_used;
+        if (!__any(redo)) break;
+        if (redo) {
+          entry_used = pe;
+          if (pe >= se) {                              // a long match of the predecessor jumps over us
+            marks = 0; exitc = pe; f0 = 0; f1 = 0;
           } else {
-            xl = l;
+            mask_t mF;
+            uint32_t xF, eF0, eF1, cpos;
+            sub_walk(pe, mS, mF, xF, eF0, eF1, cpos);
+            if (cpos != kNone) {
+              const mask_t keep = ~((1ull << (cpos - sb)) - 1ull);  // speculative chain from cpos on
+              marks = mF | (mS & keep);
+              exitc = xS;
+              // capped matches: the re-walked ones, then the speculative ones at or after cpos
+              f0 = eF0; f1 = eF1;
+              const uint32_t q = cpos - sb;
+              if (eS0 && ((eS0 >> 9) & 63u) >= q) { if (f0 == 0) f0 = eS0; else f1 = eS0; }
+              if (eS1 && ((eS1 >> 9) & 63u) >= q) { if (f0 == 0) f0 = eS1; else f1 = eS1; }
+            } else {
+              marks = mF; exitc = xF; f0 = eF0; f1 = eF1;
+            }
           }
         }
       }
+      if constexpr (kSub == 64) s_marks[L] = marks;
+      else if constexpr (kSub == 32) s_marks32[L] = (uint32_t)marks;
+      else reinterpret_cast<uint16_t*>(s_marks32)[L] = (uint16_t)marks;
+      // the position after a capped chain match is covered by it: park the full length there
+      if (f0) s_len8[sb + ((f0 >> 9) & 63u) + 1] = (uint8_t)((f0 & 511u) - 3);
+      if (f1) s_len8[sb + ((f1 >> 9) & 63u) + 1] = (uint8_t)((f1 & 511u) - 3);
     }
     __syncthreads();
     stamp(3);
@@ -472,10 +541,15 @@ struct PlanSmem {
 // to the rarest symbols.
 __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uint32_t maxbits,
                               uint8_t* lens, uint32_t lane) {
+  // keys (freq << 9 | symbol) stay in registers: symbol g*64+lane in key[g]
+  uint32_t key[5], rank[5];
   uint32_t mloc = 0;
-  for (uint32_t s = lane; s < 288; s += 64) {
+#pragma unroll
+  for (uint32_t g = 0; g < 5; ++g) {
+    const uint32_t s = g * 64 + lane;
     const uint32_t f = s < n ? freq[s] : 0u;
-    S.ukey[s] = f ? ((f << 9) | s) : 0xFFFFFFFFu;
+    key[g] = f ? ((f << 9) | s) : 0xFFFFFFFFu;
+    rank[g] = 0;
     if (s < n) lens[s] = 0;
     mloc += f != 0;
   }
@@ -484,20 +558,29 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
   __syncthreads();
   if (m == 0) return;
   if (m == 1) {
-    for (uint32_t s = lane; s < n; s += 64)
-      if (S.ukey[s] != 0xFFFFFFFFu) lens[s] = 1;
+#pragma unroll
+    for (uint32_t g = 0; g < 5; ++g)
+      if (key[g] != 0xFFFFFFFFu) lens[g * 64 + lane] = 1;
     __syncthreads();
     return;
   }
-  // rank sort ascending by (freq, symbol)
-  for (uint32_t s = lane; s < n; s += 64) {
-    const uint32_t k = S.ukey[s];
-    if (k != 0xFFFFFFFFu) {
-      uint32_t r = 0;
-      for (uint32_t j = 0; j < n; ++j) r += S.ukey[j] < k;
-      S.key[r] = k;
+  // rank sort ascending by (freq, symbol): every used key is broadcast once (v_readlane)
+  // and counted by the lanes holding larger keys -- no LDS round trips
+#pragma unroll
+  for (uint32_t g2 = 0; g2 < 5; ++g2) {
+    if (g2 * 64 >= n) break;
+    uint64_t used = __ballot(key[g2] != 0xFFFFFFFFu);
+    while (used) {
+      const uint32_t src = (uint32_t)__builtin_ctzll(used);
+      used &= used - 1;
+      const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key[g2], (int)src);
+#pragma unroll
+      for (uint32_t g = 0; g < 5; ++g) rank[g] += kk < key[g];
     }
   }
+#pragma unroll
+  for (uint32_t g = 0; g < 5; ++g)
+    if (key[g] != 0xFFFFFFFFu) S.key[rank[g]] = key[g];
   __syncthreads();
   for (uint32_t k = lane; k < m; k += 64) S.w[k] = S.key[k] >> 9;
   __syncthreads();
@@ -896,7 +979,10 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
 
   const uint32_t sh = (uint32_t)(off & 3);
   const uint32_t nwords = (sh + P.out_bytes + 3) / 4;
-  for (uint32_t k = t; k < nwords + 2 && k < K4_STAGE_WORDS; k += K4_THREADS) s_stage[k] = 0;
+  {
+    uint4* z = reinterpret_cast<uint4*>(s_stage);
+    for (uint32_t k = t; k < (nwords + 2 + 3) / 4 && k < K4_STAGE_WORDS / 4; k += K4_THREADS) z[k] = make_uint4(0, 0, 0, 0);
+  }
   if (t < 288) s_lcode[t] = C.lcode[t];
   if (t < 32) s_dcode[t] = C.dcode[t];
   __syncthreads();
@@ -912,22 +998,20 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
   const uint32_t* tk = tokens + (uint64_t)chunk * kChunk;
   uint32_t running = 8 * sh + P.header_bits;
   uint32_t buf = 0;
+  // tokens in batches of K4_THREADS*4; the next batch is in flight while this one is packed.
+  // (reads past ntok stay inside the chunk's 32768-slot token area; they are masked below)
+  uint4 q_next = ntok ? *reinterpret_cast<const uint4*>(tk + t * K4_TPT) : make_uint4(0, 0, 0, 0);
   for (uint32_t b0 = 0; b0 < ntok; b0 += K4_THREADS * K4_TPT, buf ^= 1) {
     const uint32_t i0 = b0 + t * K4_TPT;
-    uint32_t tok[K4_TPT];
-    if (i0 + K4_TPT <= ntok) {
-      const uint4 q = *reinterpret_cast<const uint4*>(tk + i0);
-      tok[0] = q.x; tok[1] = q.y; tok[2] = q.z; tok[3] = q.w;
-    } else {
-#pragma unroll
-      for (uint32_t k = 0; k < K4_TPT; ++k) tok[k] = i0 + k < ntok ? tk[i0 + k] : 0u;
-    }
+    const uint4 q = q_next;
+    if (b0 + K4_THREADS * K4_TPT < ntok) q_next = *reinterpret_cast<const uint4*>(tk + i0 + K4_THREADS * K4_TPT);
+    const uint32_t tok[K4_TPT] = {q.x, q.y, q.z, q.w};
     uint64_t val[K4_TPT];
     uint32_t nb[K4_TPT], mine = 0;
 #pragma unroll
     for (uint32_t k = 0; k < K4_TPT; ++k) {
-      if (i0 + k < ntok) token_bits(tok[k], s_lcode, s_dcode, val[k], nb[k]);
-      else { val[k] = 0; nb[k] = 0; }
+      token_bits(tok[k], s_lcode, s_dcode, val[k], nb[k]);
+      if (i0 + k >= ntok) { val[k] = 0; nb[k] = 0; }
       mine += nb[k];
     }
     const uint32_t incl = wave_incl_scan(mine, lane);
@@ -940,12 +1024,30 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
       if (w < wave) pre += v;
       all += v;
     }
-    uint32_t pos = running + pre + incl - mine;
+    // the thread's four codes are contiguous in the stream: gather them in a 64-bit window
+    // and OR whole words, instead of one to three atomics per token
+    const uint32_t pos = running + pre + incl - mine;
+    uint32_t wi = pos >> 5, ab = pos & 31;
+    uint64_t acc = 0;
+    auto put = [&](uint32_t v32, uint32_t n) {
+      acc |= (uint64_t)v32 << ab;
+      ab += n;
+      if (ab >= 32) {
+        atomicOr(&s_stage[wi++], (uint32_t)acc);
+        acc >>= 32;
+        ab -= 32;
+      }
+    };
 #pragma unroll
     for (uint32_t k = 0; k < K4_TPT; ++k) {
-      if (nb[k]) or_bits(s_stage, pos, val[k]);
-      pos += nb[k];
+      if (nb[k] <= 32) {
+        put((uint32_t)val[k], nb[k]);
+      } else {
+        put((uint32_t)val[k], 32);
+        put((uint32_t)(val[k] >> 32), nb[k] - 32);
+      }
     }
+    if (ab) atomicOr(&s_stage[wi], (uint32_t)acc);
     running += all;
   }
   __syncthreads();
