@@ -268,16 +268,12 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
     __syncthreads();
     stamp(1);
 
-    // ---- take pass (position-parallel): which positions would the greedy/lazy rule take,
-    // and for every position p the packed byte (k << 4) | l3: k = distance to the next take
-    // position in p's region (15 = none within 14), l3 = its capped len-3.  One dependent
-    // LDS byte read per match is then all the serial walker needs.
-    // Each wave owns kIter CONSECUTIVE segments (whole regions), so nothing here crosses waves:
-    // three batched LDS round trips, no barrier.
+    // ---- take pass (position-parallel): 64-bit masks of the positions whose match the
+    // greedy/lazy rule would take.  Each wave owns kIter consecutive segments: batched loads,
+    // one ballot per segment, no barrier inside.
     {
       const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;  // valid positions in this quarter
       constexpr uint32_t kIter = kQSegs / K1_WAVES;  // 64-position segments per wave
-      static_assert((kIter * 64) % kRegion == 0, "a wave's segments cover whole regions");
       const uint32_t sg0 = wave * kIter;
       uint32_t l3[kIter], n3[kIter];
 #pragma unroll
@@ -286,33 +282,13 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
         l3[j] = s_len8[rel];
         n3[j] = s_len8[rel + 1];
       }
-      uint64_t T[kIter];
 #pragma unroll
       for (uint32_t j = 0; j < kIter; ++j) {
         const uint32_t rel = (sg0 + j) * 64 + lane;
         const uint32_t cur = rel < qn ? l3[j] : 0u;  // beyond n: stale results of an earlier quarter
         const uint32_t nxt = (rel + 1 < qn && ((rel + 1) & (kRegion - 1)) != 0) ? n3[j] : 0u;
-        T[j] = __ballot(cur != 0 && !(lazy && nxt > cur));
-      }
-      uint32_t kk[kIter], lk[kIter];
-#pragma unroll
-      for (uint32_t j = 0; j < kIter; ++j) {
-        const uint32_t sg = sg0 + j;
-        const uint64_t up = T[j] >> lane;
-        uint32_t k = up ? (uint32_t)__builtin_ctzll(up) : 64u;
-        if (j + 1 < kIter && ((sg + 1) * 64) % kRegion != 0) {  // region continues in the next segment
-          const uint64_t Tn = T[j + 1 < kIter ? j + 1 : j];
-          const uint32_t k2 = Tn ? (64u - lane) + (uint32_t)__builtin_ctzll(Tn) : 64u;
-          k = k == 64u ? k2 : k;
-        }
-        kk[j] = k < 15u ? k : 15u;
-        lk[j] = s_len8[sg * 64 + lane + (kk[j] < 15u ? kk[j] : 0u)];
-      }
-#pragma unroll
-      for (uint32_t j = 0; j < kIter; ++j) {
-        const uint32_t sg = sg0 + j;
-        s_len8[sg * 64 + lane] = (uint8_t)((kk[j] << 4) | (kk[j] < 15u ? (lk[j] & 15u) : 0u));
-        if (lane == 0) s_mm[sg] = T[j];  // take mask; the emit pass ANDs it with the chain mask
+        const uint64_t T = __ballot(cur != 0 && !(lazy && nxt > cur));
+        if (lane == 0) s_mm[sg0 + j] = T;
       }
     }
     __syncthreads();
@@ -330,7 +306,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
 #define SF_K1_SUB 32
 #endif
     constexpr uint32_t kSub = SF_K1_SUB, kSubPerRegion = kRegion / kSub, kWalkWaves = kQuarter / kSub / 64;
-    static_assert((kSub == 16 || kSub == 32 || kSub == 64) && kWalkWaves >= 1 && K1_WAVES % kWalkWaves == 0, "walker geometry");
+    static_assert((kSub == 16 || kSub == 32) && kWalkWaves >= 1 && K1_WAVES % kWalkWaves == 0, "walker geometry");
     const uint32_t w0 = ((qb / kQuarter) * kWalkWaves) % K1_WAVES;  // walking waves rotate over the SIMDs
     if (wave >= w0 && wave < w0 + kWalkWaves) {
       const uint32_t L = (wave - w0) * 64 + lane;                  // sub-region index in the quarter
@@ -343,17 +319,18 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
       constexpr uint32_t kNone = 0xFFFFFFFFu;
       // walk from `pos` while inside [sb, se); stops early on a position of `conv`
       using mask_t = uint64_t;
+      static_assert(kSub <= 32, "the take-mask slice of a sub-region is one 32-bit register");
+      const uint32_t t32 = (uint32_t)(s_mm[sb >> 6] >> (sb & 63)) & (kSub == 32 ? 0xFFFFFFFFu : ((1u << (kSub & 31)) - 1u));
       auto sub_walk = [&](uint32_t pos, mask_t conv, mask_t& marks, uint32_t& exitp, uint32_t& e0, uint32_t& e1,
                           uint32_t& cpos) {
         marks = 0; e0 = 0; e1 = 0; cpos = kNone;
         uint32_t xl = 0, xmp = 0, xpa = 0, xca = 0, xmax = 0;      // extension state (xl = 0: none)
         while (pos < se) {
           if (xl == 0) {
-            const uint32_t b = s_len8[pos];
-            const uint32_t k = b >> 4;
-            const bool hit = k < 15u;
-            uint32_t nb = hit ? k + 1 : 15u;           // chain run: k literals (+ the match position)
-            nb = pos + nb <= se ? nb : se - pos;
+            const uint32_t m = t32 >> (pos - sb);      // take positions from pos to the sub-region's end
+            const bool hit = m != 0;
+            const uint32_t k = hit ? (uint32_t)__builtin_ctz(m) : 0u;
+            const uint32_t nb = hit ? k + 1 : se - pos;  // chain run: literals (+ the match position)
             const uint64_t run = ((1ull << nb) - 1ull) << (pos - sb);
             const uint64_t c = conv & run;
             if (c) {                                   // met the speculative chain: from here on it is ours
@@ -363,9 +340,9 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
               break;
             }
             marks |= run;
-            const uint32_t mp = pos + k;               // match position on a hit
-            const uint32_t len = (b & 15u) + 3;
-            if (hit && mp < se) {
+            const uint32_t mp = pos + k;               // match position on a hit (inside the sub-region)
+            if (hit) {
+              const uint32_t len = (uint32_t)s_len8[mp] + 3;  // the one dependent LDS read per match
               if (len == kCap) {                       // capped at match time: extend from here
                 xmp = mp;
                 xpa = qb + mp;
@@ -485,7 +462,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
             const uint32_t idx = total + pre[j] + (uint32_t)__popcll(marks[j] & lt_mask);
             uint32_t tok;
             if ((mm[j] >> lane) & 1) {
-              uint32_t l3 = b0[j] & 15u;           // a take position packs k = 0 and its own len-3
+              uint32_t l3 = b0[j];                 // capped len-3 from the match phase
               if (l3 == kCap - 3) l3 = b1[j];      // capped match: the walker left the full length next door
               const uint32_t d1 = dd[j] - 1;
               tok = kTokMatch | (l3 << 16) | d1;
