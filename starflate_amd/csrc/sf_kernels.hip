@@ -105,12 +105,15 @@ __device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, uint32_t a0, uint
   const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
   const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(c3, c2, csh);
   const uint32_t x3 = a3 ^ __builtin_amdgcn_alignbyte(c4, c3, csh);
-  // v_ffbl_b32 of 0 is 0xFFFFFFFF, so an all-equal dword contributes a huge value to the min
-  const uint32_t f0 = (uint32_t)(__builtin_ffs((int)x0) - 1), f1 = (uint32_t)(__builtin_ffs((int)x1) - 1);
-  const uint32_t f2 = (uint32_t)(__builtin_ffs((int)x2) - 1), f3 = (uint32_t)(__builtin_ffs((int)x3) - 1);
-  const uint32_t m01 = min(f0 >> 3, (f1 >> 3) + 4);
-  const uint32_t m23 = min((f2 >> 3) + 8, (f3 >> 3) + 12);
-  return min(min(m01, m23), 16u);
+  // first differing dword by a select chain, then ONE find-first-bit: v_ffbl_b32 of 0 is
+  // 0xFFFFFFFF, so sixteen equal bytes fall out as a huge value and the final min gives 16
+  uint32_t x = x2 ? x2 : x3, base = x2 ? 8u : 12u;
+  x = x1 ? x1 : x;
+  base = x1 ? 4u : base;
+  x = x0 ? x0 : x;
+  base = x0 ? 0u : base;
+  const uint32_t f = (uint32_t)(__builtin_ffs((int)x) - 1);
+  return min(base + (f >> 3), 16u);
 }
 
 // Table entry = ((step+1) << 10) | (1023 - t), t = position - step*1024.  Ordered exactly like
