@@ -29,6 +29,7 @@ struct compress_options {
   BlockStrategy strategy{BlockStrategy::Auto};
   bool final_stream{true};  // false: byte-aligned, non-final stream (a shard that is not the last)
   bool lazy{true};
+  bool stored_fast_path{true};  // skip the search of a chunk whose first 8 KiB are (almost) all literals
   int device{0};
 };
 
@@ -51,6 +52,7 @@ inline auto to_c(const compress_options& o) -> sfh_options {
   c.strategy = static_cast<std::uint32_t>(o.strategy);
   c.final_stream = o.final_stream ? 1U : 0U;
   c.lazy = o.lazy ? 1U : 0U;
+  c.no_stored_fast_path = o.stored_fast_path ? 0U : 1U;
   return c;
 }
 }  // namespace detail

@@ -52,7 +52,10 @@ typedef struct sfh_options {
                             0: stream ends byte-aligned and non-final (a GPU shard
                             that is not the last one) */
   uint32_t lazy;         /* 1: one-step lazy match deferral */
-  uint32_t reserved[5];  /* must be 0 */
+  uint32_t no_stored_fast_path; /* 0 (default): a 32 KiB chunk whose first 8 KiB parse to (almost) only
+                            literals is not searched further (high-entropy data -> stored blocks at a
+                            quarter of the match work); 1: always search the whole chunk */
+  uint32_t reserved[4];  /* must be 0 */
 } sfh_options;
 
 /* fills *o with defaults: AUTO, final_stream=1, lazy=1 */

@@ -336,6 +336,7 @@ void sfo_default_params(sfo_params* p) {
   p->long_hash_bytes = 0;
   p->chain_depth = 0;
   p->cap = 16;
+  p->fast_skip = 1;
 }
 
 static inline uint32_t load32(const uint8_t* p) {
@@ -481,9 +482,22 @@ void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
                      uint32_t* ntok) {
   const uint32_t R = p->region_bytes, MM = p->min_match;
   uint32_t nreg = (n + R - 1) / R;
+  /* Stored fast path: when the first SFO_SKIP_SPAN positions of a chunk parse to (almost)
+   * nothing but literals -- at least SFO_SKIP_SPAN - SFO_SKIP_SLACK tokens -- the rest of the
+   * chunk is not searched at all: every later position is emitted as a literal.  (High-entropy
+   * data then costs a quarter of the match work and ends up in a stored block.) */
+  uint32_t head_tokens = 0;
+  int skip = 0;
   for (uint32_t r = 0; r < nreg; r++) {
     uint32_t pos = r * R, end = pos + R < n ? pos + R : n, k = 0;
     uint32_t* out = tokens + (size_t)r * R;
+    if (p->fast_skip && pos == SFO_SKIP_SPAN && n > SFO_SKIP_SPAN && SFO_SKIP_SPAN % R == 0)
+      skip = head_tokens >= SFO_SKIP_SPAN - SFO_SKIP_SLACK;
+    if (skip) {
+      while (pos < end) out[k++] = data[pos++];
+      ntok[r] = k;
+      continue;
+    }
     while (pos < end) {
       uint32_t l = len16[pos];
       int take = l >= MM;
@@ -502,6 +516,7 @@ void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
       }
     }
     ntok[r] = k;
+    if (pos <= SFO_SKIP_SPAN) head_tokens += k;
   }
 }
 

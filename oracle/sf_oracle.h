@@ -93,7 +93,12 @@ typedef struct sfo_params {
   uint32_t chain_depth;  /* analysis only (not on the GPU): >0 = exact hash chains */
   uint32_t cap;          /* >0: match-time compare is capped at `cap` bytes; the parse extends
                             a capped match to its full length at chain positions only */
+  uint32_t fast_skip;    /* 1: stored fast path -- a chunk whose first SFO_SKIP_SPAN positions are (almost)
+                            all literals is not searched any further */
 } sfo_params;
+
+#define SFO_SKIP_SPAN 8192u
+#define SFO_SKIP_SLACK 128u
 
 void sfo_default_params(sfo_params* p);
 

@@ -22,7 +22,7 @@ EXPORTS = [
 
 class Options(C.Structure):
     _fields_ = [("strategy", C.c_uint32), ("final_stream", C.c_uint32), ("lazy", C.c_uint32),
-                ("reserved", C.c_uint32 * 5)]
+                ("no_stored_fast_path", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 _LIB = None
@@ -78,10 +78,11 @@ def lib():
     return L
 
 
-def make_options(strategy="auto", final_stream=True, lazy=True):
+def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True):
     o = Options()
     lib().sfh_default_options(C.byref(o))
     o.strategy = STRATEGY[strategy] if isinstance(strategy, str) else int(strategy)
     o.final_stream = int(bool(final_stream))
     o.lazy = int(bool(lazy))
+    o.no_stored_fast_path = int(not stored_fast_path)
     return o

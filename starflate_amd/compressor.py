@@ -51,18 +51,19 @@ class Compressor:
         return _capi.lib().sfh_compress_bound(int(n))
 
     # ---- host buffers (PCIe inclusive) ----
-    def compress(self, data, strategy="auto", final_stream=True, lazy=True):
+    def compress(self, data, strategy="auto", final_stream=True, lazy=True, stored_fast_path=True):
         src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         cap = self.compress_bound(src.size)
         dst = np.empty(cap, dtype=np.uint8)
         out_n = C.c_size_t(0)
-        opt = _capi.make_options(strategy, final_stream, lazy)
+        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path)
         self._check(self._lib.sfh_compress(self._h, src.ctypes.data if src.size else None, src.size,
                                            dst.ctypes.data, cap, C.byref(out_n), C.byref(opt)))
         return dst[: out_n.value].tobytes()
 
     # ---- device buffers (torch uint8 CUDA tensors) ----
-    def compress_tensor(self, src, out=None, strategy="auto", final_stream=True, lazy=True, stream=None):
+    def compress_tensor(self, src, out=None, strategy="auto", final_stream=True, lazy=True, stream=None,
+                        stored_fast_path=True):
         """src: 1-D uint8 tensor on this device. Returns (out tensor, stream byte count)."""
         import torch
 
@@ -73,7 +74,7 @@ class Compressor:
             out = torch.empty(cap, dtype=torch.uint8, device=src.device)
         self._check_tensor(out)
         out_n = C.c_size_t(0)
-        opt = _capi.make_options(strategy, final_stream, lazy)
+        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path)
         s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
         self._check(self._lib.sfh_compress_device(self._h, src.data_ptr() if n else None, n, out.data_ptr(),
                                                   out.numel(), C.byref(out_n), C.byref(opt), C.c_void_p(s)))

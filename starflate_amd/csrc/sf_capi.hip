@@ -76,8 +76,8 @@ uint32_t chunks_of(size_t n) { return n ? (uint32_t)((n + sf::kChunk - 1) / sf::
 
 int check_opt(const sfh_options* o) {
   if (!o) return 0;
-  if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 1) return -1;
-  for (int k = 0; k < 5; ++k)
+  if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 1 || o->no_stored_fast_path > 1) return -1;
+  for (int k = 0; k < 4; ++k)
     if (o->reserved[k]) return -1;
   return 0;
 }
@@ -95,7 +95,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   int rc = ensure_ws(ctx, nchunks);
   if (rc) return rc;
   ctx->last_chunks = nchunks;
-  const sf::Options ko{o.strategy, o.final_stream, o.lazy};
+  const sf::Options ko{o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path ? 0u : 1u};
   const bool prof = ctx->profiling != 0;
   if (prof) SF_HIP(hipEventRecord(ctx->ev[0], s), "event");
   SF_HIP(sf::launch_lz77((const uint8_t*)d_src, n, nchunks, ctx->ws, ko, s), "launch k_lz77");

@@ -21,6 +21,7 @@ constexpr uint32_t kHashBits = 12;
 constexpr uint32_t kRegion = 128;       // parse region: matches never cross it
 constexpr uint32_t kCap = 16;           // match-time compare width; longer matches are extended by the parse
 constexpr uint32_t kMinMatch = 4;
+constexpr uint32_t kSkipSlack = 128;    // stored fast path: first 8 KiB with >= 8192-128 tokens => no further search
 constexpr uint32_t kTokMatch = 0x80000000u;  // token: bit31 match, 16..23 len-3, 0..14 dist-1
 
 constexpr uint32_t kHistStride = 320;   // ll[0..285] at 0, d[0..29] at 288
@@ -55,6 +56,7 @@ struct Options {
   uint32_t strategy;
   uint32_t final_stream;
   uint32_t lazy;
+  uint32_t fast_skip;
 };
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
                                                      uint32_t* __restrict__ tokens,
                                                      uint32_t* __restrict__ ntok_out,
                                                      uint32_t* __restrict__ hist_out, uint32_t lazy,
-                                                     uint64_t* __restrict__ stamps) {
+                                                     uint32_t fast_skip, uint64_t* __restrict__ stamps) {
   uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t st_t = 0;
   auto stamp = [&](int slot) {
@@ -194,7 +194,19 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
   const uint32_t nsteps = (n + kStep - 1) / kStep;
   uint32_t total = 0;  // tokens of the quarters done so far (uniform)
 
+  bool skip = false;  // stored fast path (uniform): set after the first quarter
   for (uint32_t qb = 0; qb < n; qb += kQuarter) {
+    if (skip) {
+      // the first quarter was (almost) all literals: no search, every position is a literal
+      const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;
+      for (uint32_t rel = t; rel < qn; rel += K1_THREADS) {
+        const uint32_t b = s_bytes[qb + rel];
+        tk[total + rel] = b;
+        atomicAdd(&s_hist[b], 1u);
+      }
+      total += qn;
+      continue;
+    }
     // ---- match finding over this quarter ----
     const uint32_t s_end = (qb / kStep + kQuarter / kStep) < nsteps ? (qb / kStep + kQuarter / kStep) : nsteps;
     for (uint32_t s = qb / kStep; s < s_end; ++s) {
@@ -482,6 +494,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
       }
     }
     total += s_misc[0];
+    if (qb == 0) skip = fast_skip && n > kQuarter && total >= kQuarter - kSkipSlack;
     if constexpr (STAMPS) __syncthreads();
     stamp(5);
     // the next quarter's first barrier orders these reads before its result writes
@@ -1084,10 +1097,10 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
   const uint32_t K1_LDS = sf::K1_LDS + extra;
   if (ws.stamps)
     hipLaunchKernelGGL(k_lz77<true>, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
-                       ws.hist, opt.lazy, ws.stamps);
+                       ws.hist, opt.lazy, opt.fast_skip, ws.stamps);
   else
     hipLaunchKernelGGL(k_lz77<false>, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
-                       ws.hist, opt.lazy, (uint64_t*)nullptr);
+                       ws.hist, opt.lazy, opt.fast_skip, (uint64_t*)nullptr);
   return hipGetLastError();
 }
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,

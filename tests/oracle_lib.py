@@ -29,6 +29,7 @@ class Params(C.Structure):
         ("long_hash_bytes", C.c_uint32),
         ("chain_depth", C.c_uint32),
         ("cap", C.c_uint32),
+        ("fast_skip", C.c_uint32),
     ]
 
 

@@ -84,6 +84,21 @@ def test_stage_parity(compressor, starfleet):
         assert plan[c, 0] == pl.btype and plan[c, 1] == pl.out_bytes, f"chunk {c}: plan {plan[c]} vs {pl.btype},{pl.out_bytes}"
 
 
+def test_stored_fast_path(compressor):
+    """High-entropy chunks skip the search after their first 8 KiB; the rule is part of the
+    specification, so the stream still equals the oracle's, with the switch on and off."""
+    rng = np.random.default_rng(21)
+    rnd = rng.integers(0, 256, 5 * CHUNK + 999, dtype=np.uint8)
+    head_then_zeros = np.concatenate([rnd[:9000], np.zeros(3 * CHUNK, np.uint8)])
+    for data in (rnd, head_then_zeros, synth.gen_mixed(1 << 20, seed=4, stripe=1 << 15)):
+        for on in (True, False):
+            got = np.frombuffer(compressor.compress(data, stored_fast_path=on), np.uint8)
+            want = O.compress(data, O.default_params(fast_skip=int(on)))
+            assert np.array_equal(got, want)
+            _roundtrip(got, data)
+    assert len(compressor.compress(rnd)) == rnd.size + 5 * 6  # six stored blocks
+
+
 def test_device_tensor_path_and_shard_concat(compressor):
     """Device-buffer entry point; two non-final/final shards concatenate into one valid stream."""
     import torch
