@@ -326,7 +326,7 @@ void sfo_default_params(sfo_params* p) {
   p->chunk_bytes = 32768;
   p->step = 1024;
   p->hash_bits = 12;
-  p->region_bytes = 128;
+  p->region_bytes = 1024;
   p->min_match = 4;
   p->lazy = 1;
   p->final_stream = 1;

@@ -18,7 +18,7 @@ namespace sf {
 constexpr uint32_t kChunk = 32768;      // bytes per independently coded DEFLATE block
 constexpr uint32_t kStep = 1024;        // positions per hash-insertion step (= K1 threads)
 constexpr uint32_t kHashBits = 12;
-constexpr uint32_t kRegion = 128;       // parse region: matches never cross it
+constexpr uint32_t kRegion = 1024;      // parse region: matches never cross it
 constexpr uint32_t kCap = 16;           // match-time compare width; longer matches are extended by the parse
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kSkipSlack = 128;    // stored fast path: first 8 KiB with >= 8192-128 tokens => no further search
