@@ -101,7 +101,7 @@ enum sfh_debug_what {
   SFH_DBG_PLAN = 3,   /* uint32[4] per chunk: btype, out_bytes, header_bits, body_bits */
   SFH_DBG_LENS = 4,   /* uint8[320] per chunk: ll lens [0..287], d lens [288..319] */
   SFH_DBG_OFFSETS = 5, /* uint64 per chunk */
-  SFH_DBG_STAMPS = 6   /* uint64[8] per chunk; only with env SFH_K1_STAMPS=1 at sfh_create
+  SFH_DBG_STAMPS = 6   /* uint64[2][nchunks][8] (k_lz77, k_plan); only with env SFH_K1_STAMPS=1 at sfh_create
                           (diagnostic k_lz77 build: cycles per phase, never a timing claim) */
 };
 int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes);

@@ -119,7 +119,7 @@ class Compressor:
             _capi.DBG_PLAN: ((nchunks, 4), np.uint32),
             _capi.DBG_LENS: ((nchunks, 320), np.uint8),
             _capi.DBG_OFFSETS: ((nchunks,), np.uint64),
-            _capi.DBG_STAMPS: ((nchunks, 8), np.uint64),
+            _capi.DBG_STAMPS: ((2, nchunks, 8), np.uint64),  # [0] k_lz77 phases, [1] k_plan phases
         }
         shape, dt = shapes[what]
         a = np.empty(shape, dtype=dt)

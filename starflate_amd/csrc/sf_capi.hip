@@ -64,7 +64,7 @@ int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
     free_ws(ctx);
     return fail(ctx, SFH_E_NOMEM, "workspace hipMalloc", e);
   }
-  if (ctx->k1_stamps && (e = hipMalloc(&ctx->ws.stamps, nc * 8 * sizeof(uint64_t))) != hipSuccess) {
+  if (ctx->k1_stamps && (e = hipMalloc(&ctx->ws.stamps, nc * 16 * sizeof(uint64_t))) != hipSuccess) {
     free_ws(ctx);
     return fail(ctx, SFH_E_NOMEM, "stamps hipMalloc", e);
   }
@@ -253,7 +253,7 @@ int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes) {
     case SFH_DBG_HIST: p = ctx->ws.hist; avail = nc * sf::kHistStride * 4; break;
     case SFH_DBG_PLAN: p = ctx->ws.plan; avail = nc * sizeof(sf::ChunkPlan); break;
     case SFH_DBG_OFFSETS: p = ctx->ws.offsets; avail = nc * 8; break;
-    case SFH_DBG_STAMPS: p = ctx->ws.stamps; avail = p ? nc * 64 : 0; break;
+    case SFH_DBG_STAMPS: p = ctx->ws.stamps; avail = p ? nc * 128 : 0; break;
     case SFH_DBG_LENS: {
       if (bytes > nc * 320) return SFH_E_INVALID_ARG;
       SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");

@@ -512,6 +512,16 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
 // ---------------------------------------------------------------------------
 // K2: per-chunk code plan.  One wave (64-thread workgroup) per chunk.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void or_bits(uint32_t* stage, uint32_t bitpos, uint64_t value) {
+  const uint32_t w = bitpos >> 5, sh = bitpos & 31;
+  const uint64_t v0 = value << sh;
+  const uint32_t v2 = sh ? (uint32_t)(value >> (64 - sh)) : 0u;
+  const uint32_t lo = (uint32_t)v0, mid = (uint32_t)(v0 >> 32);
+  if (lo) atomicOr(&stage[w], lo);
+  if (mid) atomicOr(&stage[w + 1], mid);
+  if (v2) atomicOr(&stage[w + 2], v2);
+}
+
 struct PlanSmem {
   uint32_t freq[kHistStride];
   uint32_t ukey[288];
@@ -577,21 +587,25 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
   __syncthreads();
   for (uint32_t k = lane; k < m; k += 64) S.w[k] = S.key[k] >> 9;
   __syncthreads();
-  // two-queue merge (serial; leaves first on ties)
+  // two-queue merge (serial; leaves first on ties).  Both queues are consumed in index order,
+  // so their next heads are fetched from LDS two picks ahead of use.
   if (lane == 0) {
     const uint32_t INF = 0xFFFFFFFFu;
     uint32_t i = 0, j = m, k = m;
-    uint32_t wi = S.w[0], wj = INF;
+    uint32_t a0 = S.w[0], a1 = S.w[1], a2 = 2 < m ? S.w[2] : INF;  // leaves i, i+1, i+2 (m >= 2)
+    uint32_t b0 = INF, b1 = INF;                                    // internal nodes j, j+1
     while (k < 2 * m - 1) {
-      uint32_t a, b, wa, wb;
-      if (wi <= wj) { a = i++; wa = wi; wi = i < m ? S.w[i] : INF; }
-      else          { a = j++; wa = wj; wj = j < k ? S.w[j] : INF; }
-      if (wi <= wj) { b = i++; wb = wi; wi = i < m ? S.w[i] : INF; }
-      else          { b = j++; wb = wj; wj = j < k ? S.w[j] : INF; }
-      S.w[k] = wa + wb;
-      S.parent[a] = (uint16_t)k;
-      S.parent[b] = (uint16_t)k;
-      if (j == k) wj = wa + wb;
+      uint32_t x, y, wx, wy;
+      if (a0 <= b0) { x = i++; wx = a0; a0 = a1; a1 = a2; a2 = i + 2 < m ? S.w[i + 2] : INF; }
+      else          { x = j++; wx = b0; b0 = b1; b1 = j + 1 < k ? S.w[j + 1] : INF; }
+      if (a0 <= b0) { y = i++; wy = a0; a0 = a1; a1 = a2; a2 = i + 2 < m ? S.w[i + 2] : INF; }
+      else          { y = j++; wy = b0; b0 = b1; b1 = j + 1 < k ? S.w[j + 1] : INF; }
+      const uint32_t sum = wx + wy;
+      S.w[k] = sum;
+      S.parent[x] = (uint16_t)k;
+      S.parent[y] = (uint16_t)k;
+      if (j == k) b0 = sum;          // the new node is the internal queue's head ...
+      else if (j + 1 == k) b1 = sum; // ... or its second entry
       ++k;
     }
   }
@@ -683,27 +697,75 @@ __device__ void canonical_codes(const uint8_t* lens, uint32_t n, uint32_t* out, 
   }
 }
 
-// RLE of one code-length sequence (own state per sequence: the reference decoder
-// reads HLIT and HDIST sequences with separate vectors, src/decompress.cpp:353-360,
-// and never bounds-checks a run, :277-296).
-__device__ uint32_t rle_lengths(const uint8_t* lens, uint32_t n, uint8_t* sym, uint8_t* ext) {
-  uint32_t k = 0, i = 0;
-  while (i < n) {
-    const uint8_t v = lens[i];
-    uint32_t r = 1;
-    while (i + r < n && lens[i + r] == v) ++r;
-    i += r;
-    if (v == 0) {
-      while (r >= 11) { const uint32_t c = r < 138 ? r : 138; sym[k] = 18; ext[k++] = (uint8_t)(c - 11); r -= c; }
-      if (r >= 3) { sym[k] = 17; ext[k++] = (uint8_t)(r - 3); r = 0; }
-      while (r) { sym[k] = 0; ext[k++] = 0; --r; }
-    } else {
-      sym[k] = v; ext[k++] = 0; --r;
-      while (r >= 3) { const uint32_t c = r < 6 ? r : 6; sym[k] = 16; ext[k++] = (uint8_t)(c - 3); r -= c; }
-      while (r) { sym[k] = v; ext[k++] = 0; --r; }
-    }
+// RLE of one code-length sequence by the whole wave (own state per sequence: the reference
+// decoder reads the HLIT and HDIST sequences with separate vectors, src/decompress.cpp:353-360,
+// and never bounds-checks a run, :277-296).  Run starts by ballot, run length = distance to the
+// next start, items per run in closed form (zeros: 18 x 138, then 18 / 17 / literal zeros;
+// other values: the value, 16 x 6, then 16 / literals), item slots by a scan over the starts.
+// Writes rle_sym/rle_ext from `base` on, counts symbols into clfreq; returns the item count.
+__device__ uint32_t rle_parallel(PlanSmem& S, const uint8_t* lens, uint32_t n, uint32_t base, uint32_t lane) {
+  uint64_t Sm[5];
+  uint32_t val[5];
+#pragma unroll
+  for (uint32_t g = 0; g < 5; ++g) {
+    const uint32_t i = g * 64 + lane;
+    const uint32_t cur = i < n ? lens[i] : 0xFFu;
+    const uint32_t prev = (i > 0 && i < n) ? lens[i - 1] : 0xFEu;
+    val[g] = cur;
+    Sm[g] = __ballot(i < n && (i == 0 || prev != cur));
   }
-  return k;
+  uint32_t total = 0;
+#pragma unroll
+  for (uint32_t g = 0; g < 5; ++g) {
+    if (g * 64 >= n) break;
+    const uint32_t i = g * 64 + lane;
+    const bool start = (Sm[g] >> lane) & 1;
+    // next run start after i: in this group, else the first start of a later group, else n
+    uint32_t later = n;
+#pragma unroll
+    for (uint32_t g2 = 4; g2 > g; --g2)
+      if (Sm[g2]) later = g2 * 64 + (uint32_t)__builtin_ctzll(Sm[g2]);
+    const uint64_t up = lane < 63 ? (Sm[g] >> (lane + 1)) : 0ull;
+    uint32_t nxt = up ? i + 1 + (uint32_t)__builtin_ctzll(up) : later;
+    nxt = nxt < n ? nxt : n;
+    const uint32_t r = start ? nxt - i : 0u;
+    const uint32_t v = val[g];
+    uint32_t q = 0, rem = 0, cnt = 0;
+    if (start) {
+      if (v == 0) {
+        q = r / 138u;
+        rem = r - 138u * q;
+        cnt = q + ((rem >= 3) ? 1u : rem);
+      } else {
+        q = (r - 1) / 6u;
+        rem = (r - 1) - 6u * q;
+        cnt = 1 + q + ((rem >= 3) ? 1u : rem);
+      }
+    }
+    const uint32_t incl = wave_incl_scan(cnt, lane);
+    uint32_t k = base + total + incl - cnt;
+    auto put = [&](uint32_t sym, uint32_t ext) {
+      S.rle_sym[k] = (uint8_t)sym;
+      S.rle_ext[k] = (uint8_t)ext;
+      atomicAdd(&S.clfreq[sym], 1u);
+      ++k;
+    };
+    if (start) {
+      if (v == 0) {
+        for (uint32_t c = 0; c < q; ++c) put(18, 138 - 11);
+        if (rem >= 11) put(18, rem - 11);
+        else if (rem >= 3) put(17, rem - 3);
+        else for (uint32_t c = 0; c < rem; ++c) put(0, 0);
+      } else {
+        put(v, 0);
+        for (uint32_t c = 0; c < q; ++c) put(16, 6 - 3);
+        if (rem >= 3) put(16, rem - 3);
+        else for (uint32_t c = 0; c < rem; ++c) put(v, 0);
+      }
+    }
+    total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  }
+  return total;
 }
 
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -711,8 +773,20 @@ __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 
 __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
                                              const uint32_t* __restrict__ hist,
                                              ChunkPlan* __restrict__ plan, ChunkCodes* __restrict__ codes,
-                                             uint32_t strategy, uint32_t final_stream) {
+                                             uint32_t strategy, uint32_t final_stream,
+                                             uint64_t* __restrict__ stamps) {
   __shared__ PlanSmem S;
+  // diagnostic (stamps != nullptr, SFH_K1_STAMPS=1): cycles per phase at stamps[chunk*8 + 8*nchunks..]
+  uint64_t st_t = stamps ? __builtin_amdgcn_s_memtime() : 0;
+  uint32_t st_k = 0;
+  auto stamp = [&]() {
+    if (stamps) {
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      if (threadIdx.x == 0 && st_k < 8) stamps[((uint64_t)nchunks + blockIdx.x) * 8 + st_k] = now - st_t;
+      st_t = now;
+      ++st_k;
+    }
+  };
   const uint32_t lane = threadIdx.x;
   const uint32_t chunk = blockIdx.x;
   const uint64_t cbase = (uint64_t)chunk * kChunk;
@@ -723,8 +797,11 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   for (uint32_t s = lane; s < 320; s += 64) S.lens[s] = 0;
   __syncthreads();
 
+  stamp();  // 0 load
   build_lengths(S, S.freq, 286, 15, S.lens, lane);
+  stamp();  // 1 lit/len lengths
   build_lengths(S, S.freq + kHistD, 30, 15, S.lens + 288, lane);
+  stamp();  // 2 distance lengths
 
   // body costs
   uint32_t dyn = 0, fix = 0, extra = 0, nmatch = 0;
@@ -747,59 +824,59 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   const uint32_t dyn_body = dyn + extra;
   const uint32_t fix_body = fix + extra + 5 * nmatch;
 
-  // dynamic header: HLIT/HDIST, RLE, code-length code
+  // dynamic header: HLIT/HDIST, RLE, code-length code -- all wave-parallel
   if (lane < 32) S.clfreq[lane] = 0;
+  for (uint32_t k = lane; k < kHeaderWords; k += 64) S.header[k] = 0;
   __syncthreads();
-  if (lane == 0) {
-    uint32_t hlit = 286, hdist = 30;
-    while (hlit > 257 && S.lens[hlit - 1] == 0) --hlit;
-    while (hdist > 1 && S.lens[288 + hdist - 1] == 0) --hdist;
-    const uint32_t nl = rle_lengths(S.lens, hlit, S.rle_sym, S.rle_ext);
-    const uint32_t nd = rle_lengths(S.lens + 288, hdist, S.rle_sym + nl, S.rle_ext + nl);
-    for (uint32_t k = 0; k < nl + nd; ++k) S.clfreq[S.rle_sym[k]]++;
-    S.misc[0] = hlit;
-    S.misc[1] = hdist;
-    S.misc[2] = nl + nd;
+  uint32_t hlit, hdist;
+  {
+    // last used lit/len symbol (EOB = 256 is always used) and distance symbol
+    const uint64_t m4 = __ballot(256 + lane < 286 && S.lens[256 + lane] != 0);
+    hlit = 256 + 64 - (uint32_t)__builtin_clzll(m4);
+    const uint64_t md = __ballot(lane < 30 && S.lens[288 + lane] != 0);
+    hdist = md ? 64 - (uint32_t)__builtin_clzll(md) : 1u;
   }
+  const uint32_t nl = rle_parallel(S, S.lens, hlit, 0, lane);
+  const uint32_t nd = rle_parallel(S, S.lens + 288, hdist, nl, lane);
+  const uint32_t nitems = nl + nd;
   __syncthreads();
+  stamp();  // 3 costs + RLE
   build_lengths(S, S.clfreq, 19, 7, S.cl_lens, lane);
   canonical_codes(S.cl_lens, 19, S.cl_code, lane);
   __syncthreads();
-  if (lane == 0) {
-    const uint32_t hlit = S.misc[0], hdist = S.misc[1], nitems = S.misc[2];
-    uint32_t hclen = 19;
-    while (hclen > 4 && S.cl_lens[c_cl_order[hclen - 1]] == 0) --hclen;
-    uint64_t acc = 0;
-    uint32_t nb = 0, wpos = 0;
-    auto put = [&](uint32_t v, uint32_t n) {
-      acc |= (uint64_t)v << nb;
-      nb += n;
-      if (nb >= 32) {
-        S.header[wpos++] = (uint32_t)acc;
-        acc >>= 32;
-        nb -= 32;
+  stamp();  // 4 code-length code
+  {
+    const uint64_t mc = __ballot(lane < 19 && S.cl_lens[c_cl_order[lane < 19 ? lane : 0]] != 0);
+    uint32_t hclen = mc ? 64 - (uint32_t)__builtin_clzll(mc) : 4u;
+    hclen = hclen < 4 ? 4u : hclen;
+    // BFINAL, BTYPE=10, HLIT, HDIST, HCLEN: 17 bits; then hclen 3-bit code-length-code lengths
+    if (lane == 0)
+      or_bits(S.header, 0, (uint64_t)((fin ? 1u : 0u) | (2u << 1) | ((hlit - 257) << 3) | ((hdist - 1) << 8) | ((hclen - 4) << 13)));
+    if (lane < hclen) or_bits(S.header, 17 + 3 * lane, (uint64_t)S.cl_lens[c_cl_order[lane]]);
+    uint32_t bitbase = 17 + 3 * hclen;
+#pragma unroll
+    for (uint32_t g = 0; g < 5; ++g) {
+      if (g * 64 >= nitems) break;
+      const uint32_t k = g * 64 + lane;
+      uint32_t nb = 0;
+      uint64_t v = 0;
+      if (k < nitems) {
+        const uint32_t sy = S.rle_sym[k];
+        const uint32_t c = S.cl_code[sy];
+        const uint32_t cl = c >> 16;
+        const uint32_t eb = sy == 16 ? 2u : sy == 17 ? 3u : sy == 18 ? 7u : 0u;
+        v = (uint64_t)(c & 0xFFFF) | ((uint64_t)S.rle_ext[k] << cl);
+        nb = cl + eb;
       }
-    };
-    put(fin ? 1u : 0u, 1);
-    put(2, 2);
-    put(hlit - 257, 5);
-    put(hdist - 1, 5);
-    put(hclen - 4, 4);
-    for (uint32_t k = 0; k < hclen; ++k) put(S.cl_lens[c_cl_order[k]], 3);
-    for (uint32_t k = 0; k < nitems; ++k) {
-      const uint32_t sy = S.rle_sym[k];
-      const uint32_t c = S.cl_code[sy];
-      put(c & 0xFFFF, c >> 16);
-      if (sy == 16) put(S.rle_ext[k], 2);
-      else if (sy == 17) put(S.rle_ext[k], 3);
-      else if (sy == 18) put(S.rle_ext[k], 7);
+      const uint32_t incl = wave_incl_scan(nb, lane);
+      if (nb) or_bits(S.header, bitbase + incl - nb, v);
+      bitbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-    const uint32_t hbits = wpos * 32 + nb;
-    if (nb) S.header[wpos++] = (uint32_t)acc;
-    S.misc[3] = hbits;  // includes the 3 block-header bits
+    if (lane == 0) S.misc[3] = bitbase;  // includes the 3 block-header bits
   }
   __syncthreads();
 
+  stamp();  // 5 header bits
   const uint32_t dyn_hbits = S.misc[3];
   const uint32_t dyn_bits = dyn_hbits + dyn_body;
   const uint32_t fix_bits = 3 + fix_body;
@@ -840,6 +917,7 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
     P.body_bits = bt == 1 ? fix_body : dyn_body;
     plan[chunk] = P;
   }
+  stamp();  // 6 canonical codes + stores
 }
 
 // ---------------------------------------------------------------------------
@@ -879,16 +957,6 @@ constexpr uint32_t K4_THREADS = 512;
 constexpr uint32_t K4_WAVES = K4_THREADS / 64;
 constexpr uint32_t K4_TPT = 4;  // tokens per thread per batch
 constexpr uint32_t K4_STAGE_WORDS = 10240;  // 40 KiB: fixed-Huffman worst case of a 32 KiB chunk + align
-
-__device__ __forceinline__ void or_bits(uint32_t* stage, uint32_t bitpos, uint64_t value) {
-  const uint32_t w = bitpos >> 5, sh = bitpos & 31;
-  const uint64_t v0 = value << sh;
-  const uint32_t v2 = sh ? (uint32_t)(value >> (64 - sh)) : 0u;
-  const uint32_t lo = (uint32_t)v0, mid = (uint32_t)(v0 >> 32);
-  if (lo) atomicOr(&stage[w], lo);
-  if (mid) atomicOr(&stage[w + 1], mid);
-  if (v2) atomicOr(&stage[w + 2], v2);
-}
 
 __device__ __forceinline__ void token_bits(uint32_t tok, const uint32_t* lcode, const uint32_t* dcode,
                                            uint64_t& value, uint32_t& nb) {
@@ -1106,7 +1174,7 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,
                        hipStream_t s) {
   hipLaunchKernelGGL(k_plan, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.plan, ws.codes,
-                     opt.strategy, opt.final_stream);
+                     opt.strategy, opt.final_stream, ws.stamps);
   return hipGetLastError();
 }
 hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t* d_total, hipStream_t s) {

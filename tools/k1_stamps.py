@@ -15,8 +15,13 @@ data = synth.gen_text_torch(n, seed=3, device="cuda")
 c = Compressor(0)
 for _ in range(2):
     c.compress_tensor(data)
-st = c.debug(_capi.DBG_STAMPS, n // 32768).astype(np.float64)
+both = c.debug(_capi.DBG_STAMPS, n // 32768).astype(np.float64)
+st = both[0]
 names = ["stage", "match", "take", "walk", "segpre", "emit", "tail"]
 med = np.median(st[:, :7], axis=0)
 print("median cycles per chunk:", {k: int(v) for k, v in zip(names, med)}, "sum", int(med.sum()))
 print("shares:", {k: round(v / med.sum(), 3) for k, v in zip(names, med)})
+k2 = both[1]
+names2 = ["load", "ll_lengths", "d_lengths", "costs+rle", "cl_code", "header", "codes+store"]
+med2 = np.median(k2[:, :7], axis=0)
+print("k_plan median cycles per chunk:", {k: int(v) for k, v in zip(names2, med2)}, "sum", int(med2.sum()))
