@@ -6,7 +6,9 @@ Workload (BASELINE.json configs[2]): 1 GiB synthetic enwik-like text per GPU,
 region starts.  A "step" = one pass of the whole hot path (k_lz77 -> k_plan ->
 k_scan -> k_emit) over that input; with N > 1 every rank compresses its own 1 GiB
 shard (weak scaling) and the byte-aligned streams are concatenated on rank 0 over
-RCCL (sizes all_gather + one point-to-point send per rank).
+RCCL.  For N > 1 the sharding is block-cyclic in --rounds rounds (global piece g = k*N + rank),
+so the gather of round k (sizes all_gather + one point-to-point send per rank, straight to
+the final offset) overlaps the compression of round k+1 (starflate_amd/multigpu.py).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--bytes B] [--workload text|random|mixed]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -38,6 +40,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bytes", type=int, default=512 << 20)
+    ap.add_argument("--rounds", type=int, default=4, help="N > 1: block-cyclic rounds per rank (gather/compute overlap)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the N > 1 code path (RCCL group, rounds, gather) even with one rank")
     args = ap.parse_args()
 
     import numpy as np
@@ -54,8 +59,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.bytes
@@ -73,26 +80,38 @@ def main():
 
     comp = Compressor(local_rank)
     comp.set_profiling(True)
-    bound = comp.compress_bound(n)
-    scratch = torch.empty(bound, dtype=torch.uint8, device=dev)
-    gathered = torch.empty(bound * world, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    K = max(1, args.rounds) if multi else 1
+    if n % (K * 32768):
+        raise SystemExit("--bytes must be a multiple of rounds * 32768")
+    pieces = list(data.chunk(K))
+    bound = comp.compress_bound(n // K)
+    scratch = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(K)]
+    gathered = torch.empty(bound * K * world, dtype=torch.uint8, device=dev) if (multi and rank == 0) else None
     stage_acc = {}
     result = {}
 
     def step():
-        if world == 1:
-            out, total = comp.compress_tensor(data, out=scratch)
-            result["local"], result["local_n"] = out, total
+        ms = {}
+        sizes = [0] * K
+
+        def compress_fn(piece, final, k):
+            out, nb = comp.compress_tensor(piece, out=scratch[k], final_stream=final)
+            sizes[k] = nb
+            for name, v in comp.stage_ms().items():
+                ms[name] = ms.get(name, 0.0) + v
+            return out, nb
+
+        if not multi:
+            out, total = compress_fn(data, True, 0)
         else:
-            local, ln = comp.compress_tensor(data, out=scratch, final_stream=(rank == world - 1))
-            out, total = multigpu.concat_streams(local, ln, out=gathered)
-            result["local"], result["local_n"] = local, ln
+            out, total = multigpu.compress_pipelined(compress_fn, pieces, out=gathered)
+        result["sizes"], result["local_n"] = sizes, sum(sizes)
         result["out"], result["total"] = out, total
-        for k, v in comp.stage_ms().items():
-            stage_acc.setdefault(k, []).append(v)
+        for name, v in ms.items():
+            stage_acc.setdefault(name, []).append(v)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -105,7 +124,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -119,43 +138,48 @@ def main():
     # ---- verification (untimed): every rank inflates its own shard stream with zlib ----
     ok = None
     if not args.no_verify:
-        host_in = data.cpu().numpy()
-        stream = result["local"][:local_n].cpu().numpy().tobytes()
-        d = zlib.decompressobj(-15)
-        back = d.decompress(stream)
-        ok = len(back) == n and back == host_in.tobytes()
-        del back
-        if world > 1:
+        ok = True
+        my_crcs = []
+        for k in range(K):
+            host_piece = pieces[k].cpu().numpy().tobytes()
+            stream = scratch[k][: result["sizes"][k]].cpu().numpy().tobytes()
+            back = zlib.decompressobj(-15).decompress(stream)  # a non-final piece is still inflatable
+            ok = ok and back == host_piece
+            my_crcs.append(zlib.crc32(host_piece))
+            del back, host_piece
+        if multi:
             flag = torch.tensor([1 if ok else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item())
-            crc = torch.tensor([zlib.crc32(host_in.tobytes())], dtype=torch.int64, device=dev)
-            crcs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            crc = torch.tensor(my_crcs, dtype=torch.int64, device=dev)
+            crcs = [torch.zeros(K, dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(crcs, crc)
-            if rank == 0:
+            if rank == 0:  # the concatenation is ONE valid stream of all pieces in the order g = k*N + rank
                 whole = zlib.decompress(result["out"][:total_out].cpu().numpy().tobytes(), -15)
+                pb = n // K
                 ok = ok and len(whole) == total_in and all(
-                    zlib.crc32(whole[r * n:(r + 1) * n]) == int(crcs[r].item()) for r in range(world))
+                    zlib.crc32(whole[(k * world + r) * pb:(k * world + r + 1) * pb]) == int(crcs[r][k].item())
+                    for k in range(K) for r in range(world))
                 del whole
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     # ---- ratio vs zlib -6 on a bounded sample of the same bytes ----
-    zs = min(n, 64 << 20)
-    host_sample = data[:zs].cpu().numpy().tobytes()
+    last = pieces[-1]  # the piece of the last compress call (its chunk offsets are still in the ctx)
+    zs = min(last.numel(), 64 << 20)
+    host_sample = last[:zs].cpu().numpy().tobytes()
     tz = time.perf_counter()
     co = zlib.compressobj(6, zlib.DEFLATED, -15)
     zlen = len(co.compress(host_sample)) + len(co.flush())
     tz = time.perf_counter() - tz
     # our bytes for the same prefix: chunk offsets of the last timed call (no extra launch)
     from starflate_amd import _capi
-    nchunks = (n + 32767) // 32768
+    nchunks = (last.numel() + 32767) // 32768
     offs = comp.debug(_capi.DBG_OFFSETS, nchunks)
-    ours_sample = int(offs[zs // 32768]) if zs < n else local_n
+    ours_sample = int(offs[zs // 32768]) if zs < last.numel() else result["sizes"][-1]
     ratio = n / max(local_n, 1)
     ratio_zlib6 = zs / zlen
     ratio_ours_sample = zs / ours_sample
@@ -181,7 +205,7 @@ def main():
 
     # ---- CPU baseline: oracle restatement of the reference decompress(), 1 thread ----
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not args.force_dist:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
 
@@ -205,7 +229,8 @@ def main():
         "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": wl, "block_bytes": 32768, "strategy": "auto", "parallelism": f"shard{world}"},
+        "config": {"workload": wl, "block_bytes": 32768, "strategy": "auto",
+                   "parallelism": f"shard{world}" + (f" block-cyclic x{K}, gather overlapped" if multi else "")},
         "ratio": round(ratio, 4), "ratio_zlib6": round(ratio_zlib6, 4),
         "ratio_vs_zlib6": round(ratio_ours_sample / ratio_zlib6, 4),
         "compressed_bytes": total_out, "roundtrip_ok": ok,
@@ -213,7 +238,7 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,6 +50,57 @@ def concat_streams(local, local_n, group=None, out=None):
     return None, total
 
 
+def compress_pipelined(compress_fn, pieces, group=None, out=None):
+    """Block-cyclic sharding with overlap: the global input is K*world pieces in the order
+    g = k*world + rank; this rank holds `pieces[k]` for rounds k = 0..K-1.  Round k's streams are
+    gathered straight to their final offsets (they only depend on the sizes of rounds <= k, known
+    after one small all_gather), asynchronously, while round k+1 is being compressed -- so the
+    point-to-point gather over xGMI hides behind compression instead of following it.
+
+    compress_fn(piece, final, k) -> (uint8 tensor, nbytes): this rank's stream for round k, in a
+    buffer that stays untouched until this function returns (use one buffer per round);
+    `final` is True only for the globally last piece.  Returns (out, total) on rank 0 and
+    (None, total) elsewhere; `out` (rank 0) must hold the whole concatenation if given."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    K = len(pieces)
+    works, keep, parts = [], [], []
+    base = 0
+    for k, piece in enumerate(pieces):
+        local, n = compress_fn(piece, k == K - 1 and rank == world - 1, k)
+        dev = local.device
+        mine = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, mine, group=group)
+        sizes = [int(x.item()) for x in sizes]
+        if rank == 0:
+            if out is not None:
+                if out.numel() < base + sum(sizes):
+                    raise ValueError("compress_pipelined: `out` is smaller than the concatenated stream")
+                dst, o0 = out, base
+            else:  # no preallocated output: one buffer per round, concatenated at the end
+                dst, o0 = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device=dev), 0
+                parts.append(dst[: sum(sizes)])
+            dst[o0: o0 + sizes[0]] = local[: sizes[0]]
+            ops, off = [], o0 + sizes[0]
+            for r in range(1, world):
+                if sizes[r]:
+                    ops.append(dist.P2POp(dist.irecv, dst[off: off + sizes[r]], r, group=group))
+                off += sizes[r]
+        else:
+            ops = [dist.P2POp(dist.isend, local[:n], 0, group=group)] if n else []
+        if ops:
+            works.extend(dist.batch_isend_irecv(ops))
+        keep.append(local)
+        base += sum(sizes)
+    for w in works:
+        w.wait()
+    del keep
+    if rank != 0:
+        return None, base
+    return (out[:base] if out is not None else torch.cat(parts)), base
+
+
 def compress_sharded(compressor, shard, group=None, out=None, scratch=None, **kw):
     """Compress this rank's shard (BFINAL only on the last rank) and concatenate on rank 0."""
     world = dist.get_world_size(group)

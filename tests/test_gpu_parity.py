@@ -130,3 +130,38 @@ def test_size_independent_properties_large(compressor):
     assert zlib.decompress(bytes(s1), -15) == data.tobytes()
     offs = compressor.debug(_capi.DBG_OFFSETS, (data.size + CHUNK - 1) // CHUNK)
     assert np.all(np.diff(offs.astype(np.int64)) > 0) and offs[0] == 0
+
+
+def test_pipelined_rounds_over_rccl_single_rank(compressor):
+    """The N > 1 bench path (block-cyclic rounds + gather) on the one GPU we have: a 1-rank
+    `nccl` (= RCCL) group exercises the real process group, the real compressor and the
+    BFINAL / alignment logic across rounds; the 2- and 3-rank exchange is covered over gloo."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from starflate_amd import multigpu
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        data = synth.gen_text(4 * 5 * CHUNK, seed=31)
+        src = torch.from_numpy(data).cuda()
+        pieces = list(src.chunk(4))
+        bufs = [torch.empty(compressor.compress_bound(p.numel()), dtype=torch.uint8, device="cuda") for p in pieces]
+
+        def compress_fn(piece, final, k):
+            return compressor.compress_tensor(piece, out=bufs[k], final_stream=final)
+
+        out, total = multigpu.compress_pipelined(compress_fn, pieces)
+        stream = out[:total].cpu().numpy()
+        _roundtrip(stream, data)
+        want = np.concatenate([O.compress(data[k * 5 * CHUNK:(k + 1) * 5 * CHUNK], _params(final_stream=(k == 3))) for k in range(4)])
+        assert np.array_equal(stream, want)
+    finally:
+        dist.destroy_process_group()

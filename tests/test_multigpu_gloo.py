@@ -45,6 +45,49 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
+def _worker_pipelined(rank, world, port, piece_bytes, K, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_lib as O
+    from starflate_amd import multigpu, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    whole = synth.gen_text(piece_bytes * K * world, seed=12)
+    # global piece g = k*world + rank
+    pieces = [torch.from_numpy(whole[(k * world + rank) * piece_bytes:(k * world + rank + 1) * piece_bytes].copy()) for k in range(K)]
+
+    def compress_fn(piece, final, k):
+        s = O.compress(piece.numpy(), O.default_params(final_stream=int(final)))
+        buf = torch.zeros(s.size + 64, dtype=torch.uint8)
+        buf[: s.size] = torch.from_numpy(s)
+        return buf, s.size
+
+    out, total = multigpu.compress_pipelined(compress_fn, pieces)
+    if rank == 0:
+        st, w, back = O.decompress(out[:total].numpy(), whole.size)
+        q.put((st, w, bool(np.array_equal(back, whole)), total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,piece,K", [(2, 2 * 32768, 3), (3, 32768 + 32768, 2), (2, 32768, 1)])
+def test_pipelined_block_cyclic_gloo(world, piece, K):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, piece, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    st, w, same, total = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert st == 0 and w == piece * K * world and same and total > 0
+
+
 @pytest.mark.parametrize("world,n", [(2, 5 * 32768 + 777), (2, 1000), (3, 7 * 32768)])
 def test_shard_concat_gloo(world, n):
     ctx = mp.get_context("spawn")
