@@ -337,6 +337,7 @@ void sfo_default_params(sfo_params* p) {
   p->chain_depth = 0;
   p->cap = 16;
   p->fast_skip = 1;
+  p->far4_dist = 4096;
 }
 
 static inline uint32_t load32(const uint8_t* p) {
@@ -468,6 +469,9 @@ void sfo_match_chunk(const uint8_t* src, uint32_t n, const sfo_params* p, uint16
           if (l > best || (l == best && l && dist < bdist)) { best = l; bdist = dist; }
         }
       }
+      /* a 4-byte match far away costs more bits than four literals (length code + 5-bit
+       * distance code + up to 13 extra bits): drop it */
+      if (p->far4_dist && best == 4 && bdist > p->far4_dist) best = 0;
       if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)bdist; }
     }
   }

@@ -95,6 +95,7 @@ typedef struct sfo_params {
                             a capped match to its full length at chain positions only */
   uint32_t fast_skip;    /* 1: stored fast path -- a chunk whose first SFO_SKIP_SPAN positions are (almost)
                             all literals is not searched any further */
+  uint32_t far4_dist;    /* >0: a match of exactly 4 bytes at a distance beyond this is not used */
 } sfo_params;
 
 #define SFO_SKIP_SPAN 8192u

@@ -21,6 +21,7 @@ constexpr uint32_t kHashBits = 12;
 constexpr uint32_t kRegion = 1024;      // parse region: matches never cross it
 constexpr uint32_t kCap = 16;           // match-time compare width; longer matches are extended by the parse
 constexpr uint32_t kMinMatch = 4;
+constexpr uint32_t kFar4 = 4096;        // a match of exactly 4 bytes beyond this distance is not used
 constexpr uint32_t kSkipSlack = 128;    // stored fast path: first 8 KiB with >= 8192-128 tokens => no further search
 constexpr uint32_t kTokMatch = 0x80000000u;  // token: bit31 match, 16..23 len-3, 0..14 dist-1
 

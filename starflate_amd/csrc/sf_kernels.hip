@@ -264,7 +264,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
           best = lf;
           bd = p - farpos[k];
         }
-        const bool ok = best >= kMinMatch && (p + kMinMatch <= n);
+        // a 4-byte match farther than kFar4 costs more bits than four literals: drop it
+        const bool ok = best >= kMinMatch && (p + kMinMatch <= n) && !(best == 4 && bd > kFar4);
         len4 |= (ok ? best - 3 : 0u) << (8 * k);
         dist[k] = ok ? bd : 0u;
       }

@@ -30,6 +30,7 @@ class Params(C.Structure):
         ("chain_depth", C.c_uint32),
         ("cap", C.c_uint32),
         ("fast_skip", C.c_uint32),
+        ("far4_dist", C.c_uint32),
     ]
 
 
