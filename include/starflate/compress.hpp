@@ -51,7 +51,7 @@ inline auto to_c(const compress_options& o) -> sfh_options {
   sfh_default_options(&c);
   c.strategy = static_cast<std::uint32_t>(o.strategy);
   c.final_stream = o.final_stream ? 1U : 0U;
-  c.lazy = o.lazy ? 1U : 0U;
+  c.lazy = o.lazy ? 3U : 0U;
   c.no_stored_fast_path = o.stored_fast_path ? 0U : 1U;
   return c;
 }

@@ -51,14 +51,14 @@ typedef struct sfh_options {
   uint32_t final_stream; /* 1: last block carries BFINAL (src/decompress.cpp:410-415);
                             0: stream ends byte-aligned and non-final (a GPU shard
                             that is not the last one) */
-  uint32_t lazy;         /* 1: one-step lazy match deferral */
+  uint32_t lazy;         /* 0..3: lazy match deferral, positions of look-ahead (default 3) */
   uint32_t no_stored_fast_path; /* 0 (default): a 32 KiB chunk whose first 8 KiB parse to (almost) only
                             literals is not searched further (high-entropy data -> stored blocks at a
                             quarter of the match work); 1: always search the whole chunk */
   uint32_t reserved[4];  /* must be 0 */
 } sfh_options;
 
-/* fills *o with defaults: AUTO, final_stream=1, lazy=1 */
+/* fills *o with defaults: AUTO, final_stream=1, lazy=3 */
 void sfh_default_options(sfh_options* o);
 
 int sfh_device_count(void);

@@ -328,7 +328,7 @@ void sfo_default_params(sfo_params* p) {
   p->hash_bits = 12;
   p->region_bytes = 1024;
   p->min_match = 4;
-  p->lazy = 1;
+  p->lazy = 3;
   p->final_stream = 1;
   p->strategy = 0;
   p->depth = 1;
@@ -505,7 +505,10 @@ void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
     while (pos < end) {
       uint32_t l = len16[pos];
       int take = l >= MM;
-      if (take && p->lazy && pos + 1 < end && len16[pos + 1] > l) take = 0;
+      /* lazy deferral, up to p->lazy positions ahead: a match is not taken when a position k
+       * ahead (inside the region) offers one longer than l + (k-1) */
+      for (uint32_t k = 1; take && k <= p->lazy; k++)
+        if (pos + k < end && len16[pos + k] > l + (k - 1)) take = 0;
       if (take) {
         if (p->cap && l >= p->cap) { /* capped at match time: extend at the chain position */
           uint32_t maxlen = end - pos < 258 ? end - pos : 258;

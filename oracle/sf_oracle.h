@@ -84,7 +84,7 @@ typedef struct sfo_params {
   uint32_t hash_bits;    /* hash table = 1<<hash_bits entries */
   uint32_t region_bytes; /* parse region; matches never cross a region boundary */
   uint32_t min_match;    /* 3 or 4 */
-  uint32_t lazy;         /* 1: defer a match when the next position has a longer one */
+  uint32_t lazy;         /* 0..3: defer a match when a position k <= lazy ahead has one longer than len+k-1 */
   uint32_t final_stream; /* 1: last chunk carries BFINAL (0 for a non-last GPU shard) */
   uint32_t strategy;     /* 0 auto (smallest of stored/fixed/dynamic), 1 stored, 2 fixed, 3 dynamic */
   uint32_t depth;        /* history levels per hash table (1..3) */

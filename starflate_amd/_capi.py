@@ -83,6 +83,6 @@ def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path
     lib().sfh_default_options(C.byref(o))
     o.strategy = STRATEGY[strategy] if isinstance(strategy, str) else int(strategy)
     o.final_stream = int(bool(final_stream))
-    o.lazy = int(bool(lazy))
+    o.lazy = 3 if lazy is True else int(lazy)
     o.no_stored_fast_path = int(not stored_fast_path)
     return o

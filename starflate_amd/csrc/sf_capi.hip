@@ -76,7 +76,7 @@ uint32_t chunks_of(size_t n) { return n ? (uint32_t)((n + sf::kChunk - 1) / sf::
 
 int check_opt(const sfh_options* o) {
   if (!o) return 0;
-  if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 1 || o->no_stored_fast_path > 1) return -1;
+  if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 3 || o->no_stored_fast_path > 1) return -1;
   for (int k = 0; k < 4; ++k)
     if (o->reserved[k]) return -1;
   return 0;
@@ -118,7 +118,7 @@ void sfh_default_options(sfh_options* o) {
   memset(o, 0, sizeof *o);
   o->strategy = SFH_AUTO;
   o->final_stream = 1;
-  o->lazy = 1;
+  o->lazy = 3;
 }
 
 int sfh_device_count(void) {

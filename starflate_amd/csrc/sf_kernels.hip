@@ -291,19 +291,26 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
       const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;  // valid positions in this quarter
       constexpr uint32_t kIter = kQSegs / K1_WAVES;  // 64-position segments per wave
       const uint32_t sg0 = wave * kIter;
-      uint32_t l3[kIter], n3[kIter];
+      uint32_t l3[kIter], n1[kIter], n2[kIter], n3[kIter];
 #pragma unroll
       for (uint32_t j = 0; j < kIter; ++j) {
         const uint32_t rel = (sg0 + j) * 64 + lane;
         l3[j] = s_len8[rel];
-        n3[j] = s_len8[rel + 1];
+        n1[j] = s_len8[rel + 1];
+        n2[j] = s_len8[rel + 2];
+        n3[j] = s_len8[rel + 3];
       }
 #pragma unroll
       for (uint32_t j = 0; j < kIter; ++j) {
         const uint32_t rel = (sg0 + j) * 64 + lane;
         const uint32_t cur = rel < qn ? l3[j] : 0u;  // beyond n: stale results of an earlier quarter
-        const uint32_t nxt = (rel + 1 < qn && ((rel + 1) & (kRegion - 1)) != 0) ? n3[j] : 0u;
-        const uint64_t T = __ballot(cur != 0 && !(lazy && nxt > cur));
+        // lazy deferral looks up to `lazy` positions ahead, inside the region and the input
+        const uint32_t room = kRegion - (rel & (kRegion - 1));  // positions left in the region, this one included
+        const uint32_t a1 = (lazy >= 1 && rel + 1 < qn && room > 1) ? n1[j] : 0u;
+        const uint32_t a2 = (lazy >= 2 && rel + 2 < qn && room > 2) ? n2[j] : 0u;
+        const uint32_t a3 = (lazy >= 3 && rel + 3 < qn && room > 3) ? n3[j] : 0u;
+        const bool defer = a1 > cur || a2 > cur + 1 || a3 > cur + 2;
+        const uint64_t T = __ballot(cur != 0 && !defer);
         if (lane == 0) s_mm[sg0 + j] = T;
       }
     }

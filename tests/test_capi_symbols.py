@@ -30,7 +30,7 @@ def test_host_side_entry_points_without_gpu():
     lib = _capi.lib()
     o = _capi.Options()
     lib.sfh_default_options(C.byref(o))
-    assert (o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path) == (0, 1, 1, 0) and all(v == 0 for v in o.reserved)
+    assert (o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path) == (0, 1, 3, 0) and all(v == 0 for v in o.reserved)
     assert lib.sfh_compress_bound(0) == 32768 + 4096 + 640
     assert lib.sfh_compress_bound(32768) == 32768 + 4096 + 640
     assert lib.sfh_compress_bound(32769) == 2 * (32768 + 4096 + 640)

@@ -16,7 +16,7 @@ CHUNK = 32768
 
 
 def _params(strategy="auto", final_stream=True, lazy=True):
-    return O.default_params(strategy=_capi.STRATEGY[strategy], final_stream=int(final_stream), lazy=int(lazy))
+    return O.default_params(strategy=_capi.STRATEGY[strategy], final_stream=int(final_stream), lazy=3 if lazy is True else int(lazy))
 
 
 def _inputs(starfleet):
@@ -82,6 +82,18 @@ def test_stage_parity(compressor, starfleet):
         assert np.array_equal(lens[c, :288], np.frombuffer(pl.ll_lens, np.uint8)), f"chunk {c}: ll lens"
         assert np.array_equal(lens[c, 288:320], np.frombuffer(pl.d_lens, np.uint8)), f"chunk {c}: d lens"
         assert plan[c, 0] == pl.btype and plan[c, 1] == pl.out_bytes, f"chunk {c}: plan {plan[c]} vs {pl.btype},{pl.out_bytes}"
+
+
+def test_lazy_levels(compressor, starfleet):
+    """Every look-ahead depth of the lazy rule (0 = greedy .. 3 = default) against the oracle."""
+    for data in (synth.gen_text(3 * CHUNK + 17, seed=6), np.frombuffer(starfleet, np.uint8)):
+        sizes = []
+        for lazy in (0, 1, 2, 3):
+            got = np.frombuffer(compressor.compress(data, lazy=lazy), np.uint8)
+            assert np.array_equal(got, O.compress(data, _params(lazy=lazy))), f"lazy={lazy}"
+            _roundtrip(got, data)
+            sizes.append(got.size)
+        assert sizes[3] < sizes[0]
 
 
 def test_stored_fast_path(compressor):
