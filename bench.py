@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bytes", type=int, default=512 << 20)
     ap.add_argument("--rounds", type=int, default=4, help="N > 1: block-cyclic rounds per rank (gather/compute overlap)")
+    ap.add_argument("--container", default="raw", choices=["raw", "zlib", "gzip"],
+                    help="wrap the stream (RFC 1950 / 1952); the checksum kernels are then inside the timed step")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N > 1 code path (RCCL group, rounds, gather) even with one rank")
     args = ap.parse_args()
@@ -86,7 +88,8 @@ def main():
     pieces = list(data.chunk(K))
     bound = comp.compress_bound(n // K)
     scratch = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(K)]
-    gathered = torch.empty(bound * K * world, dtype=torch.uint8, device=dev) if (multi and rank == 0) else None
+    gathered = torch.empty(bound * K * world + 32, dtype=torch.uint8, device=dev) if (multi and rank == 0) else None
+    wbits = {"raw": -15, "zlib": 15, "gzip": 31}[args.container]
     stage_acc = {}
     result = {}
 
@@ -95,7 +98,8 @@ def main():
         sizes = [0] * K
 
         def compress_fn(piece, final, k):
-            out, nb = comp.compress_tensor(piece, out=scratch[k], final_stream=final)
+            out, nb = comp.compress_tensor(piece, out=scratch[k], final_stream=final,
+                                           container="raw" if multi else args.container)
             sizes[k] = nb
             for name, v in comp.stage_ms().items():
                 ms[name] = ms.get(name, 0.0) + v
@@ -104,7 +108,9 @@ def main():
         if not multi:
             out, total = compress_fn(data, True, 0)
         else:
-            out, total = multigpu.compress_pipelined(compress_fn, pieces, out=gathered)
+            out, total = multigpu.compress_pipelined(
+                compress_fn, pieces, out=gathered, container=args.container,
+                checksum_fn=(lambda piece, k: comp.checksum_tensor(piece, args.container)) if args.container != "raw" else None)
         result["sizes"], result["local_n"] = sizes, sum(sizes)
         result["out"], result["total"] = out, total
         for name, v in ms.items():
@@ -143,7 +149,7 @@ def main():
         for k in range(K):
             host_piece = pieces[k].cpu().numpy().tobytes()
             stream = scratch[k][: result["sizes"][k]].cpu().numpy().tobytes()
-            back = zlib.decompressobj(-15).decompress(stream)  # a non-final piece is still inflatable
+            back = zlib.decompressobj(-15 if multi else wbits).decompress(stream)  # a non-final piece is still inflatable
             ok = ok and back == host_piece
             my_crcs.append(zlib.crc32(host_piece))
             del back, host_piece
@@ -155,7 +161,7 @@ def main():
             crcs = [torch.zeros(K, dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(crcs, crc)
             if rank == 0:  # the concatenation is ONE valid stream of all pieces in the order g = k*N + rank
-                whole = zlib.decompress(result["out"][:total_out].cpu().numpy().tobytes(), -15)
+                whole = zlib.decompress(result["out"][:total_out].cpu().numpy().tobytes(), wbits)
                 pb = n // K
                 ok = ok and len(whole) == total_in and all(
                     zlib.crc32(whole[(k * world + r) * pb:(k * world + r + 1) * pb]) == int(crcs[r][k].item())
@@ -229,7 +235,7 @@ def main():
         "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": wl, "block_bytes": 32768, "strategy": "auto",
+        "config": {"workload": wl, "block_bytes": 32768, "strategy": "auto", "container": args.container,
                    "parallelism": f"shard{world}" + (f" block-cyclic x{K}, gather overlapped" if multi else "")},
         "ratio": round(ratio, 4), "ratio_zlib6": round(ratio_zlib6, 4),
         "ratio_vs_zlib6": round(ratio_ours_sample / ratio_zlib6, 4),

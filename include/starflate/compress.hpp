@@ -1,10 +1,12 @@
-// starflate::compress -- the sibling of decompress(): raw RFC 1951 out of the MI355X kernels.
+// starflate::compress -- the sibling of decompress(): raw RFC 1951 (optionally zlib / gzip wrapped) out of
+// the MI355X kernels.
 // Thin C++23 wrapper over the C-ABI (include/starflate_hip.h); link with libstarflate_hip.so.
 // Same conventions as the reference's one public function
 // (/root/reference/src/decompress.hpp:63-71): non-owning spans, caller-owned buffers, no
 // exceptions, a uint8_t status enum; the size comes back through expected<>.
 #pragma once
 #include "starflate/compat/expected.hpp"
+#include "starflate/container.hpp"
 #include "starflate_hip.h"
 
 #include <cstddef>
@@ -30,6 +32,7 @@ struct compress_options {
   bool final_stream{true};  // false: byte-aligned, non-final stream (a shard that is not the last)
   bool lazy{true};
   bool stored_fast_path{true};  // skip the search of a chunk whose first 8 KiB are (almost) all literals
+  Container container{Container::Raw};  // Zlib / Gzip: wrapper + GPU-computed Adler-32 / CRC-32 (needs final_stream)
   int device{0};
 };
 
@@ -53,6 +56,7 @@ inline auto to_c(const compress_options& o) -> sfh_options {
   c.final_stream = o.final_stream ? 1U : 0U;
   c.lazy = o.lazy ? 3U : 0U;
   c.no_stored_fast_path = o.stored_fast_path ? 0U : 1U;
+  c.container = static_cast<std::uint32_t>(o.container);
   return c;
 }
 }  // namespace detail

@@ -7,9 +7,10 @@
  *     starflate::decompress(span<const byte> src, span<byte> dst) -> DecompressStatus
  *     (/root/reference/src/decompress.hpp:63-71):
  * caller-owned buffers in, callee never allocates output, no exceptions, a small
- * integer status out.  sfh_compress* produce raw RFC 1951 streams (no zlib/gzip
- * wrapper, as /root/reference/tools/deflate_compress.py:8-13 does for the
- * reference's fixtures) that the reference's decompress() inverts.
+ * integer status out.  By default sfh_compress* produce raw RFC 1951 streams (no
+ * zlib/gzip wrapper, as /root/reference/tools/deflate_compress.py:8-13 does for the
+ * reference's fixtures) that the reference's decompress() inverts; the wrappers
+ * that tool strips (RFC 1950 / RFC 1952) are available through sfh_options.container.
  * The C++23 wrapper starflate::compress() (include/starflate/compress.hpp) is the
  * only intended caller besides tests and bench.py (ctypes).
  *
@@ -46,6 +47,13 @@ enum sfh_strategy {
   SFH_DYNAMIC = 3 /* BTYPE 10 only  (src/decompress.cpp:447-458) */
 };
 
+/* stream wrapper around the raw DEFLATE data (what tools/deflate_compress.py:8-13 removes) */
+enum sfh_container {
+  SFH_RAW = 0,  /* RFC 1951 only: what the reference's decompress() reads */
+  SFH_ZLIB = 1, /* RFC 1950: 78 9C, stream, Adler-32 big-endian */
+  SFH_GZIP = 2  /* RFC 1952: 1F 8B 08 00, MTIME 0, XFL 0, OS 255, stream, CRC-32, ISIZE (both little-endian) */
+};
+
 typedef struct sfh_options {
   uint32_t strategy;     /* enum sfh_strategy */
   uint32_t final_stream; /* 1: last block carries BFINAL (src/decompress.cpp:410-415);
@@ -55,7 +63,9 @@ typedef struct sfh_options {
   uint32_t no_stored_fast_path; /* 0 (default): a 32 KiB chunk whose first 8 KiB parse to (almost) only
                             literals is not searched further (high-entropy data -> stored blocks at a
                             quarter of the match work); 1: always search the whole chunk */
-  uint32_t reserved[4];  /* must be 0 */
+  uint32_t container;    /* enum sfh_container; SFH_ZLIB / SFH_GZIP need final_stream = 1.  The checksum is
+                            computed on the GPU from the same device buffer (two more launches) */
+  uint32_t reserved[3];  /* must be 0 */
 } sfh_options;
 
 /* fills *o with defaults: AUTO, final_stream=1, lazy=3 */
@@ -66,7 +76,7 @@ int sfh_create(sfh_ctx** out, int device);
 void sfh_destroy(sfh_ctx* ctx);
 const char* sfh_last_error(const sfh_ctx* ctx);
 
-/* worst-case output bytes for n input bytes (any strategy) */
+/* worst-case output bytes for n input bytes (any strategy, any container) */
 size_t sfh_compress_bound(size_t n);
 
 /* Host buffers: H2D copy, compress, D2H copy, synchronous.  *out_n = stream bytes. */
@@ -85,7 +95,17 @@ int sfh_compress_device_async(sfh_ctx* ctx, const void* d_src, size_t n, void* d
 
 /* ---- measurement hooks (bench.py, tests) ---- */
 
-#define SFH_NSTAGES 4 /* 0 lz77 match+parse, 1 code plan, 2 offset scan, 3 emit */
+/* ---- container checksums ---- */
+
+/* Checksum of n device bytes (d_src 16-byte aligned): kind = SFH_ZLIB -> Adler-32, SFH_GZIP -> CRC-32,
+ * bit-exact with zlib's adler32()/crc32().  Synchronises `stream` (NULL = the ctx's own). */
+int sfh_checksum_device(sfh_ctx* ctx, const void* d_src, size_t n, uint32_t kind, uint32_t* out, void* stream);
+/* Checksum of A||B from the checksums of A and B and the length of B (host arithmetic; a multi-GPU job
+ * combines its shards' checksums with these and writes one wrapper around the concatenated raw streams). */
+uint32_t sfh_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+uint32_t sfh_adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b);
+
+#define SFH_NSTAGES 5 /* 0 lz77 match+parse, 1 code plan, 2 offset scan, 3 emit, 4 checksum + wrapper (container modes) */
 
 /* on != 0: bracket every kernel launch with HIP events on the launch stream */
 void sfh_set_profiling(sfh_ctx* ctx, int on);

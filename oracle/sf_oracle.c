@@ -783,11 +783,84 @@ static void emit_chunk(const uint8_t* data, uint32_t n, const uint32_t* tokens,
 size_t sfo_compress_bound(size_t n, const sfo_params* p) {
   size_t cb = p->chunk_bytes;
   size_t nchunks = n ? (n + cb - 1) / cb : 1;
-  return nchunks * (cb + cb / 8 + 640);
+  return nchunks * (cb + cb / 8 + 640); /* the per-chunk slack also covers the <= 18 wrapper bytes */
+}
+
+/* RFC 1952 section 8: CRC-32, reflected polynomial 0xEDB88320, one bit at a time */
+uint32_t sfo_crc32(const uint8_t* data, size_t n) {
+  uint32_t c = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; i++) {
+    c ^= data[i];
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+  }
+  return ~c;
+}
+
+/* RFC 1950 section 8.2: s1 = 1 + sum of bytes, s2 = sum of the s1 values, both mod 65521 */
+uint32_t sfo_adler32(const uint8_t* data, size_t n) {
+  uint32_t s1 = 1, s2 = 0;
+  for (size_t i = 0; i < n; i++) {
+    s1 = (s1 + data[i]) % 65521u;
+    s2 = (s2 + s1) % 65521u;
+  }
+  return (s2 << 16) | s1;
+}
+
+/* crc(A||B): append len_b zero bytes to A's register (bit-serially squared operator, here simply
+ * by feeding zero bits through the shift register in log steps) and xor crc(B).
+ * Uses: crc(A||B) = crc(A||0^len) ^ crc(0^len) ^ crc(B)  (linearity over GF(2)). */
+static uint32_t gf2_mul(uint32_t a, uint32_t b) { /* a(x)*b(x) mod P, reflected bit order, x^0 = bit 31 */
+  uint32_t prod = 0;
+  for (int k = 31; k >= 0; k--) {
+    if ((a >> k) & 1) prod ^= b;
+    b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+  }
+  return prod;
+}
+
+uint32_t sfo_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+  /* x^(8*len_b) by square and multiply; x^8 is bit 23 in this representation */
+  uint32_t op = 0x80000000u, base = 0x00800000u;
+  for (uint64_t e = len_b; e; e >>= 1) {
+    if (e & 1) op = gf2_mul(op, base);
+    base = gf2_mul(base, base);
+  }
+  return gf2_mul(op, crc_a) ^ crc_b;
+}
+
+uint32_t sfo_adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b) {
+  const uint64_t M = 65521u;
+  uint64_t a1 = adler_a & 0xFFFF, b1 = adler_a >> 16, a2 = adler_b & 0xFFFF, b2 = adler_b >> 16;
+  uint64_t a = (a1 + a2 + M - 1) % M;
+  uint64_t b = (b1 + b2 + (len_b % M) * ((a1 + M - 1) % M)) % M;
+  return (uint32_t)((b << 16) | a);
 }
 
 int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,
                  const sfo_params* p) {
+  if (p->container) {
+    if (p->container > 2 || !p->final_stream) return -1;
+    static const uint8_t zhdr[2] = {0x78, 0x9C};
+    static const uint8_t ghdr[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, 0, 0xFF};
+    const size_t h = p->container == 1 ? 2 : 10, t = p->container == 1 ? 4 : 8;
+    if (cap < h + t) return -2;
+    sfo_params raw = *p;
+    raw.container = 0;
+    size_t body = 0;
+    int rc = sfo_compress(src, n, dst + h, cap - h - t, &body, &raw);
+    if (rc) return rc;
+    memcpy(dst, p->container == 1 ? zhdr : ghdr, h);
+    uint8_t* tr = dst + h + body;
+    if (p->container == 1) {
+      uint32_t a = sfo_adler32(src, n);
+      tr[0] = (uint8_t)(a >> 24); tr[1] = (uint8_t)(a >> 16); tr[2] = (uint8_t)(a >> 8); tr[3] = (uint8_t)a;
+    } else {
+      uint32_t c = sfo_crc32(src, n), isz = (uint32_t)n;
+      for (int k = 0; k < 4; k++) { tr[k] = (uint8_t)(c >> (8 * k)); tr[4 + k] = (uint8_t)(isz >> (8 * k)); }
+    }
+    *out_len = h + body + t;
+    return 0;
+  }
   if (p->chunk_bytes == 0 || p->chunk_bytes > 32768 || p->region_bytes == 0 ||
       p->step == 0 || p->step > 4096 || p->hash_bits < 8 || p->hash_bits > 16 ||
       (p->min_match != 3 && p->min_match != 4))

@@ -96,6 +96,8 @@ typedef struct sfo_params {
   uint32_t fast_skip;    /* 1: stored fast path -- a chunk whose first SFO_SKIP_SPAN positions are (almost)
                             all literals is not searched any further */
   uint32_t far4_dist;    /* >0: a match of exactly 4 bytes at a distance beyond this is not used */
+  uint32_t container;    /* 0 raw RFC 1951; 1 zlib (RFC 1950: 78 9C .. Adler-32 BE); 2 gzip (RFC 1952:
+                            1F 8B 08 00, MTIME 0, XFL 0, OS 255 .. CRC-32 LE, ISIZE LE); needs final_stream */
 } sfo_params;
 
 #define SFO_SKIP_SPAN 8192u
@@ -107,6 +109,13 @@ void sfo_default_params(sfo_params* p);
 #define SFO_TOK_MATCH 0x80000000u
 
 size_t sfo_compress_bound(size_t n, const sfo_params* p);
+
+/* container checksums, bit/byte-serial by definition (RFC 1952 section 8 / RFC 1950 section 8.2) */
+uint32_t sfo_crc32(const uint8_t* data, size_t n);
+uint32_t sfo_adler32(const uint8_t* data, size_t n);
+/* checksum of A||B from the checksums of A and B and len(B) */
+uint32_t sfo_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+uint32_t sfo_adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b);
 
 /* whole pipeline; returns 0 or negative error; *out_len = bytes written */
 int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,

@@ -8,21 +8,23 @@ import os
 
 from . import build as _build
 
-NSTAGES = 4
+NSTAGES = 5
 STRATEGY = {"auto": 0, "stored": 1, "fixed": 2, "dynamic": 3}
+CONTAINER = {"raw": 0, "zlib": 1, "gzip": 2}
 DBG_NTOK, DBG_TOKENS, DBG_HIST, DBG_PLAN, DBG_LENS, DBG_OFFSETS, DBG_STAMPS = range(7)
 
 # every symbol include/starflate_hip.h declares
 EXPORTS = [
     "sfh_default_options", "sfh_device_count", "sfh_create", "sfh_destroy", "sfh_last_error",
     "sfh_compress_bound", "sfh_compress", "sfh_compress_device", "sfh_compress_device_async",
+    "sfh_checksum_device", "sfh_crc32_combine", "sfh_adler32_combine",
     "sfh_set_profiling", "sfh_last_stage_ms", "sfh_stage_name", "sfh_debug_read",
 ]
 
 
 class Options(C.Structure):
     _fields_ = [("strategy", C.c_uint32), ("final_stream", C.c_uint32), ("lazy", C.c_uint32),
-                ("no_stored_fast_path", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+                ("no_stored_fast_path", C.c_uint32), ("container", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 _LIB = None
@@ -66,6 +68,12 @@ def lib():
     L.sfh_compress_device.restype = C.c_int
     L.sfh_compress_device_async.argtypes = [vp, vp, sz, vp, sz, vp, C.POINTER(Options), vp]
     L.sfh_compress_device_async.restype = C.c_int
+    L.sfh_checksum_device.argtypes = [vp, vp, sz, C.c_uint32, C.POINTER(C.c_uint32), vp]
+    L.sfh_checksum_device.restype = C.c_int
+    L.sfh_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+    L.sfh_crc32_combine.restype = C.c_uint32
+    L.sfh_adler32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+    L.sfh_adler32_combine.restype = C.c_uint32
     L.sfh_set_profiling.argtypes = [vp, C.c_int]
     L.sfh_set_profiling.restype = None
     L.sfh_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float * NSTAGES)]
@@ -78,11 +86,12 @@ def lib():
     return L
 
 
-def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True):
+def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw"):
     o = Options()
     lib().sfh_default_options(C.byref(o))
     o.strategy = STRATEGY[strategy] if isinstance(strategy, str) else int(strategy)
     o.final_stream = int(bool(final_stream))
     o.lazy = 3 if lazy is True else int(lazy)
     o.no_stored_fast_path = int(not stored_fast_path)
+    o.container = CONTAINER[container] if isinstance(container, str) else int(container)
     return o

@@ -3,7 +3,9 @@ compression itself happens only in libstarflate_hip.so (HIP kernels, gfx950).
 
 `compress()` is the sibling of the reference's
 `starflate::decompress(src, dst) -> status` (/root/reference/src/decompress.hpp:63-71):
-raw RFC 1951 out, caller-owned buffers, integer status turned into an exception.
+raw RFC 1951 out (or, with container="zlib"/"gzip", the RFC 1950 / RFC 1952 wrapper the
+reference's fixture tool strips, tools/deflate_compress.py:8-13), caller-owned buffers,
+integer status turned into an exception.
 """
 import ctypes as C
 
@@ -51,19 +53,19 @@ class Compressor:
         return _capi.lib().sfh_compress_bound(int(n))
 
     # ---- host buffers (PCIe inclusive) ----
-    def compress(self, data, strategy="auto", final_stream=True, lazy=True, stored_fast_path=True):
+    def compress(self, data, strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw"):
         src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         cap = self.compress_bound(src.size)
         dst = np.empty(cap, dtype=np.uint8)
         out_n = C.c_size_t(0)
-        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path)
+        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container)
         self._check(self._lib.sfh_compress(self._h, src.ctypes.data if src.size else None, src.size,
                                            dst.ctypes.data, cap, C.byref(out_n), C.byref(opt)))
         return dst[: out_n.value].tobytes()
 
     # ---- device buffers (torch uint8 CUDA tensors) ----
     def compress_tensor(self, src, out=None, strategy="auto", final_stream=True, lazy=True, stream=None,
-                        stored_fast_path=True):
+                        stored_fast_path=True, container="raw"):
         """src: 1-D uint8 tensor on this device. Returns (out tensor, stream byte count)."""
         import torch
 
@@ -74,13 +76,14 @@ class Compressor:
             out = torch.empty(cap, dtype=torch.uint8, device=src.device)
         self._check_tensor(out)
         out_n = C.c_size_t(0)
-        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path)
+        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container)
         s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
         self._check(self._lib.sfh_compress_device(self._h, src.data_ptr() if n else None, n, out.data_ptr(),
                                                   out.numel(), C.byref(out_n), C.byref(opt), C.c_void_p(s)))
         return out, out_n.value
 
-    def compress_tensor_async(self, src, out, size_out, strategy="auto", final_stream=True, lazy=True, stream=None):
+    def compress_tensor_async(self, src, out, size_out, strategy="auto", final_stream=True, lazy=True, stream=None,
+                              container="raw"):
         """Enqueue only. size_out: 1-element int64 CUDA tensor receiving the stream size."""
         import torch
 
@@ -88,11 +91,23 @@ class Compressor:
         self._check_tensor(out)
         if size_out.dtype not in (torch.int64, torch.uint64) or not size_out.is_cuda:
             raise ValueError("size_out must be a 1-element int64 CUDA tensor")
-        opt = _capi.make_options(strategy, final_stream, lazy)
+        opt = _capi.make_options(strategy, final_stream, lazy, container=container)
         s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
         n = src.numel()
         self._check(self._lib.sfh_compress_device_async(self._h, src.data_ptr() if n else None, n, out.data_ptr(),
                                                         out.numel(), size_out.data_ptr(), C.byref(opt), C.c_void_p(s)))
+
+    def checksum_tensor(self, src, kind, stream=None):
+        """kind "zlib" -> Adler-32, "gzip" -> CRC-32 of a 1-D uint8 tensor on this device (GPU kernels)."""
+        import torch
+
+        self._check_tensor(src)
+        out = C.c_uint32(0)
+        s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
+        n = src.numel()
+        self._check(self._lib.sfh_checksum_device(self._h, src.data_ptr() if n else None, n, _capi.CONTAINER[kind],
+                                                  C.byref(out), C.c_void_p(s)))
+        return out.value
 
     def _check_tensor(self, t):
         import torch
@@ -125,6 +140,22 @@ class Compressor:
         a = np.empty(shape, dtype=dt)
         self._check(self._lib.sfh_debug_read(self._h, what, a.ctypes.data, a.nbytes))
         return a
+
+
+def checksum_combine(kind, a, b, len_b):
+    """Checksum of A||B from checksum(A), checksum(B), len(B); kind "zlib" (Adler-32) or "gzip" (CRC-32)."""
+    L = _capi.lib()
+    return (L.sfh_adler32_combine if kind == "zlib" else L.sfh_crc32_combine)(a, b, int(len_b))
+
+
+def wrapper_bytes(kind, checksum, n):
+    """(header, trailer) of the zlib / gzip wrapper exactly as the kernels write them (for a multi-GPU job,
+    whose rank 0 wraps the concatenated raw shard streams with the combined checksum)."""
+    if kind == "zlib":
+        return b"\x78\x9c", int(checksum).to_bytes(4, "big")
+    if kind == "gzip":
+        return b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff", int(checksum).to_bytes(4, "little") + (n & 0xFFFFFFFF).to_bytes(4, "little")
+    return b"", b""
 
 
 _DEFAULT = {}

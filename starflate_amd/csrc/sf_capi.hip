@@ -13,8 +13,10 @@ struct sfh_ctx {
   hipStream_t stream = nullptr;  // used when the caller passes no stream
   sf::Workspace ws{};
   uint32_t cap_chunks = 0;       // chunks the workspace can hold
+  uint32_t sums_cap = 0;         // chunks ws.sums can hold
   uint32_t last_chunks = 0;
   uint64_t* d_total = nullptr;   // own result slot for the synchronous entry points
+  uint32_t* d_value = nullptr;   // result slot of sfh_checksum_device
   uint8_t* d_in = nullptr;       // staging for the host-buffer entry point
   uint8_t* d_out = nullptr;
   size_t d_in_cap = 0, d_out_cap = 0;
@@ -46,8 +48,22 @@ void free_ws(sfh_ctx* c) {
   (void)hipFree(c->ws.codes);
   (void)hipFree(c->ws.offsets);
   (void)hipFree(c->ws.stamps);
+  uint32_t* keep = c->ws.sums;  // sized on its own (ensure_sums)
   c->ws = sf::Workspace{};
+  c->ws.sums = keep;
   c->cap_chunks = 0;
+}
+
+// checksum partials: 4 bytes per chunk, needed without the rest of the workspace by sfh_checksum_device
+int ensure_sums(sfh_ctx* ctx, uint32_t nchunks) {
+  if (nchunks <= ctx->sums_cap) return SFH_OK;
+  (void)hipFree(ctx->ws.sums);
+  ctx->ws.sums = nullptr;
+  ctx->sums_cap = 0;
+  hipError_t e = hipMalloc(&ctx->ws.sums, (size_t)nchunks * sizeof(uint32_t));
+  if (e != hipSuccess) return fail(ctx, SFH_E_NOMEM, "checksum scratch hipMalloc", e);
+  ctx->sums_cap = nchunks;
+  return SFH_OK;
 }
 
 int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
@@ -77,7 +93,8 @@ uint32_t chunks_of(size_t n) { return n ? (uint32_t)((n + sf::kChunk - 1) / sf::
 int check_opt(const sfh_options* o) {
   if (!o) return 0;
   if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 3 || o->no_stored_fast_path > 1) return -1;
-  for (int k = 0; k < 4; ++k)
+  if (o->container > SFH_GZIP || (o->container && !o->final_stream)) return -1;  // a non-final shard has no trailer
+  for (int k = 0; k < 3; ++k)
     if (o->reserved[k]) return -1;
   return 0;
 }
@@ -93,6 +110,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   const uint32_t nchunks = chunks_of(n);
   int rc = ensure_ws(ctx, nchunks);
+  if (!rc && o.container) rc = ensure_sums(ctx, nchunks);
   if (rc) return rc;
   ctx->last_chunks = nchunks;
   const sf::Options ko{o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path ? 0u : 1u};
@@ -102,10 +120,15 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   if (prof) SF_HIP(hipEventRecord(ctx->ev[1], s), "event");
   SF_HIP(sf::launch_plan(n, nchunks, ctx->ws, ko, s), "launch k_plan");
   if (prof) SF_HIP(hipEventRecord(ctx->ev[2], s), "event");
-  SF_HIP(sf::launch_scan(nchunks, ctx->ws, d_out_n, s), "launch k_scan");
+  SF_HIP(sf::launch_scan(nchunks, ctx->ws, sf::wrapper_header_bytes(o.container), d_out_n, s), "launch k_scan");
   if (prof) SF_HIP(hipEventRecord(ctx->ev[3], s), "event");
   SF_HIP(sf::launch_emit((const uint8_t*)d_src, n, nchunks, ctx->ws, (uint8_t*)d_dst, s), "launch k_emit");
   if (prof) SF_HIP(hipEventRecord(ctx->ev[4], s), "event");
+  if (o.container) {
+    SF_HIP(sf::launch_checksum((const uint8_t*)d_src, n, nchunks, o.container, ctx->ws.sums, s), "launch k_checksum");
+    SF_HIP(sf::launch_wrap(ctx->ws.sums, nchunks, n, o.container, (uint8_t*)d_dst, d_out_n, nullptr, s), "launch k_wrap");
+  }
+  if (prof) SF_HIP(hipEventRecord(ctx->ev[5], s), "event");
   ctx->ev_valid = prof;
   return SFH_OK;
 }
@@ -141,7 +164,8 @@ int sfh_create(sfh_ctx** out, int device) {
   }
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-      (e = hipMalloc(&ctx->d_total, sizeof(uint64_t))) != hipSuccess || (e = sf::init_kernels()) != hipSuccess) {
+      (e = hipMalloc(&ctx->d_total, sizeof(uint64_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->d_value, sizeof(uint32_t))) != hipSuccess || (e = sf::init_kernels()) != hipSuccess) {
     sfh_destroy(ctx);
     return SFH_E_HIP;
   }
@@ -159,7 +183,9 @@ void sfh_destroy(sfh_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_ws(ctx);
+  (void)hipFree(ctx->ws.sums);
   (void)hipFree(ctx->d_total);
+  (void)hipFree(ctx->d_value);
   (void)hipFree(ctx->d_in);
   (void)hipFree(ctx->d_out);
   for (int k = 0; k <= SFH_NSTAGES; ++k)
@@ -227,6 +253,27 @@ int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap,
   return SFH_OK;
 }
 
+int sfh_checksum_device(sfh_ctx* ctx, const void* d_src, size_t n, uint32_t kind, uint32_t* out, void* stream) {
+  if (!ctx || (!d_src && n) || !out || (kind != SFH_ZLIB && kind != SFH_GZIP)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
+  if ((uintptr_t)d_src & 15) return fail(ctx, SFH_E_INVALID_ARG, "device pointer alignment (src 16)", hipSuccess);
+  if (n > ((size_t)1 << 44)) return fail(ctx, SFH_E_INVALID_ARG, "input too large", hipSuccess);
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  const uint32_t nchunks = chunks_of(n);
+  int rc = ensure_sums(ctx, nchunks);
+  if (rc) return rc;
+  SF_HIP(sf::launch_checksum((const uint8_t*)d_src, n, nchunks, kind, ctx->ws.sums, s), "launch k_checksum");
+  SF_HIP(sf::launch_wrap(ctx->ws.sums, nchunks, n, kind, nullptr, nullptr, ctx->d_value, s), "launch k_wrap");
+  SF_HIP(hipMemcpyAsync(out, ctx->d_value, sizeof *out, hipMemcpyDeviceToHost, s), "copy checksum");
+  SF_HIP(hipStreamSynchronize(s), "stream sync");
+  return SFH_OK;
+}
+
+uint32_t sfh_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) { return sf::crc32_combine(crc_a, crc_b, len_b); }
+uint32_t sfh_adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b) {
+  return sf::adler32_combine(adler_a, adler_b, len_b);
+}
+
 void sfh_set_profiling(sfh_ctx* ctx, int on) {
   if (ctx) ctx->profiling = on;
 }
@@ -238,7 +285,7 @@ int sfh_last_stage_ms(sfh_ctx* ctx, float ms[SFH_NSTAGES]) {
 }
 
 const char* sfh_stage_name(int stage) {
-  static const char* names[SFH_NSTAGES] = {"k_lz77", "k_plan", "k_scan", "k_emit"};
+  static const char* names[SFH_NSTAGES] = {"k_lz77", "k_plan", "k_scan", "k_emit", "k_checksum"};
   return (stage >= 0 && stage < SFH_NSTAGES) ? names[stage] : "";
 }
 

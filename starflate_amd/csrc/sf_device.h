@@ -9,6 +9,9 @@
 //   K3 k_scan   exclusive scan of chunk byte sizes -> output offsets, total
 //   K4 k_emit   one workgroup per chunk: bit-pack tokens into LDS, flush to the
 //               chunk's final byte offset (or copy raw bytes for a stored block)
+// With a zlib / gzip container two more launches (sf_checksum.hip):
+//   K5 k_checksum  one workgroup per chunk: Adler-32 / CRC-32 partial of the chunk's input bytes
+//   K6 k_wrap      one workgroup: fold the partials, write wrapper header + trailer
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,6 +27,10 @@ constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kFar4 = 4096;        // a match of exactly 4 bytes beyond this distance is not used
 constexpr uint32_t kSkipSlack = 128;    // stored fast path: first 8 KiB with >= 8192-128 tokens => no further search
 constexpr uint32_t kTokMatch = 0x80000000u;  // token: bit31 match, 16..23 len-3, 0..14 dist-1
+
+constexpr uint32_t kChecksumAdler32 = 1;  // = SFH_ZLIB
+constexpr uint32_t kChecksumCrc32 = 2;    // = SFH_GZIP
+constexpr uint32_t kCrcPoly = 0xEDB88320u;  // RFC 1952 section 8, reflected
 
 constexpr uint32_t kHistStride = 320;   // ll[0..285] at 0, d[0..29] at 288
 constexpr uint32_t kHistD = 288;
@@ -51,6 +58,7 @@ struct Workspace {
   ChunkCodes* codes;  // [nchunks]
   uint64_t* offsets;  // [nchunks]
   uint64_t* stamps;   // [nchunks][8], diagnostic build only (SFH_K1_STAMPS=1), else null
+  uint32_t* sums;     // [nchunks] checksum partials (container modes / sfh_checksum_device)
 };
 
 struct Options {
@@ -64,9 +72,20 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
                        const Options& opt, hipStream_t s);
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,
                        hipStream_t s);
-hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t* d_total, hipStream_t s);
+// offsets start at `base` (bytes of wrapper header in front of the stream); *d_total = base + stream bytes
+hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, uint64_t* d_total, hipStream_t s);
 hipError_t launch_emit(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
                        uint8_t* dst, hipStream_t s);
 hipError_t init_kernels();
+
+// sf_checksum.hip
+uint32_t wrapper_header_bytes(uint32_t kind);
+hipError_t launch_checksum(const uint8_t* src, uint64_t n, uint32_t nchunks, uint32_t kind, uint32_t* sums,
+                           hipStream_t s);
+// dst != null: header at dst[0..), trailer at dst[*d_total..), *d_total += trailer bytes; d_value (nullable) = checksum
+hipError_t launch_wrap(const uint32_t* sums, uint32_t nchunks, uint64_t n, uint32_t kind, uint8_t* dst,
+                       uint64_t* d_total, uint32_t* d_value, hipStream_t s);
+uint32_t crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);        // host arithmetic
+uint32_t adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b);  // host arithmetic
 
 }  // namespace sf

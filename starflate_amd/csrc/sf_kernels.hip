@@ -933,7 +933,7 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
 // ---------------------------------------------------------------------------
 constexpr uint32_t K3_THREADS = 1024;
 __global__ __launch_bounds__(K3_THREADS) void k_scan(uint32_t nchunks, const ChunkPlan* __restrict__ plan,
-                                                     uint64_t* __restrict__ offsets,
+                                                     uint64_t base, uint64_t* __restrict__ offsets,
                                                      uint64_t* __restrict__ total) {
   __shared__ uint64_t s_part[K3_THREADS];
   const uint32_t t = threadIdx.x;
@@ -949,12 +949,12 @@ __global__ __launch_bounds__(K3_THREADS) void k_scan(uint32_t nchunks, const Chu
     s_part[t] += u;
     __syncthreads();
   }
-  uint64_t run = s_part[t] - sum;
+  uint64_t run = base + s_part[t] - sum;
   for (uint32_t c = b; c < e; ++c) {
     offsets[c] = run;
     run += plan[c].out_bytes;
   }
-  if (t == K3_THREADS - 1) *total = s_part[t];
+  if (t == K3_THREADS - 1) *total = base + s_part[t];
 }
 
 // ---------------------------------------------------------------------------
@@ -1185,8 +1185,8 @@ hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const 
                      opt.strategy, opt.final_stream, ws.stamps);
   return hipGetLastError();
 }
-hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t* d_total, hipStream_t s) {
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(K3_THREADS), 0, s, nchunks, ws.plan, ws.offsets, d_total);
+hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, uint64_t* d_total, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(K3_THREADS), 0, s, nchunks, ws.plan, base, ws.offsets, d_total);
   return hipGetLastError();
 }
 hipError_t launch_emit(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,

@@ -50,7 +50,7 @@ def concat_streams(local, local_n, group=None, out=None):
     return None, total
 
 
-def compress_pipelined(compress_fn, pieces, group=None, out=None):
+def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw", checksum_fn=None):
     """Block-cyclic sharding with overlap: the global input is K*world pieces in the order
     g = k*world + rank; this rank holds `pieces[k]` for rounds k = 0..K-1.  Round k's streams are
     gathered straight to their final offsets (they only depend on the sizes of rounds <= k, known
@@ -60,19 +60,36 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None):
     compress_fn(piece, final, k) -> (uint8 tensor, nbytes): this rank's stream for round k, in a
     buffer that stays untouched until this function returns (use one buffer per round);
     `final` is True only for the globally last piece.  Returns (out, total) on rank 0 and
-    (None, total) elsewhere; `out` (rank 0) must hold the whole concatenation if given."""
+    (None, total) elsewhere; `out` (rank 0) must hold the whole concatenation if given.
+
+    container "zlib" / "gzip": the raw piece streams are wrapped once, on rank 0.  checksum_fn(piece, k)
+    -> this rank's Adler-32 / CRC-32 of pieces[k] (Compressor.checksum_tensor on the GPU); the values ride
+    the same small all_gather as the sizes and are folded in the global piece order with the combine
+    rules of the C-ABI (sfh_adler32_combine / sfh_crc32_combine) -- no extra collective."""
+    from .compressor import checksum_combine, wrapper_bytes
+
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     K = len(pieces)
+    wrapped = container != "raw"
+    if wrapped and checksum_fn is None:
+        raise ValueError("compress_pipelined: a container needs checksum_fn")
+    header = wrapper_bytes(container, 0, 0)[0] if wrapped else b""
     works, keep, parts = [], [], []
-    base = 0
+    base = len(header)
+    running, n_in = None, 0
     for k, piece in enumerate(pieces):
         local, n = compress_fn(piece, k == K - 1 and rank == world - 1, k)
         dev = local.device
-        mine = torch.tensor([int(n)], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, mine, group=group)
-        sizes = [int(x.item()) for x in sizes]
+        cs = int(checksum_fn(piece, k)) if wrapped else 0
+        mine = torch.tensor([int(n), cs, int(piece.numel())], dtype=torch.int64, device=dev)
+        rows = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(rows, mine, group=group)
+        rows = [[int(v) for v in x.tolist()] for x in rows]
+        sizes = [r[0] for r in rows]
+        for _, c, ln in rows if wrapped else []:  # global order g = k*world + r
+            running = c if running is None else checksum_combine(container, running, c, ln)
+            n_in += ln
         if rank == 0:
             if out is not None:
                 if out.numel() < base + sum(sizes):
@@ -96,9 +113,20 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None):
     for w in works:
         w.wait()
     del keep
+    trailer = wrapper_bytes(container, running, n_in)[1] if wrapped else b""
+    total = base + len(trailer)
     if rank != 0:
-        return None, base
-    return (out[:base] if out is not None else torch.cat(parts)), base
+        return None, total
+    if not wrapped:
+        return (out[:base] if out is not None else torch.cat(parts)), base
+    as_t = lambda b: torch.tensor(list(b), dtype=torch.uint8, device=dev)  # noqa: E731
+    if out is None:
+        return torch.cat([as_t(header)] + parts + [as_t(trailer)]), total
+    if out.numel() < total:
+        raise ValueError("compress_pipelined: `out` is smaller than the wrapped stream")
+    out[: len(header)] = as_t(header)
+    out[base:total] = as_t(trailer)
+    return out[:total], total
 
 
 def compress_sharded(compressor, shard, group=None, out=None, scratch=None, **kw):

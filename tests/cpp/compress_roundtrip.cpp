@@ -45,6 +45,31 @@ auto main(int argc, char** argv) -> int {
       }
     }
   }
+  // zlib / gzip wrappers: GPU-computed checksum verified by the host-side wrapper-aware decompress()
+  for (const auto kind : {Container::Zlib, Container::Gzip}) {
+    for (const auto& in : inputs) {
+      std::vector<std::byte> comp(compress_bound(in.size()));
+      compress_options opt;
+      opt.container = kind;
+      const auto n = gpu.compress(in, comp, opt);
+      if (!n) { std::printf("wrapped compress failed: %d\n", static_cast<int>(n.error())); ++fail; continue; }
+      comp.resize(*n);
+      std::vector<std::byte> back(in.size());
+      const auto st = decompress(comp, back, kind);
+      if (st != DecompressStatus::Success || back != in) {
+        std::printf("wrapped round trip failed: kind %d size %zu status %d\n", static_cast<int>(kind), in.size(), static_cast<int>(st));
+        ++fail;
+      }
+    }
+  }
+  {
+    compress_options opt;
+    opt.container = Container::Gzip;
+    opt.final_stream = false;  // a non-final shard cannot carry a trailer
+    std::vector<std::byte> comp(compress_bound(html.size()));
+    const auto r2 = gpu.compress(html, comp, opt);
+    if (r2 || r2.error() != CompressStatus::InvalidArgument) { std::printf("expected InvalidArgument\n"); ++fail; }
+  }
   // too-small destination: status, no exception
   std::vector<std::byte> tiny(8);
   const auto r = gpu.compress(html, tiny);

@@ -2,7 +2,9 @@
 // tests assert (boost.ut is not available, so a 10-line checker stands in):
 //   huffman/test/{bit,code,bit_span,table_from_*,table_find_code,decode}_test.cpp
 //   src/test/decompress_test.cpp
-// argv[1] = tests/golden directory.
+// argv[1] = tests/golden directory; argv[2] (optional) = directory holding starfleet.html.zlib / .gz /
+// .named.gz made by zlib / gzip at test time (tests/test_cpp_host_api.py).
+#include "starflate/container.hpp"
 #include "starflate/decompress.hpp"
 #include "starflate/huffman/huffman.hpp"
 
@@ -223,8 +225,54 @@ static void test_decompress(const std::string& golden) {
   static_assert(static_cast<int>(DecompressStatus::InvalidDistance) == 7 && static_cast<int>(DecompressStatus::DstTooSmall) == 4);
 }
 
+static auto bytes_of(const char* s) -> std::vector<std::byte> {
+  std::vector<std::byte> b;
+  for (; *s != 0; ++s) b.push_back(static_cast<std::byte>(*s));
+  return b;
+}
+
+static void test_container(const std::string& golden, const std::string& wrapped) {
+  using starflate::Container;
+  using starflate::decompress;
+  // published check values: CRC-32("123456789") and Adler-32("Wikipedia")
+  CHECK(starflate::crc32(bytes_of("123456789")) == 0xCBF43926U);
+  CHECK(starflate::adler32(bytes_of("Wikipedia")) == 0x11E60398U);
+  CHECK(starflate::crc32({}) == 0U && starflate::adler32({}) == 1U);
+  {
+    const std::vector<std::byte> ff(70000, std::byte{0xFF});  // no 32-bit overflow inside a 5552-byte run
+    std::uint64_t a = 1, b = 0;
+    for (std::size_t i = 0; i < ff.size(); ++i) { a = (a + 255) % 65521; b = (b + a) % 65521; }
+    CHECK(starflate::adler32(ff) == ((b << 16U) | a));
+  }
+  if (wrapped.empty()) return;
+  const auto want = read_file(golden + "/starfleet.html");
+  for (const auto& [name, kind] : {std::pair{"/starfleet.html.zlib", Container::Zlib}, std::pair{"/starfleet.html.gz", Container::Gzip},
+                                   std::pair{"/starfleet.html.named.gz", Container::Gzip}}) {
+    auto comp = read_file(wrapped + name);
+    std::vector<std::byte> dst(want.size());
+    CHECK(!comp.empty() && decompress(comp, dst, kind) == DecompressStatus::Success && dst == want);
+    comp[comp.size() - (kind == Container::Zlib ? 1U : 5U)] ^= std::byte{1};  // checksum byte
+    CHECK(decompress(comp, dst, kind) == DecompressStatus::Error);
+    comp[comp.size() - (kind == Container::Zlib ? 1U : 5U)] ^= std::byte{1};
+    comp[0] ^= std::byte{0x10};  // header
+    CHECK(decompress(comp, dst, kind) == DecompressStatus::Error);
+    comp[0] ^= std::byte{0x10};
+    CHECK(decompress(std::span<const std::byte>{comp}.first(5), dst, kind) == DecompressStatus::SrcTooSmall);
+    if (kind == Container::Gzip) {
+      std::vector<std::byte> small(want.size() - 1);
+      CHECK(decompress(comp, small, kind) == DecompressStatus::DstTooSmall);
+    }
+  }
+  {
+    const auto raw = read_file(golden + "/starfleet.html.dynamic");
+    std::vector<std::byte> dst(want.size());
+    CHECK(decompress(raw, dst, Container::Raw) == DecompressStatus::Success && dst == want);
+  }
+}
+
 auto main(int argc, char** argv) -> int {
   const std::string golden = argc > 1 ? argv[1] : "tests/golden";
+  test_container(golden, argc > 2 ? argv[2] : "");
   test_bit_and_code();
   test_bit_span();
   test_table_from_frequencies();

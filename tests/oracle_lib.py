@@ -31,6 +31,7 @@ class Params(C.Structure):
         ("cap", C.c_uint32),
         ("fast_skip", C.c_uint32),
         ("far4_dist", C.c_uint32),
+        ("container", C.c_uint32),
     ]
 
 
@@ -77,6 +78,14 @@ def lib():
         L.sfo_compress_bound.restype = C.c_size_t
         L.sfo_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Params)]
         L.sfo_compress.restype = C.c_int
+        L.sfo_crc32.argtypes = [C.c_void_p, C.c_size_t]
+        L.sfo_crc32.restype = C.c_uint32
+        L.sfo_adler32.argtypes = [C.c_void_p, C.c_size_t]
+        L.sfo_adler32.restype = C.c_uint32
+        L.sfo_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.sfo_crc32_combine.restype = C.c_uint32
+        L.sfo_adler32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.sfo_adler32_combine.restype = C.c_uint32
         L.sfo_match_chunk.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Params), C.c_void_p, C.c_void_p]
         L.sfo_match_chunk.restype = None
         L.sfo_parse_chunk.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -130,6 +139,16 @@ def compress(data, params=None):
     if rc:
         raise RuntimeError(f"sfo_compress rc={rc}")
     return dst[: n.value].copy()
+
+
+def crc32(data):
+    s = _u8(data)
+    return lib().sfo_crc32(_ptr(s) if s.size else None, s.size)
+
+
+def adler32(data):
+    s = _u8(data)
+    return lib().sfo_adler32(_ptr(s) if s.size else None, s.size)
 
 
 def match_chunk(data, params):

@@ -13,7 +13,7 @@ from starflate_amd import _capi, build
 def _declared():
     with open(os.path.join(ROOT, "include", "starflate_hip.h")) as f:
         src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    return sorted(set(re.findall(r"\b(sfh_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(sfh_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -30,11 +30,17 @@ def test_host_side_entry_points_without_gpu():
     lib = _capi.lib()
     o = _capi.Options()
     lib.sfh_default_options(C.byref(o))
-    assert (o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path) == (0, 1, 3, 0) and all(v == 0 for v in o.reserved)
+    assert (o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path, o.container) == (0, 1, 3, 0, 0)
+    assert all(v == 0 for v in o.reserved) and C.sizeof(o) == 32
     assert lib.sfh_compress_bound(0) == 32768 + 4096 + 640
     assert lib.sfh_compress_bound(32768) == 32768 + 4096 + 640
     assert lib.sfh_compress_bound(32769) == 2 * (32768 + 4096 + 640)
     assert lib.sfh_stage_name(0) == b"k_lz77" and lib.sfh_stage_name(3) == b"k_emit" and lib.sfh_stage_name(9) == b""
+    import zlib
+    a, b = bytes(range(256)) * 300, b"starflate" * 5000  # host-side checksum combine rules against zlib
+    assert lib.sfh_crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+    assert lib.sfh_adler32_combine(zlib.adler32(a), zlib.adler32(b), len(b)) == zlib.adler32(a + b)
+    assert lib.sfh_crc32_combine(zlib.crc32(a), zlib.crc32(b""), 0) == zlib.crc32(a)
 
 
 def test_no_cpu_fallback():

@@ -25,7 +25,21 @@ def test_host_api_cpu(tmp_path, san):
         pytest.skip("no clang++")
     exe = tmp_path / "host_api_test"
     subprocess.check_call([CLANG, "-O1", "-g"] + FLAGS + san + [os.path.join(ROOT, "tests", "cpp", "host_api_test.cpp"), "-o", str(exe)])
-    out = subprocess.run([str(exe), GOLDEN], capture_output=True, text=True, timeout=120)
+    # wrapped fixtures made by zlib / gzip themselves (the reference's tool strips these wrappers,
+    # tools/deflate_compress.py:8-13); .named.gz carries FNAME so the optional-field skipping is exercised
+    import gzip
+    import io
+    import zlib
+
+    with open(os.path.join(GOLDEN, "starfleet.html"), "rb") as f:
+        html = f.read()
+    (tmp_path / "starfleet.html.zlib").write_bytes(zlib.compress(html, 6))
+    (tmp_path / "starfleet.html.gz").write_bytes(gzip.compress(html, 6, mtime=0))
+    buf = io.BytesIO()
+    with gzip.GzipFile(filename="starfleet.html", mode="wb", fileobj=buf, mtime=1) as g:
+        g.write(html)
+    (tmp_path / "starfleet.html.named.gz").write_bytes(buf.getvalue())
+    out = subprocess.run([str(exe), GOLDEN, str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failed" in out.stdout
 

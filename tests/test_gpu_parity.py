@@ -144,6 +144,52 @@ def test_size_independent_properties_large(compressor):
     assert np.all(np.diff(offs.astype(np.int64)) > 0) and offs[0] == 0
 
 
+@pytest.mark.parametrize("container", ["zlib", "gzip"])
+def test_container_wrappers(compressor, starfleet, container):
+    """RFC 1950 / RFC 1952 wrappers written on the GPU (checksum kernels): bit-exact with the oracle's
+    wrapper, body identical to the raw stream, and accepted by zlib's wrapper-checking inflate."""
+    import gzip
+
+    kind = _capi.CONTAINER[container]
+    h, t = (2, 4) if container == "zlib" else (10, 8)
+    for name, data in _inputs(starfleet).items():
+        got = np.frombuffer(compressor.compress(data, container=container), np.uint8)
+        want = O.compress(data, O.default_params(container=kind))
+        assert np.array_equal(got, want), f"{name}: first diff at {np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:4]}"
+        raw = np.frombuffer(compressor.compress(data), np.uint8)
+        assert np.array_equal(got[h:-t], raw), name
+        assert zlib.decompress(bytes(got), 15 if container == "zlib" else 31) == data.tobytes(), name
+        if container == "gzip":
+            assert gzip.decompress(bytes(got)) == data.tobytes()
+        _roundtrip(got[h:-t], data)
+    with pytest.raises(Exception):  # a non-final shard has no trailer
+        compressor.compress(b"abc", container=container, final_stream=False)
+
+
+def test_checksum_kernels_match_zlib(compressor):
+    """sfh_checksum_device against zlib.crc32 / zlib.adler32 (and the oracle's bit-serial definitions) on
+    empty, sub-chunk, ragged, all-0xFF (Adler worst case) and > 1024-chunk inputs; combine rules."""
+    import torch
+
+    from starflate_amd import checksum_combine
+
+    rng = np.random.default_rng(17)
+    cases = [np.zeros(0, np.uint8), np.array([1], np.uint8), rng.integers(0, 256, 127, dtype=np.uint8),
+             rng.integers(0, 256, CHUNK, dtype=np.uint8), rng.integers(0, 256, CHUNK + 1, dtype=np.uint8),
+             np.full(3 * CHUNK + 4097, 255, np.uint8), rng.integers(0, 256, 1500 * CHUNK + 12345, dtype=np.uint8),
+             synth.gen_text(2050 * CHUNK - 1, seed=8)]
+    for data in cases:
+        src = torch.from_numpy(data).cuda() if data.size else torch.empty(0, dtype=torch.uint8, device="cuda")
+        b = data.tobytes()
+        assert compressor.checksum_tensor(src, "gzip") == zlib.crc32(b), data.size
+        assert compressor.checksum_tensor(src, "zlib") == zlib.adler32(b), data.size
+        if data.size <= 4 * CHUNK:
+            assert O.crc32(data) == zlib.crc32(b) and O.adler32(data) == zlib.adler32(b)
+        cut = data.size // 3
+        for kind, f in (("gzip", zlib.crc32), ("zlib", zlib.adler32)):
+            assert checksum_combine(kind, f(b[:cut]), f(b[cut:]), len(b) - cut) == f(b)
+
+
 def test_pipelined_rounds_over_rccl_single_rank(compressor):
     """The N > 1 bench path (block-cyclic rounds + gather) on the one GPU we have: a 1-rank
     `nccl` (= RCCL) group exercises the real process group, the real compressor and the

@@ -45,7 +45,7 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-def _worker_pipelined(rank, world, port, piece_bytes, K, q):
+def _worker_pipelined(rank, world, port, piece_bytes, K, q, container="raw"):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -65,12 +65,45 @@ def _worker_pipelined(rank, world, port, piece_bytes, K, q):
         buf[: s.size] = torch.from_numpy(s)
         return buf, s.size
 
+    if container != "raw":
+        import zlib
+
+        f = zlib.crc32 if container == "gzip" else zlib.adler32
+        prealloc = torch.zeros(whole.size * 2 + 64, dtype=torch.uint8) if rank == 0 and K > 1 else None
+        out, total = multigpu.compress_pipelined(compress_fn, pieces, container=container, out=prealloc,
+                                                 checksum_fn=lambda piece, k: f(piece.numpy().tobytes()))
+        if rank == 0:  # zlib's wrapper-checking inflate is the judge of header, checksum and ISIZE
+            back = zlib.decompress(out[:total].numpy().tobytes(), 31 if container == "gzip" else 15)
+            h, t = (10, 8) if container == "gzip" else (2, 4)
+            st, w, body = O.decompress(out[h:total - t].numpy(), whole.size)
+            q.put((st, w, back == whole.tobytes() and bool(np.array_equal(body, whole)), total))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     out, total = multigpu.compress_pipelined(compress_fn, pieces)
     if rank == 0:
         st, w, back = O.decompress(out[:total].numpy(), whole.size)
         q.put((st, w, bool(np.array_equal(back, whole)), total))
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K,container", [(2, 3, "gzip"), (2, 1, "zlib"), (3, 2, "zlib")])
+def test_pipelined_wrapped_gloo(world, K, container):
+    """Shard checksums travel with the sizes and are combined in global piece order on every rank;
+    rank 0 wraps the concatenation once (SURVEY.md 8(f)1 on the N > 1 path)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    piece = 2 * 32768
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, piece, K, q, container)) for r in range(world)]
+    for p in procs:
+        p.start()
+    st, w, same, total = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert st == 0 and w == piece * K * world and same and total > 0
 
 
 @pytest.mark.parametrize("world,piece,K", [(2, 2 * 32768, 3), (3, 32768 + 32768, 2), (2, 32768, 1)])

@@ -158,3 +158,37 @@ def test_ratio_floor_vs_zlib6(starfleet):
         co = zlib.compressobj(6, zlib.DEFLATED, -15)
         z = len(co.compress(data.tobytes())) + len(co.flush())
         assert O.compress(data).size <= 1.33 * z
+
+
+def test_checksums_match_zlib(starfleet):
+    """The oracle's bit-serial CRC-32 / Adler-32 and their combine rules against zlib's (golden: zlib itself)."""
+    rng = np.random.default_rng(21)
+    for n in (0, 1, 2, 255, 5552, 5553, 32768, 65521, 100_003):
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        assert O.crc32(d) == zlib.crc32(d.tobytes()) and O.adler32(d) == zlib.adler32(d.tobytes())
+    ff = np.full(70_000, 255, np.uint8)  # Adler worst case for overflow
+    assert O.adler32(ff) == zlib.adler32(ff.tobytes())
+    d = np.frombuffer(starfleet, np.uint8)
+    for cut in (0, 1, 32768, 99_999, d.size):
+        a, b = d[:cut].tobytes(), d[cut:].tobytes()
+        assert O.lib().sfo_crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(d.tobytes())
+        assert O.lib().sfo_adler32_combine(zlib.adler32(a), zlib.adler32(b), len(b)) == zlib.adler32(d.tobytes())
+
+
+@pytest.mark.parametrize("container", [1, 2])
+def test_container_wrappers(starfleet, container):
+    """zlib (RFC 1950) and gzip (RFC 1952) wrappers: the body is the raw stream unchanged, and zlib's
+    own wrapper-checking inflate (wbits 15 / 31) accepts the whole thing (header, checksum, ISIZE)."""
+    import gzip
+
+    for name, data in _cases(starfleet).items():
+        raw = O.compress(data)
+        s = O.compress(data, O.default_params(container=container))
+        h, t = (2, 4) if container == 1 else (10, 8)
+        assert s.size == raw.size + h + t and np.array_equal(s[h:-t], raw), name
+        assert zlib.decompress(bytes(s), 15 if container == 1 else 31) == data.tobytes(), name
+        if container == 2:
+            assert gzip.decompress(bytes(s)) == data.tobytes()
+        assert s.size <= O.lib().sfo_compress_bound(data.size, O.default_params())
+    with pytest.raises(RuntimeError):  # a non-final shard cannot carry a trailer
+        O.compress(b"abc", O.default_params(container=container, final_stream=0))
