@@ -207,6 +207,14 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
                 "read_frac": round(n / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    try:  # what hipDeviceProp_t implies; `peak` above stays the guide's figure
+        from starflate_amd import _capi as _c
+        dp = _c.device_props(local_rank)
+        roofline["device"] = {"name": dp["name"], "arch": dp["arch"], "compute_units": dp["compute_units"],
+                              "memory_clock_khz": dp["memory_clock_khz"], "memory_bus_bits": dp["memory_bus_bits"],
+                              "hbm_peak_from_props_GBs": round(2 * dp["memory_clock_khz"] * 1e3 * dp["memory_bus_bits"] / 8 / 1e9, 1)}
+    except Exception as e:  # noqa: BLE001
+        roofline["device"] = {"error": str(e)}
     kern_total_ms = sum(stage_ms.values())
 
     # ---- CPU baseline: oracle restatement of the reference decompress(), 1 thread ----
@@ -228,6 +236,22 @@ def main():
                          f"of the first {cs >> 20} MiB of the workload; output MiB/s; round-trip equal={good}; "
                          f"host has {os.cpu_count()} logical cores",
                "zlib6_compress_MiBps_1core": round(zs / tz / 2**20, 2)}
+        # block-parallel zlib -6 on this host's cores (1 MiB independent slices; zlib releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+
+        nthreads = min(16, os.cpu_count() or 1)
+        sl = [host_sample[i:i + (1 << 20)] for i in range(0, zs, 1 << 20)]
+
+        def _z(b):
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            return len(co.compress(b)) + len(co.flush())
+
+        tp = time.perf_counter()
+        with ThreadPoolExecutor(nthreads) as ex:
+            zpar = sum(ex.map(_z, sl))
+        tp = time.perf_counter() - tp
+        cpu["zlib6_compress_MiBps_block_parallel"] = {"value": round(zs / tp / 2**20, 1), "threads": nthreads,
+                                                      "ratio": round(zs / zpar, 4)}
         ok = good if ok is None else (ok and good)
 
     line = {

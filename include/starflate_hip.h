@@ -72,6 +72,20 @@ typedef struct sfh_options {
 void sfh_default_options(sfh_options* o);
 
 int sfh_device_count(void);
+
+/* what hipDeviceProp_t reports for `device` (bench.py prints the HBM peak these imply) */
+typedef struct sfh_device_props {
+  char name[64];
+  char arch[32];             /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+  uint32_t compute_units;
+  uint32_t lds_bytes_per_cu; /* maxSharedMemoryPerMultiProcessor */
+  uint32_t l2_bytes;
+  uint32_t memory_clock_khz;
+  uint32_t memory_bus_bits;
+  uint32_t reserved;
+  uint64_t total_memory;
+} sfh_device_props;
+int sfh_get_device_props(int device, sfh_device_props* out);
 int sfh_create(sfh_ctx** out, int device);
 void sfh_destroy(sfh_ctx* ctx);
 const char* sfh_last_error(const sfh_ctx* ctx);
@@ -94,6 +108,36 @@ int sfh_compress_device_async(sfh_ctx* ctx, const void* d_src, size_t n, void* d
                               uint64_t* d_out_n, const sfh_options* opt, void* stream);
 
 /* ---- measurement hooks (bench.py, tests) ---- */
+
+/* ---- block index + GPU decompress ----
+ * A stream written by sfh_compress* consists of independently decodable segments, one per 32 KiB of input
+ * (SFH_SEGMENT_BYTES): each starts on a byte, and no match reaches before it.  The index is the table of their
+ * first bytes plus the end of the last one: nseg + 1 uint64 offsets into the stream (wrapper header included,
+ * trailer excluded).  With it the reference's decompress() (src/decompress.hpp:63-71) runs on the GPU, all
+ * segments at once; without it DEFLATE decoding is serial (README.md:5-6).  Any stream with such an index
+ * qualifies, e.g. zlib output flushed with Z_FULL_FLUSH every 32 KiB. */
+#define SFH_SEGMENT_BYTES 32768u
+
+/* entries of the index of the last sfh_compress* call on this ctx (segments + 1); 0 before any call */
+size_t sfh_index_entries(const sfh_ctx* ctx);
+/* copies that index to `dst` (host memory, or device memory if dst_on_device); synchronises `stream` */
+int sfh_copy_index(sfh_ctx* ctx, uint64_t* dst, size_t entries, int dst_on_device, void* stream);
+
+/* Device buffers (d_src 4-byte, d_index 8-byte, d_dst 16-byte aligned).  nseg must be ceil(dst_n / 32768)
+ * (1 for dst_n = 0); segment i decodes stream bytes [index[i], index[i+1]) into dst[i*32768 ...) and must
+ * produce exactly that many bytes.  Returns SFH_OK when the kernels ran; *status is then the reference's
+ * DecompressStatus (0 = Success) of the first failing segment in stream order; dst is complete only on 0.
+ * Synchronises `stream` (NULL = the ctx's own). */
+int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const uint64_t* d_index, size_t nseg,
+                          void* d_dst, size_t dst_n, uint32_t* status, void* stream);
+/* Host buffers: H2D (stream + index), decode, D2H. */
+int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* index, size_t nseg, void* dst,
+                   size_t dst_n, uint32_t* status);
+
+#define SFH_INFLATE_NSTAGES 2 /* 0 k_inflate_tokens (Huffman decode), 1 k_inflate_bytes (match copies) */
+/* with profiling on: milliseconds per decoder kernel of the last sfh_decompress* call */
+int sfh_last_inflate_ms(sfh_ctx* ctx, float ms[SFH_INFLATE_NSTAGES]);
+const char* sfh_inflate_stage_name(int stage);
 
 /* ---- container checksums ---- */
 

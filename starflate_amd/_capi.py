@@ -9,15 +9,18 @@ import os
 from . import build as _build
 
 NSTAGES = 5
+INFLATE_NSTAGES = 2
+SEGMENT_BYTES = 32768
 STRATEGY = {"auto": 0, "stored": 1, "fixed": 2, "dynamic": 3}
 CONTAINER = {"raw": 0, "zlib": 1, "gzip": 2}
 DBG_NTOK, DBG_TOKENS, DBG_HIST, DBG_PLAN, DBG_LENS, DBG_OFFSETS, DBG_STAMPS = range(7)
 
 # every symbol include/starflate_hip.h declares
 EXPORTS = [
-    "sfh_default_options", "sfh_device_count", "sfh_create", "sfh_destroy", "sfh_last_error",
+    "sfh_default_options", "sfh_device_count", "sfh_get_device_props", "sfh_create", "sfh_destroy", "sfh_last_error",
     "sfh_compress_bound", "sfh_compress", "sfh_compress_device", "sfh_compress_device_async",
-    "sfh_checksum_device", "sfh_crc32_combine", "sfh_adler32_combine",
+    "sfh_index_entries", "sfh_copy_index", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms",
+    "sfh_inflate_stage_name", "sfh_checksum_device", "sfh_crc32_combine", "sfh_adler32_combine",
     "sfh_set_profiling", "sfh_last_stage_ms", "sfh_stage_name", "sfh_debug_read",
 ]
 
@@ -25,6 +28,12 @@ EXPORTS = [
 class Options(C.Structure):
     _fields_ = [("strategy", C.c_uint32), ("final_stream", C.c_uint32), ("lazy", C.c_uint32),
                 ("no_stored_fast_path", C.c_uint32), ("container", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class DeviceProps(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("arch", C.c_char * 32), ("compute_units", C.c_uint32),
+                ("lds_bytes_per_cu", C.c_uint32), ("l2_bytes", C.c_uint32), ("memory_clock_khz", C.c_uint32),
+                ("memory_bus_bits", C.c_uint32), ("reserved", C.c_uint32), ("total_memory", C.c_uint64)]
 
 
 _LIB = None
@@ -54,6 +63,8 @@ def lib():
     L.sfh_default_options.restype = None
     L.sfh_device_count.argtypes = []
     L.sfh_device_count.restype = C.c_int
+    L.sfh_get_device_props.argtypes = [C.c_int, C.POINTER(DeviceProps)]
+    L.sfh_get_device_props.restype = C.c_int
     L.sfh_create.argtypes = [C.POINTER(vp), C.c_int]
     L.sfh_create.restype = C.c_int
     L.sfh_destroy.argtypes = [vp]
@@ -68,6 +79,18 @@ def lib():
     L.sfh_compress_device.restype = C.c_int
     L.sfh_compress_device_async.argtypes = [vp, vp, sz, vp, sz, vp, C.POINTER(Options), vp]
     L.sfh_compress_device_async.restype = C.c_int
+    L.sfh_index_entries.argtypes = [vp]
+    L.sfh_index_entries.restype = sz
+    L.sfh_copy_index.argtypes = [vp, vp, sz, C.c_int, vp]
+    L.sfh_copy_index.restype = C.c_int
+    L.sfh_decompress_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.POINTER(C.c_uint32), vp]
+    L.sfh_decompress_device.restype = C.c_int
+    L.sfh_decompress.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.POINTER(C.c_uint32)]
+    L.sfh_decompress.restype = C.c_int
+    L.sfh_last_inflate_ms.argtypes = [vp, C.POINTER(C.c_float * INFLATE_NSTAGES)]
+    L.sfh_last_inflate_ms.restype = C.c_int
+    L.sfh_inflate_stage_name.argtypes = [C.c_int]
+    L.sfh_inflate_stage_name.restype = C.c_char_p
     L.sfh_checksum_device.argtypes = [vp, vp, sz, C.c_uint32, C.POINTER(C.c_uint32), vp]
     L.sfh_checksum_device.restype = C.c_int
     L.sfh_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
@@ -84,6 +107,14 @@ def lib():
     L.sfh_debug_read.restype = C.c_int
     _LIB = L
     return L
+
+
+def device_props(device=0):
+    p = DeviceProps()
+    rc = lib().sfh_get_device_props(int(device), C.byref(p))
+    if rc:
+        raise RuntimeError(f"sfh_get_device_props({device}) -> {rc}")
+    return {k: (getattr(p, k).decode() if isinstance(getattr(p, k), bytes) else getattr(p, k)) for k, _ in p._fields_ if k != "reserved"}
 
 
 def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw"):

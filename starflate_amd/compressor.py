@@ -97,6 +97,60 @@ class Compressor:
         self._check(self._lib.sfh_compress_device_async(self._h, src.data_ptr() if n else None, n, out.data_ptr(),
                                                         out.numel(), size_out.data_ptr(), C.byref(opt), C.c_void_p(s)))
 
+    # ---- block index + GPU decompress (the reference's decompress(), /root/reference/src/decompress.hpp:63-71,
+    #      for streams whose independently decodable 32 KiB segments are known) ----
+    def last_index(self, device=None):
+        """Index of the last compress call: segments + 1 stream offsets.  numpy uint64 array, or (device given)
+        an int64 tensor on that CUDA device."""
+        n = self._lib.sfh_index_entries(self._h)
+        if n == 0:
+            raise StarflateError(-1, "no compress call on this context yet")
+        if device is None:
+            idx = np.empty(n, dtype=np.uint64)
+            self._check(self._lib.sfh_copy_index(self._h, idx.ctypes.data, n, 0, None))
+            return idx
+        import torch
+
+        idx = torch.empty(n, dtype=torch.int64, device=device)
+        s = torch.cuda.current_stream(idx.device).cuda_stream
+        self._check(self._lib.sfh_copy_index(self._h, idx.data_ptr(), n, 1, C.c_void_p(s)))
+        return idx
+
+    def decompress_tensor(self, stream, index, out_n, out=None, hip_stream=None):
+        """stream: 1-D uint8 CUDA tensor (exactly the compressed bytes); index: int64 CUDA tensor of segments + 1
+        offsets; out_n: decompressed size.  Returns (out tensor, DecompressStatus int, 0 = Success)."""
+        import torch
+
+        self._check_tensor(stream)
+        if not (isinstance(index, torch.Tensor) and index.is_cuda and index.dtype == torch.int64 and index.is_contiguous()):
+            raise ValueError("index must be a contiguous int64 CUDA tensor")
+        nseg = index.numel() - 1
+        if out is None:
+            out = torch.empty(max(int(out_n), 1), dtype=torch.uint8, device=stream.device)
+        self._check_tensor(out)
+        if out.numel() < out_n:
+            raise ValueError("out is smaller than out_n")
+        st = C.c_uint32(0)
+        s = torch.cuda.current_stream(stream.device).cuda_stream if hip_stream is None else hip_stream
+        self._check(self._lib.sfh_decompress_device(self._h, stream.data_ptr(), stream.numel(), index.data_ptr(), nseg,
+                                                    out.data_ptr() if out_n else None, int(out_n), C.byref(st), C.c_void_p(s)))
+        return out[:out_n], st.value
+
+    def decompress(self, data, index, out_n):
+        """Host buffers: bytes-like stream + numpy uint64 index -> (bytes, DecompressStatus int)."""
+        src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        idx = np.ascontiguousarray(index, dtype=np.uint64)
+        dst = np.empty(max(int(out_n), 1), dtype=np.uint8)
+        st = C.c_uint32(0)
+        self._check(self._lib.sfh_decompress(self._h, src.ctypes.data, src.size, idx.ctypes.data, idx.size - 1,
+                                             dst.ctypes.data if out_n else None, int(out_n), C.byref(st)))
+        return (dst[:out_n].tobytes() if st.value == 0 else b""), st.value
+
+    def inflate_ms(self):
+        ms = (C.c_float * _capi.INFLATE_NSTAGES)()
+        self._check(self._lib.sfh_last_inflate_ms(self._h, C.byref(ms)))
+        return {self._lib.sfh_inflate_stage_name(k).decode(): float(ms[k]) for k in range(_capi.INFLATE_NSTAGES)}
+
     def checksum_tensor(self, src, kind, stream=None):
         """kind "zlib" -> Adler-32, "gzip" -> CRC-32 of a 1-D uint8 tensor on this device (GPU kernels)."""
         import torch

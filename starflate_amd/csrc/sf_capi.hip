@@ -15,8 +15,13 @@ struct sfh_ctx {
   uint32_t cap_chunks = 0;       // chunks the workspace can hold
   uint32_t sums_cap = 0;         // chunks ws.sums can hold
   uint32_t last_chunks = 0;
+  bool index_valid = false;      // ws.offsets holds the index of the last compress call
   uint64_t* d_total = nullptr;   // own result slot for the synchronous entry points
-  uint32_t* d_value = nullptr;   // result slot of sfh_checksum_device
+  uint32_t* d_value = nullptr;   // result slot of sfh_checksum_device; [2] for the decoder's status
+  uint64_t* d_index = nullptr;   // staging for the host-buffer decoder
+  size_t d_index_cap = 0;
+  hipEvent_t ev_inf[SFH_INFLATE_NSTAGES + 1] = {};
+  bool ev_inf_valid = false;
   uint8_t* d_in = nullptr;       // staging for the host-buffer entry point
   uint8_t* d_out = nullptr;
   size_t d_in_cap = 0, d_out_cap = 0;
@@ -48,6 +53,7 @@ void free_ws(sfh_ctx* c) {
   (void)hipFree(c->ws.codes);
   (void)hipFree(c->ws.offsets);
   (void)hipFree(c->ws.stamps);
+  (void)hipFree(c->ws.seginfo);
   uint32_t* keep = c->ws.sums;  // sized on its own (ensure_sums)
   c->ws = sf::Workspace{};
   c->ws.sums = keep;
@@ -76,7 +82,8 @@ int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
       (e = hipMalloc(&ctx->ws.hist, nc * sf::kHistStride * sizeof(uint32_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.plan, nc * sizeof(sf::ChunkPlan))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.codes, nc * sizeof(sf::ChunkCodes))) != hipSuccess ||
-      (e = hipMalloc(&ctx->ws.offsets, nc * sizeof(uint64_t))) != hipSuccess) {
+      (e = hipMalloc(&ctx->ws.offsets, (nc + 1) * sizeof(uint64_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.seginfo, nc * sizeof(sf::SegInfo))) != hipSuccess) {
     free_ws(ctx);
     return fail(ctx, SFH_E_NOMEM, "workspace hipMalloc", e);
   }
@@ -130,6 +137,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   }
   if (prof) SF_HIP(hipEventRecord(ctx->ev[5], s), "event");
   ctx->ev_valid = prof;
+  ctx->index_valid = true;
   return SFH_OK;
 }
 
@@ -150,6 +158,24 @@ int sfh_device_count(void) {
   return n;
 }
 
+int sfh_get_device_props(int device, sfh_device_props* out) {
+  if (!out) return SFH_E_INVALID_ARG;
+  memset(out, 0, sizeof *out);
+  const int n = sfh_device_count();
+  if (n <= 0 || device < 0 || device >= n) return SFH_E_NO_DEVICE;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) return SFH_E_HIP;
+  snprintf(out->name, sizeof out->name, "%s", p.name);
+  snprintf(out->arch, sizeof out->arch, "%s", p.gcnArchName);
+  out->compute_units = (uint32_t)p.multiProcessorCount;
+  out->lds_bytes_per_cu = (uint32_t)p.maxSharedMemoryPerMultiProcessor;
+  out->l2_bytes = (uint32_t)p.l2CacheSize;
+  out->memory_clock_khz = (uint32_t)p.memoryClockRate;
+  out->memory_bus_bits = (uint32_t)p.memoryBusWidth;
+  out->total_memory = (uint64_t)p.totalGlobalMem;
+  return SFH_OK;
+}
+
 int sfh_create(sfh_ctx** out, int device) {
   if (!out) return SFH_E_INVALID_ARG;
   *out = nullptr;
@@ -165,12 +191,18 @@ int sfh_create(sfh_ctx** out, int device) {
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
       (e = hipMalloc(&ctx->d_total, sizeof(uint64_t))) != hipSuccess ||
-      (e = hipMalloc(&ctx->d_value, sizeof(uint32_t))) != hipSuccess || (e = sf::init_kernels()) != hipSuccess) {
+      (e = hipMalloc(&ctx->d_value, 2 * sizeof(uint32_t))) != hipSuccess || (e = sf::init_kernels()) != hipSuccess ||
+      (e = sf::init_inflate_kernels()) != hipSuccess) {
     sfh_destroy(ctx);
     return SFH_E_HIP;
   }
   for (int k = 0; k <= SFH_NSTAGES; ++k)
     if (hipEventCreate(&ctx->ev[k]) != hipSuccess) {
+      sfh_destroy(ctx);
+      return SFH_E_HIP;
+    }
+  for (int k = 0; k <= SFH_INFLATE_NSTAGES; ++k)
+    if (hipEventCreate(&ctx->ev_inf[k]) != hipSuccess) {
       sfh_destroy(ctx);
       return SFH_E_HIP;
     }
@@ -186,6 +218,9 @@ void sfh_destroy(sfh_ctx* ctx) {
   (void)hipFree(ctx->ws.sums);
   (void)hipFree(ctx->d_total);
   (void)hipFree(ctx->d_value);
+  (void)hipFree(ctx->d_index);
+  for (int k = 0; k <= SFH_INFLATE_NSTAGES; ++k)
+    if (ctx->ev_inf[k]) (void)hipEventDestroy(ctx->ev_inf[k]);
   (void)hipFree(ctx->d_in);
   (void)hipFree(ctx->d_out);
   for (int k = 0; k <= SFH_NSTAGES; ++k)
@@ -251,6 +286,100 @@ int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap,
   SF_HIP(hipStreamSynchronize(s), "stream sync");
   *out_n = total;
   return SFH_OK;
+}
+
+size_t sfh_index_entries(const sfh_ctx* ctx) { return (ctx && ctx->index_valid) ? (size_t)ctx->last_chunks + 1 : 0; }
+
+int sfh_copy_index(sfh_ctx* ctx, uint64_t* dst, size_t entries, int dst_on_device, void* stream) {
+  if (!ctx || !dst || !ctx->index_valid || entries != (size_t)ctx->last_chunks + 1)
+    return fail(ctx, SFH_E_INVALID_ARG, "index: no compress call yet, or entries != segments + 1", hipSuccess);
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  SF_HIP(hipMemcpyAsync(dst, ctx->ws.offsets, entries * sizeof(uint64_t),
+                        dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s), "copy index");
+  SF_HIP(hipStreamSynchronize(s), "stream sync");
+  return SFH_OK;
+}
+
+int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const uint64_t* d_index, size_t nseg,
+                          void* d_dst, size_t dst_n, uint32_t* status, void* stream) {
+  if (!ctx || !d_src || !d_index || !status || (!d_dst && dst_n)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
+  if (((uintptr_t)d_src & 3) || ((uintptr_t)d_index & 7) || ((uintptr_t)d_dst & 15))
+    return fail(ctx, SFH_E_INVALID_ARG, "device pointer alignment (src 4, index 8, dst 16)", hipSuccess);
+  if (dst_n > ((size_t)1 << 44) || nseg != (size_t)chunks_of(dst_n))
+    return fail(ctx, SFH_E_INVALID_ARG, "nseg != ceil(dst_n / 32768)", hipSuccess);
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  int rc = ensure_ws(ctx, (uint32_t)nseg);
+  if (rc) return rc;
+  ctx->index_valid = false;  // the decoder reuses the scratch: what sfh_debug_read returns now belongs to this call
+  ctx->last_chunks = (uint32_t)nseg;
+  const bool prof = ctx->profiling != 0;
+  if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[0], s), "event");
+  SF_HIP(sf::launch_inflate_tokens((const uint8_t*)d_src, src_n, d_index, (uint32_t)nseg, dst_n, ctx->ws.tokens,
+                                   ctx->ws.seginfo, s), "launch k_inflate_tokens");
+  if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[1], s), "event");
+  SF_HIP(sf::launch_inflate_bytes((const uint8_t*)d_src, src_n, (uint32_t)nseg, ctx->ws.tokens, ctx->ws.seginfo,
+                                  (uint8_t*)d_dst, s), "launch k_inflate_bytes");
+  if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[2], s), "event");
+  ctx->ev_inf_valid = prof;
+  SF_HIP(sf::launch_inflate_status(ctx->ws.seginfo, (uint32_t)nseg, ctx->d_value, s), "launch k_inflate_status");
+  uint32_t res[2] = {0, 0};
+  SF_HIP(hipMemcpyAsync(res, ctx->d_value, sizeof res, hipMemcpyDeviceToHost, s), "copy status");
+  SF_HIP(hipStreamSynchronize(s), "stream sync");
+  *status = res[0];
+  if (res[0]) snprintf(ctx->err, sizeof ctx->err, "segment %u: DecompressStatus %u", res[1], res[0]);
+  return SFH_OK;
+}
+
+int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* index, size_t nseg, void* dst,
+                   size_t dst_n, uint32_t* status) {
+  if (!ctx || !src || !index || !status || (!dst && dst_n)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  const size_t in_need = src_n ? src_n : 16, out_need = dst_n ? dst_n : 16;
+  if (ctx->d_in_cap < in_need) {
+    (void)hipFree(ctx->d_in);
+    ctx->d_in = nullptr;
+    ctx->d_in_cap = 0;
+    if (hipMalloc(&ctx->d_in, in_need) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "input staging", hipSuccess);
+    ctx->d_in_cap = in_need;
+  }
+  if (ctx->d_out_cap < out_need) {
+    (void)hipFree(ctx->d_out);
+    ctx->d_out = nullptr;
+    ctx->d_out_cap = 0;
+    if (hipMalloc(&ctx->d_out, out_need) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "output staging", hipSuccess);
+    ctx->d_out_cap = out_need;
+  }
+  if (ctx->d_index_cap < nseg + 1) {
+    (void)hipFree(ctx->d_index);
+    ctx->d_index = nullptr;
+    ctx->d_index_cap = 0;
+    if (hipMalloc(&ctx->d_index, (nseg + 1) * sizeof(uint64_t)) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "index staging", hipSuccess);
+    ctx->d_index_cap = nseg + 1;
+  }
+  hipStream_t s = ctx->stream;
+  if (src_n) SF_HIP(hipMemcpyAsync(ctx->d_in, src, src_n, hipMemcpyHostToDevice, s), "H2D");
+  SF_HIP(hipMemcpyAsync(ctx->d_index, index, (nseg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s), "H2D index");
+  int rc = sfh_decompress_device(ctx, ctx->d_in, src_n, ctx->d_index, nseg, ctx->d_out, dst_n, status, s);
+  if (rc) return rc;
+  if (*status == 0 && dst_n) {
+    SF_HIP(hipMemcpyAsync(dst, ctx->d_out, dst_n, hipMemcpyDeviceToHost, s), "D2H");
+    SF_HIP(hipStreamSynchronize(s), "stream sync");
+  }
+  return SFH_OK;
+}
+
+int sfh_last_inflate_ms(sfh_ctx* ctx, float ms[SFH_INFLATE_NSTAGES]) {
+  if (!ctx || !ms || !ctx->ev_inf_valid) return SFH_E_INVALID_ARG;
+  for (int k = 0; k < SFH_INFLATE_NSTAGES; ++k)
+    SF_HIP(hipEventElapsedTime(&ms[k], ctx->ev_inf[k], ctx->ev_inf[k + 1]), "elapsed");
+  return SFH_OK;
+}
+
+const char* sfh_inflate_stage_name(int stage) {
+  static const char* names[SFH_INFLATE_NSTAGES] = {"k_inflate_tokens", "k_inflate_bytes"};
+  return (stage >= 0 && stage < SFH_INFLATE_NSTAGES) ? names[stage] : "";
 }
 
 int sfh_checksum_device(sfh_ctx* ctx, const void* d_src, size_t n, uint32_t kind, uint32_t* out, void* stream) {

@@ -50,15 +50,25 @@ struct ChunkCodes {
   uint8_t lens[320];     // ll lens [0..287], d lens [288..319] (debug / parity)
 };
 
+// per-segment record of the decoder (sf_inflate.hip): written by k_inflate_tokens, read by k_inflate_bytes
+struct SegInfo {
+  uint32_t status;   // DecompressStatus of the reference (src/decompress.hpp:13-23), 0 = Success
+  uint32_t ntok;
+  uint32_t raw;      // 1: one stored block holding the whole segment, bytes at raw_off of the stream
+  uint32_t out_n;    // bytes this segment produces
+  uint64_t raw_off;
+};
+
 struct Workspace {
   uint32_t* tokens;   // [nchunks][kChunk]
   uint32_t* ntok;     // [nchunks]
   uint32_t* hist;     // [nchunks][kHistStride]
   ChunkPlan* plan;    // [nchunks]
   ChunkCodes* codes;  // [nchunks]
-  uint64_t* offsets;  // [nchunks]
+  uint64_t* offsets;  // [nchunks + 1]: first stream byte of every chunk, then the end of the last one (= the index)
   uint64_t* stamps;   // [nchunks][8], diagnostic build only (SFH_K1_STAMPS=1), else null
   uint32_t* sums;     // [nchunks] checksum partials (container modes / sfh_checksum_device)
+  SegInfo* seginfo;   // [nchunks] decoder only
 };
 
 struct Options {
@@ -85,6 +95,14 @@ hipError_t launch_checksum(const uint8_t* src, uint64_t n, uint32_t nchunks, uin
 // dst != null: header at dst[0..), trailer at dst[*d_total..), *d_total += trailer bytes; d_value (nullable) = checksum
 hipError_t launch_wrap(const uint32_t* sums, uint32_t nchunks, uint64_t n, uint32_t kind, uint8_t* dst,
                        uint64_t* d_total, uint32_t* d_value, hipStream_t s);
+// sf_inflate.hip
+hipError_t init_inflate_kernels();
+hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint64_t* index, uint32_t nseg, uint64_t dst_n,
+                                 uint32_t* tokens, SegInfo* info, hipStream_t s);
+hipError_t launch_inflate_bytes(const uint8_t* src, uint64_t src_n, uint32_t nseg, const uint32_t* tokens, SegInfo* info,
+                                uint8_t* dst, hipStream_t s);
+hipError_t launch_inflate_status(const SegInfo* info, uint32_t nseg, uint32_t* d_result, hipStream_t s);
+
 uint32_t crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);        // host arithmetic
 uint32_t adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b);  // host arithmetic
 

@@ -1,0 +1,410 @@
+// sf_inflate_core.h -- one DEFLATE segment -> tokens, written once for device and host.
+//
+// This is the bit-serial half of the GPU decoder: the inverse of k_emit, i.e. what
+// the reference's decompress() does per block (/root/reference/src/decompress.cpp:402-461: header
+// :370-385, stored :416-436, fixed tables :25-40, dynamic tables :253-367, symbol loop :122-187),
+// minus the byte copies -- a match becomes a token (bit31, len-3 in 16..23, dist-1 in 0..14), a literal
+// its byte value, exactly the token format k_lz77 writes.  On the GPU every LANE runs this function on its
+// own segment (k_inflate_tokens, sf_inflate.hip); the table memory `m` is that lane's slice of LDS.
+// The same source compiles for the host so that tests can run it without a GPU (tests/cpp/inflate_core_host.cpp);
+// the product never calls the host build.
+//
+// Differences from the reference, all on inputs where the reference is undefined or wrong:
+//  * the HLIT+HDIST code lengths are one sequence (RFC 1951 3.2.7: a run may cross from the literal/length
+//    into the distance lengths); the reference reads two sequences (hazards A/B of SURVEY.md 8(c)).  Streams
+//    made by this library never contain such a run, so both decoders agree on them.
+//  * truncated input is SrcTooSmall and a code-length run past the end is Error, where the reference asserts.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SF_HD __host__ __device__ __forceinline__
+#else
+#define SF_HD inline
+#endif
+
+namespace sf {
+namespace inflate {
+
+// DecompressStatus of the reference (src/decompress.hpp:13-23), same values
+enum : uint32_t {
+  kOk = 0,
+  kError = 1,
+  kInvalidBlockHeader = 2,
+  kNoCompressionLenMismatch = 3,
+  kDstTooSmall = 4,
+  kSrcTooSmall = 5,
+  kInvalidLitOrLen = 6,
+  kInvalidDistance = 7
+};
+
+constexpr uint32_t kTokMatchBit = 0x80000000u;
+constexpr uint32_t kFastBits = 9;   // literal/length codes up to 9 bits: one table read
+constexpr uint32_t kDFastBits = 7;  // distance codes up to 7 bits: one table read
+
+// per-segment table memory (byte offsets); 537 dwords: an odd stride spreads the lanes over the LDS banks
+constexpr uint32_t kOffFast = 0;      // u16[512]: (symbol << 4) | code bits, 0 = longer code
+constexpr uint32_t kOffLSym = 1024;   // u16[288]: literal/length symbols sorted by (code bits, symbol)
+constexpr uint32_t kOffLCnt = 1600;   // u16[16] : codes per length
+constexpr uint32_t kOffDFast = 1632;  // u8[128] : (symbol << 3) | code bits, 0 = longer code
+constexpr uint32_t kOffDSym = 1760;   // u8[32]
+constexpr uint32_t kOffDCnt = 1792;   // u16[16]
+constexpr uint32_t kOffLens = 1824;   // u8[320] : code lengths while a header is parsed
+constexpr uint32_t kLaneBytes = 2148;
+
+struct SegmentResult {
+  uint32_t status;   // one of the values above
+  uint32_t ntok;     // tokens written (raw == 0)
+  uint32_t raw;      // 1: the segment is one stored block holding all `out_n` bytes at byte `raw_off`
+  uint64_t raw_off;  // of the stream buffer
+};
+
+SF_HD uint16_t ld16(const uint8_t* m, uint32_t off) { return *reinterpret_cast<const uint16_t*>(m + off); }
+SF_HD void st16(uint8_t* m, uint32_t off, uint32_t v) { *reinterpret_cast<uint16_t*>(m + off) = (uint16_t)v; }
+
+// RFC 1951 3.2.5 (src/decompress.cpp:53-84)
+SF_HD void length_info(uint32_t sym /*257..285*/, uint32_t& base, uint32_t& extra) {
+  const uint32_t k = sym - 257;
+  if (k < 8) { base = 3 + k; extra = 0; return; }
+  if (k == 28) { base = 258; extra = 0; return; }
+  extra = (k - 4) >> 2;
+  base = 3 + ((4 + (k & 3)) << extra);
+}
+SF_HD void distance_info(uint32_t sym /*0..29*/, uint32_t& base, uint32_t& extra) {
+  if (sym < 4) { base = 1 + sym; extra = 0; return; }
+  extra = (sym - 2) >> 1;
+  base = 1 + ((2 + (sym & 1)) << extra);
+}
+
+struct BitReader {
+  const uint8_t* base;  // stream buffer, 4-byte aligned
+  uint64_t src_n;       // bytes in the buffer; nothing at or past it is read
+  uint64_t word;        // next dword to load
+  uint64_t buf;
+  uint32_t cnt;
+  uint32_t next;        // dword `word - 1`, loaded one refill ahead of its use
+  uint64_t bitpos;      // bits consumed since the segment began
+  uint64_t nbits;       // bits the segment holds
+
+  SF_HD uint32_t load_word(uint64_t w) const {
+    const uint64_t b = 4 * w;
+    if (b + 4 <= src_n) return reinterpret_cast<const uint32_t*>(base)[w];
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 4; ++k)
+      if (b + k < src_n) v |= (uint32_t)base[b + k] << (8 * k);
+    return v;
+  }
+  SF_HD void seek(uint64_t byte) {  // bit accounting is left alone
+    word = byte >> 2;
+    const uint32_t sh = 8 * (uint32_t)(byte & 3);
+    buf = (uint64_t)(load_word(word++) >> sh);
+    cnt = 32 - sh;
+    next = load_word(word++);
+  }
+  SF_HD void refill() {  // afterwards at least 33 bits are buffered
+    if (cnt <= 32) {
+      buf |= (uint64_t)next << cnt;
+      cnt += 32;
+      next = load_word(word++);
+    }
+  }
+  SF_HD uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }  // n <= 31
+  SF_HD void drop(uint32_t n) {
+    buf >>= n;
+    cnt -= n;
+    bitpos += n;
+  }
+  SF_HD uint32_t get(uint32_t n) {
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  SF_HD bool overrun() const { return bitpos > nbits; }
+};
+
+SF_HD uint32_t bit_reverse(uint32_t code, uint32_t len) {
+  uint32_t r = 0;
+  for (uint32_t k = 0; k < len; ++k) r |= ((code >> k) & 1u) << (len - 1 - k);
+  return r;
+}
+
+// Canonical code (huffman/src/table.hpp:177-216) from lens[0..n) (bytes at m + kOffLens + lens_at):
+// per-length counts, symbols sorted by (length, symbol), and the one-read table for codes <= fast_bits.
+// WIDE: literal/length alphabet (u16 entries / symbols), else distance alphabet (u8).
+template <bool WIDE>
+SF_HD void build_tables(uint8_t* m, uint32_t lens_at, uint32_t n) {
+  const uint32_t off_cnt = WIDE ? kOffLCnt : kOffDCnt, off_sym = WIDE ? kOffLSym : kOffDSym;
+  const uint32_t off_fast = WIDE ? kOffFast : kOffDFast, fast_bits = WIDE ? kFastBits : kDFastBits;
+  const uint8_t* lens = m + kOffLens + lens_at;
+  for (uint32_t l = 0; l < 16; ++l) st16(m, off_cnt + 2 * l, 0);
+  for (uint32_t s = 0; s < n; ++s) {
+    const uint32_t l = lens[s] & 15u;
+    st16(m, off_cnt + 2 * l, ld16(m, off_cnt + 2 * l) + 1u);
+  }
+  st16(m, off_cnt, 0);  // length 0 = unused symbol
+  uint32_t offs[16];
+  offs[0] = 0;
+  offs[1] = 0;
+#pragma unroll
+  for (uint32_t l = 1; l < 15; ++l) offs[l + 1] = offs[l] + ld16(m, off_cnt + 2 * l);
+  for (uint32_t s = 0; s < n; ++s) {
+    const uint32_t l = lens[s] & 15u;
+    if (!l) continue;
+    // offs[l]++ without indexing a register array by a runtime value
+    uint32_t at = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 16; ++k)
+      if (k == l) { at = offs[k]; offs[k] = at + 1; }
+    if (WIDE) st16(m, off_sym + 2 * at, s); else m[off_sym + at] = (uint8_t)s;
+  }
+  const uint32_t fast_n = 1u << fast_bits;
+  for (uint32_t k = 0; k < fast_n; ++k) {
+    if (WIDE) st16(m, off_fast + 2 * k, 0); else m[off_fast + k] = 0;
+  }
+  uint32_t code = 0, idx = 0;
+  for (uint32_t l = 1; l <= fast_bits; ++l) {
+    const uint32_t c = ld16(m, off_cnt + 2 * l);
+    for (uint32_t j = 0; j < c; ++j, ++idx, ++code) {
+      const uint32_t sym = WIDE ? ld16(m, off_sym + 2 * idx) : m[off_sym + idx];
+      const uint32_t rev = bit_reverse(code & ((1u << l) - 1u), l);  // an over-subscribed code cannot index past the table
+      for (uint32_t e = rev; e < fast_n; e += 1u << l) {
+        if (WIDE) st16(m, off_fast + 2 * e, (sym << 4) | l); else m[off_fast + e] = (uint8_t)((sym << 3) | l);
+      }
+    }
+    code <<= 1;
+  }
+}
+
+// One symbol.  Returns its code length (0: no code matches the next bits) and the symbol in `sym`.
+// The caller has refilled: >= 15 bits are buffered (bits past the end of the input read as zero).
+template <bool WIDE>
+SF_HD uint32_t decode_symbol(const uint8_t* m, const BitReader& br, uint32_t& sym) {
+  const uint32_t fast_bits = WIDE ? kFastBits : kDFastBits;
+  const uint32_t e = WIDE ? ld16(m, kOffFast + 2 * br.peek(fast_bits)) : m[kOffDFast + br.peek(fast_bits)];
+  if (e) {
+    sym = WIDE ? e >> 4 : e >> 3;
+    return WIDE ? (e & 15u) : (e & 7u);
+  }
+  // longer code: canonical bit-serial walk (one table row per length), rare
+  const uint32_t off_cnt = WIDE ? kOffLCnt : kOffDCnt, off_sym = WIDE ? kOffLSym : kOffDSym;
+  uint32_t bits = (uint32_t)br.buf, code = 0, first = 0, index = 0;
+  for (uint32_t l = 1; l <= 15; ++l) {
+    code |= bits & 1u;
+    bits >>= 1;
+    const uint32_t c = ld16(m, off_cnt + 2 * l);
+    if (code < first + c) {
+      const uint32_t at = index + (code - first);
+      sym = WIDE ? ld16(m, off_sym + 2 * at) : m[off_sym + at];
+      return l;
+    }
+    index += c;
+    first = (first + c) << 1;
+    code <<= 1;
+  }
+  return 0;
+}
+
+// Token sink: groups four tokens into one 16-byte store (the GPU lanes write 128 KiB apart).
+struct alignas(16) Tok4 {
+  uint32_t a, b, c, d;
+};
+struct TokenSink {
+  uint32_t* out;  // 16-byte aligned, room for 32768 tokens
+  uint32_t n;
+  uint32_t q0, q1, q2;
+  SF_HD void put(uint32_t t) {
+    const uint32_t k = n & 3u;
+    if (k == 0) q0 = t;
+    else if (k == 1) q1 = t;
+    else if (k == 2) q2 = t;
+    else {
+      *reinterpret_cast<Tok4*>(out + (n & ~3u)) = Tok4{q0, q1, q2, t};  // one dwordx4 store
+    }
+    ++n;
+  }
+  SF_HD void flush() {
+    const uint32_t k = n & 3u;
+    uint32_t* p = out + (n & ~3u);
+    if (k > 0) p[0] = q0;
+    if (k > 1) p[1] = q1;
+    if (k > 2) p[2] = q2;
+  }
+};
+
+// Decodes the blocks of one segment: stream bytes [seg_begin, seg_end) of `src`, which must produce exactly
+// out_n (<= 32768) bytes.  Tokens go to tokens[0..ntok).  `m`: kLaneBytes of scratch.
+SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end,
+                                   uint32_t out_n, uint32_t* tokens, uint8_t* m) {
+  SegmentResult r{kOk, 0, 0, 0};
+  if (seg_begin > seg_end || seg_end > src_n) {
+    r.status = kSrcTooSmall;
+    return r;
+  }
+  BitReader br;
+  br.base = src;
+  br.src_n = src_n;
+  br.bitpos = 0;
+  br.nbits = 8 * (seg_end - seg_begin);
+  br.seek(seg_begin);
+  TokenSink sink{tokens, 0, 0, 0, 0};
+  uint32_t out_pos = 0;
+  uint32_t status = kOk;
+  bool last = false;
+  while (!last && status == kOk) {
+    if (br.bitpos + 3 > br.nbits) {
+      // out of input: fine when the segment is complete (a non-final shard ends without BFINAL), else truncated
+      if (out_pos != out_n || br.bitpos == 0) status = br.bitpos == 0 ? kInvalidBlockHeader : kSrcTooSmall;
+      break;
+    }
+    br.refill();
+    last = br.get(1) != 0;
+    const uint32_t type = br.get(2);
+    if (type == 3) { status = kInvalidBlockHeader; break; }
+    if (type == 0) {
+      // stored: src/decompress.cpp:416-436
+      br.drop((uint32_t)((8 - (br.bitpos & 7)) & 7));
+      br.refill();
+      if (br.bitpos + 32 > br.nbits) { status = kSrcTooSmall; break; }
+      const uint32_t len = br.get(16);
+      br.refill();
+      const uint32_t nlen = br.get(16);
+      if ((len ^ nlen) != 0xFFFFu) { status = kNoCompressionLenMismatch; break; }
+      if (br.bitpos + 8ull * len > br.nbits) { status = kSrcTooSmall; break; }
+      if (len > out_n - out_pos) { status = kDstTooSmall; break; }
+      const uint64_t data_at = seg_begin + (br.bitpos >> 3);
+      if (sink.n == 0 && out_pos == 0 && len == out_n && len != 0) {
+        r.raw = 1;  // the whole segment is this block: the byte-copy kernel takes it from the stream
+        r.raw_off = data_at;
+        out_pos = len;
+      } else {
+        for (uint32_t k = 0; k < len; ++k) sink.put(src[data_at + k]);
+        out_pos += len;
+      }
+      br.bitpos += 8ull * len;
+      br.seek(data_at + len);
+      continue;
+    }
+    if (type == 1) {
+      // fixed: src/decompress.cpp:25-40
+      uint8_t* lens = m + kOffLens;
+      for (uint32_t s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+      for (uint32_t s = 0; s < 32; ++s) lens[288 + s] = 5;
+    } else {
+      // dynamic: src/decompress.cpp:314-367
+      br.refill();
+      if (br.bitpos + 14 > br.nbits) { status = kSrcTooSmall; break; }
+      const uint32_t hlit = br.get(5) + 257, hdist = br.get(5) + 1, hclen = br.get(4) + 4;
+      if (br.bitpos + 3ull * hclen > br.nbits) { status = kSrcTooSmall; break; }
+      uint8_t* cl = m + kOffDFast;  // the distance tables are built after the header: borrow their memory
+      for (uint32_t k = 0; k < 19; ++k) cl[k] = 0;
+      for (uint32_t k = 0; k < hclen; ++k) {
+        br.refill();
+        // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (src/decompress.cpp:250-251)
+        const uint32_t order = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 8 + ((k - 4) >> 1);
+        cl[order] = (uint8_t)br.get(3);
+      }
+      // code-length code: counts and sorted symbols (<= 7 bits), canonical walk per symbol
+      uint8_t* ccnt = m + kOffDSym;        // u8[8]
+      uint8_t* csym = m + kOffDSym + 8;    // u8[19]
+      for (uint32_t l = 0; l < 8; ++l) ccnt[l] = 0;
+      for (uint32_t s = 0; s < 19; ++s) ccnt[cl[s]]++;
+      ccnt[0] = 0;
+      {
+        uint32_t at = 0;
+        for (uint32_t l = 1; l < 8; ++l)
+          for (uint32_t s = 0; s < 19; ++s)
+            if (cl[s] == l) csym[at++] = (uint8_t)s;
+      }
+      uint8_t* lens = m + kOffLens;
+      const uint32_t total = hlit + hdist;
+      uint32_t i = 0, prev = 0;
+      while (i < total && status == kOk) {
+        br.refill();
+        if (br.overrun()) { status = kSrcTooSmall; break; }
+        uint32_t bits = (uint32_t)br.buf, code = 0, first = 0, index = 0, sym = 19, used = 0;
+        for (uint32_t l = 1; l <= 7; ++l) {
+          code |= bits & 1u;
+          bits >>= 1;
+          const uint32_t c = ccnt[l];
+          if (code < first + c) { sym = csym[index + (code - first)]; used = l; break; }
+          index += c;
+          first = (first + c) << 1;
+          code <<= 1;
+        }
+        if (sym > 18) { status = kError; break; }
+        br.drop(used);
+        if (sym < 16) {
+          lens[i++] = (uint8_t)sym;
+          prev = sym;
+        } else {
+          uint32_t rep, val = 0;
+          if (sym == 16) {
+            if (i == 0) { status = kError; break; }  // nothing to repeat (src/decompress.cpp:278)
+            val = prev;
+            rep = 3 + br.get(2);
+          } else if (sym == 17) {
+            rep = 3 + br.get(3);
+          } else {
+            rep = 11 + br.get(7);
+          }
+          if (i + rep > total) { status = kError; break; }  // run past the last length
+          for (uint32_t k = 0; k < rep; ++k) lens[i++] = (uint8_t)val;
+          prev = val;
+        }
+      }
+      if (status != kOk) break;
+      if (br.overrun()) { status = kSrcTooSmall; break; }
+      // move the distance lengths to their fixed place [288..) so both layouts look alike (downwards: the
+      // ranges may overlap and the destination is the higher one)
+      if (hlit < 288) {
+        for (uint32_t s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];
+        for (uint32_t s = hlit; s < 288; ++s) lens[s] = 0;
+      }
+      for (uint32_t s = hdist; s < 32; ++s) lens[288 + s] = 0;
+    }
+    build_tables<true>(m, 0, 288);
+    build_tables<false>(m, 288, 32);
+    // symbol loop: src/decompress.cpp:122-187
+    for (;;) {
+      br.refill();
+      uint32_t sym;
+      const uint32_t l = decode_symbol<true>(m, br, sym);
+      if (l == 0) { status = kInvalidLitOrLen; break; }
+      br.drop(l);
+      if (sym < 256) {
+        if (out_pos >= out_n) { status = kDstTooSmall; break; }
+        sink.put(sym);
+        ++out_pos;
+        continue;
+      }
+      if (sym == 256) break;
+      if (sym > 285) { status = kInvalidLitOrLen; break; }
+      uint32_t lbase, lextra;
+      length_info(sym, lbase, lextra);
+      const uint32_t len = lbase + br.get(lextra);
+      br.refill();
+      uint32_t dsym;
+      const uint32_t dl = decode_symbol<false>(m, br, dsym);
+      if (dl == 0 || dsym > 29) { status = kInvalidDistance; break; }
+      br.drop(dl);
+      uint32_t dbase, dextra;
+      distance_info(dsym, dbase, dextra);
+      const uint32_t dist = dbase + br.get(dextra);
+      if (dist > out_pos) { status = kInvalidDistance; break; }   // src/decompress.cpp:178
+      if (len > out_n - out_pos) { status = kDstTooSmall; break; }
+      sink.put(kTokMatchBit | ((len - 3) << 16) | (dist - 1));
+      out_pos += len;
+      if (br.overrun()) { status = kSrcTooSmall; break; }
+    }
+    if (status == kOk && br.overrun()) status = kSrcTooSmall;
+  }
+  if (status == kOk && out_pos != out_n) status = kSrcTooSmall;  // the index promised more bytes
+  if (status == kOk && r.raw && sink.n != 0) status = kDstTooSmall;
+  sink.flush();
+  r.status = status;
+  r.ntok = sink.n;
+  return r;
+}
+
+}  // namespace inflate
+}  // namespace sf

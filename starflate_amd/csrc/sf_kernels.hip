@@ -954,7 +954,10 @@ __global__ __launch_bounds__(K3_THREADS) void k_scan(uint32_t nchunks, const Chu
     offsets[c] = run;
     run += plan[c].out_bytes;
   }
-  if (t == K3_THREADS - 1) *total = base + s_part[t];
+  if (t == K3_THREADS - 1) {
+    *total = base + s_part[t];
+    offsets[nchunks] = base + s_part[t];  // closes the index: chunk c occupies [offsets[c], offsets[c + 1])
+  }
 }
 
 // ---------------------------------------------------------------------------

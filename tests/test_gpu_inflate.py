@@ -1,0 +1,157 @@
+"""GPU decompress of block-indexed streams (k_inflate_tokens + k_inflate_bytes through the C-ABI): the output must
+be byte-identical to what the oracle's restatement of the reference decoder (src/decompress.cpp:402-461) produces
+from the same stream, for every block type, for wrapped streams, and for zlib-made indexed streams; the decoder's
+tokens must equal the compressor's; malformed segments must report the reference's status codes."""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from starflate_amd import _capi, synth
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 32768
+
+
+def _inputs(starfleet):
+    rng = np.random.default_rng(7)
+    text = synth.gen_text(200_000, seed=2)
+    return {
+        "empty": np.zeros(0, np.uint8),
+        "one": np.array([65], np.uint8),
+        "tiny_rep": np.frombuffer(b"abcabcabcabcabcabcabcabcabc", np.uint8),
+        "zeros_ragged": np.zeros(CHUNK * 2 + 777, np.uint8),
+        "text_ragged": text[: CHUNK * 5 + 1234],
+        "text_chunk_minus1": text[: CHUNK - 1],
+        "starfleet": np.frombuffer(starfleet, np.uint8),
+        "random": rng.integers(0, 256, CHUNK * 3 + 5, dtype=np.uint8),
+        "low_entropy": rng.integers(0, 4, CHUNK + 99, dtype=np.uint8),
+        "period7": np.tile(np.arange(7, dtype=np.uint8), 9000),
+        "period300": np.tile(rng.integers(0, 256, 300, dtype=np.uint8), 400),
+        "mixed": synth.gen_mixed(3 << 20, seed=4, stripe=1 << 16)[: (1 << 20) + 13],
+    }
+
+
+def _gpu_roundtrip(compressor, data, **kw):
+    import torch
+
+    src = torch.from_numpy(data).cuda() if data.size else torch.empty(0, dtype=torch.uint8, device="cuda")
+    out, n = compressor.compress_tensor(src, **kw)
+    index = compressor.last_index(device="cuda")
+    stream = out[:n].clone()
+    back, status = compressor.decompress_tensor(stream, index, data.size)
+    return stream.cpu().numpy(), index.cpu().numpy().astype(np.uint64), back.cpu().numpy(), status
+
+
+@pytest.mark.parametrize("strategy", ["auto", "stored", "fixed", "dynamic"])
+def test_inflate_own_streams_equals_reference_decoder(compressor, starfleet, strategy):
+    for name, data in _inputs(starfleet).items():
+        stream, index, back, status = _gpu_roundtrip(compressor, data, strategy=strategy)
+        assert status == 0, (name, status)
+        st, w, ref = O.decompress(stream, data.size)  # the reference restatement on the same stream
+        assert st == 0 and w == data.size
+        assert np.array_equal(back, ref[: data.size]) and np.array_equal(back, data), name
+        nseg = max(1, (data.size + CHUNK - 1) // CHUNK)
+        assert index.size == nseg + 1 and index[0] == 0 and index[-1] == stream.size
+        assert np.all(np.diff(index.astype(np.int64)) > 0)
+
+
+def test_decoder_tokens_equal_compressor_tokens(compressor):
+    """k_inflate_tokens inverts k_emit exactly: the token stream it recovers is the one k_lz77 produced."""
+    import torch
+
+    data = synth.gen_text(CHUNK * 6 + 99, seed=13)
+    nch = 7
+    src = torch.from_numpy(data).cuda()
+    out, n = compressor.compress_tensor(src, strategy="dynamic")
+    index = compressor.last_index(device="cuda")
+    ntok_c = compressor.debug(_capi.DBG_NTOK, nch).copy()
+    tok_c = compressor.debug(_capi.DBG_TOKENS, nch).copy()
+    back, status = compressor.decompress_tensor(out[:n].clone(), index, data.size)
+    assert status == 0 and np.array_equal(back.cpu().numpy(), data)
+    ntok_d = compressor.debug(_capi.DBG_NTOK, nch)  # untouched by the decoder: counts live in the segment records
+    tok_d = compressor.debug(_capi.DBG_TOKENS, nch)
+    assert np.array_equal(ntok_c, ntok_d)
+    for c in range(nch):
+        k = int(ntok_c[c])
+        assert np.array_equal(tok_c[c, :k], tok_d[c, :k]), c
+
+
+@pytest.mark.parametrize("container", ["zlib", "gzip"])
+def test_inflate_wrapped_streams(compressor, starfleet, container):
+    """The index of a wrapped stream points past the wrapper header, so the same call decodes it in place."""
+    data = np.frombuffer(starfleet, np.uint8)
+    stream, index, back, status = _gpu_roundtrip(compressor, data, container=container)
+    h, t = (2, 4) if container == "zlib" else (10, 8)
+    assert status == 0 and np.array_equal(back, data)
+    assert index[0] == h and index[-1] == stream.size - t
+    assert zlib.decompress(stream.tobytes(), 15 if container == "zlib" else 31) == data.tobytes()
+
+
+@pytest.mark.parametrize("level,strategy", [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                            (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (0, zlib.Z_DEFAULT_STRATEGY)])
+def test_inflate_zlib_made_indexed_streams(compressor, starfleet, level, strategy):
+    """Streams this library did not write: zlib with Z_FULL_FLUSH every 32 KiB (3-byte matches, distances up to
+    32768, 15-bit codes, several blocks per segment, stored blocks inside segments)."""
+    for name, data in _inputs(starfleet).items():
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        nch = max(1, (data.size + CHUNK - 1) // CHUNK)
+        parts = []
+        for c in range(nch):
+            b = co.compress(data[c * CHUNK:(c + 1) * CHUNK].tobytes())
+            parts.append(b + co.flush(zlib.Z_FINISH if c == nch - 1 else zlib.Z_FULL_FLUSH))
+        stream = b"".join(parts)
+        index = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+        got, status = compressor.decompress(stream, index, data.size)  # host-buffer entry point
+        assert status == 0, (name, status)
+        assert got == data.tobytes(), name
+
+
+def test_malformed_segments_report_reference_statuses(compressor, starfleet):
+    data = np.frombuffer(starfleet, np.uint8)
+    nseg = (data.size + CHUNK - 1) // CHUNK
+    raw = np.frombuffer(compressor.compress(data, strategy="stored"), np.uint8).copy()
+    idx = compressor.last_index()
+    assert compressor.decompress(raw, idx, data.size) == (data.tobytes(), 0)
+    bad = raw.copy()
+    bad[int(idx[2]) + 3] ^= 1  # NLEN of the third stored block
+    assert compressor.decompress(bad, idx, data.size)[1] == 3  # NoCompressionLenMismatch
+    bad = raw.copy()
+    bad[int(idx[1])] |= 0b110  # BTYPE 3 in the second segment; the first failing segment in stream order wins
+    bad[int(idx[3]) + 3] ^= 1
+    assert compressor.decompress(bad, idx, data.size)[1] == 2  # InvalidBlockHeader
+    dyn = np.frombuffer(compressor.compress(data, strategy="dynamic"), np.uint8).copy()
+    idx = compressor.last_index()
+    assert compressor.decompress(dyn, idx, data.size) == (data.tobytes(), 0)
+    cut = idx.copy()
+    cut[1:] -= np.uint64(100)  # every segment starts 100 bytes early: garbage
+    assert compressor.decompress(dyn, cut, data.size)[1] != 0
+    short = idx.copy()
+    short[-1] -= np.uint64(40)  # last segment truncated
+    assert compressor.decompress(dyn[: int(short[-1])], short, data.size)[1] in (5, 6, 7)
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, dyn.size, dtype=np.uint8)
+    assert compressor.decompress(noise, idx, data.size)[1] != 0  # garbage never crashes, never reports success
+    with pytest.raises(Exception):  # nseg must match the output size
+        compressor.decompress(dyn, idx[:-1], data.size)
+    assert nseg + 1 == idx.size
+
+
+def test_inflate_large_roundtrip_and_timing(compressor):
+    import torch
+
+    data = synth.gen_text(64 << 20, seed=3)
+    src = torch.from_numpy(data).cuda()
+    out, n = compressor.compress_tensor(src)
+    index = compressor.last_index(device="cuda")
+    stream = out[:n].clone()
+    compressor.set_profiling(True)
+    back, status = compressor.decompress_tensor(stream, index, data.size)
+    assert status == 0 and torch.equal(back, src)
+    ms = compressor.inflate_ms()
+    compressor.set_profiling(False)
+    print("inflate 64 MiB:", ms)
+    back2, status2 = compressor.decompress_tensor(stream, index, data.size)  # deterministic
+    assert status2 == 0 and torch.equal(back2, back)
