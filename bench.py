@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=4, help="N > 1: block-cyclic rounds per rank (gather/compute overlap)")
     ap.add_argument("--container", default="raw", choices=["raw", "zlib", "gzip"],
                     help="wrap the stream (RFC 1950 / 1952); the checksum kernels are then inside the timed step")
+    ap.add_argument("--no-decompress", action="store_true", help="skip the GPU decompress leg (N = 1 only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N > 1 code path (RCCL group, rounds, gather) even with one rank")
     args = ap.parse_args()
@@ -217,6 +218,32 @@ def main():
         roofline["device"] = {"error": str(e)}
     kern_total_ms = sum(stage_ms.values())
 
+    # ---- GPU decompress of the stream just made: the reference's own function, on the GPU ----
+    decomp = None
+    if not multi and not args.no_decompress:
+        out_t, nb = comp.compress_tensor(data, out=scratch[0], container=args.container)
+        index = comp.last_index(device=dev)
+        subindex = comp.last_subindex(device=dev)
+        stream_t = out_t[:nb].clone()
+        back = torch.empty(n, dtype=torch.uint8, device=dev)
+        decomp = {}
+        for label, sub in (("sub_indexed", subindex), ("segment_indexed", None)):
+            back.zero_()
+            comp.decompress_tensor(stream_t, index, n, out=back, subindex=sub)  # warm-up
+            torch.cuda.synchronize()
+            reps = 3
+            td = time.perf_counter()
+            for _ in range(reps):
+                _, dstatus = comp.decompress_tensor(stream_t, index, n, out=back, subindex=sub)
+            torch.cuda.synchronize()
+            td = (time.perf_counter() - td) / reps
+            decomp[label] = {"value": round(n / td / 2**20, 1), "unit": "MiB/s of output", "ms": round(td * 1e3, 3),
+                             "status": dstatus, "equal_to_input": bool(torch.equal(back, data)),
+                             "kernel_ms": {k: round(v, 4) for k, v in comp.inflate_ms().items()}}
+        decomp["note"] = ("sub_indexed: chunk offsets + 32 region entries per chunk (sfh_copy_index, sfh_copy_subindex), "
+                          "32 lanes per segment; segment_indexed: chunk offsets only, one lane per segment (any indexed stream)")
+        del back, stream_t
+
     # ---- CPU baseline: oracle restatement of the reference decompress(), 1 thread ----
     cpu = None
     if not args.no_cpu_baseline and world == 1 and not args.force_dist:
@@ -265,7 +292,7 @@ def main():
         "ratio_vs_zlib6": round(ratio_ours_sample / ratio_zlib6, 4),
         "compressed_bytes": total_out, "roundtrip_ok": ok,
         "kernel_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "kernels_total_ms": round(kern_total_ms, 4),
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "decompress": decomp,
     }
     print(json.dumps(line), flush=True)
     if multi:

@@ -123,16 +123,27 @@ size_t sfh_index_entries(const sfh_ctx* ctx);
 /* copies that index to `dst` (host memory, or device memory if dst_on_device); synchronises `stream` */
 int sfh_copy_index(sfh_ctx* ctx, uint64_t* dst, size_t entries, int dst_on_device, void* stream);
 
-/* Device buffers (d_src 4-byte, d_index 8-byte, d_dst 16-byte aligned).  nseg must be ceil(dst_n / 32768)
+/* Sub-index of the last sfh_compress* call: per segment, for each of its 32 parse regions (1024 bytes of output;
+ * no match of this library's streams crosses them) {bit offset of the region's first token code counted from
+ * the segment's first byte, tokens before the region}: SFH_SUBINDEX_WORDS uint32 per segment, all zero for a
+ * stored segment.  Optional side information: with it 32 lanes decode one segment's Huffman codes side by
+ * side instead of one (the decoder checks it against the stream: a wrong sub-index is an error, never wrong
+ * output).  Streams from elsewhere have none and take the one-lane-per-segment path. */
+#define SFH_SUBINDEX_WORDS 64u
+int sfh_copy_subindex(sfh_ctx* ctx, uint32_t* dst, size_t words, int dst_on_device, void* stream);
+
+/* Device buffers (d_src 4-byte, d_index 8-byte, d_dst 16-byte aligned; d_subindex 4-byte aligned or NULL).
+ * nseg must be ceil(dst_n / 32768)
  * (1 for dst_n = 0); segment i decodes stream bytes [index[i], index[i+1]) into dst[i*32768 ...) and must
  * produce exactly that many bytes.  Returns SFH_OK when the kernels ran; *status is then the reference's
  * DecompressStatus (0 = Success) of the first failing segment in stream order; dst is complete only on 0.
  * Synchronises `stream` (NULL = the ctx's own). */
-int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const uint64_t* d_index, size_t nseg,
-                          void* d_dst, size_t dst_n, uint32_t* status, void* stream);
-/* Host buffers: H2D (stream + index), decode, D2H. */
-int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* index, size_t nseg, void* dst,
-                   size_t dst_n, uint32_t* status);
+int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const uint64_t* d_index,
+                          const uint32_t* d_subindex, size_t nseg, void* d_dst, size_t dst_n, uint32_t* status,
+                          void* stream);
+/* Host buffers: H2D (stream + index [+ sub-index, may be NULL]), decode, D2H. */
+int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* index, const uint32_t* subindex,
+                   size_t nseg, void* dst, size_t dst_n, uint32_t* status);
 
 #define SFH_INFLATE_NSTAGES 2 /* 0 k_inflate_tokens (Huffman decode), 1 k_inflate_bytes (match copies) */
 /* with profiling on: milliseconds per decoder kernel of the last sfh_decompress* call */
@@ -165,6 +176,7 @@ enum sfh_debug_what {
   SFH_DBG_PLAN = 3,   /* uint32[4] per chunk: btype, out_bytes, header_bits, body_bits */
   SFH_DBG_LENS = 4,   /* uint8[320] per chunk: ll lens [0..287], d lens [288..319] */
   SFH_DBG_OFFSETS = 5, /* uint64 per chunk */
+  SFH_DBG_SUBINDEX = 7, /* uint32[64] per chunk */
   SFH_DBG_STAMPS = 6   /* uint64[2][nchunks][8] (k_lz77, k_plan); only with env SFH_K1_STAMPS=1 at sfh_create
                           (diagnostic k_lz77 build: cycles per phase, never a timing claim) */
 };

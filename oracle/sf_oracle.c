@@ -726,10 +726,14 @@ void sfo_plan_chunk(const uint32_t* ll, const uint32_t* d, uint32_t n_raw, int i
 }
 
 /* Stage n4 for one chunk; dst zero-initialised by the caller. */
+/* sub (NULL or SFO_SUB_REGIONS pairs): per parse region the bit offset, from the chunk's first byte, of the
+ * region's first token code, and the number of tokens before it; regions past the data name the
+ * end-of-block code and the token total; a stored chunk has all zeros. */
 static void emit_chunk(const uint8_t* data, uint32_t n, const uint32_t* tokens,
                        const uint32_t* ntok, const sfo_params* p, const sfo_plan* plan,
-                       int is_last, uint8_t* dst) {
+                       int is_last, uint8_t* dst, uint32_t* sub) {
   int bfinal = is_last && p->final_stream;
+  if (sub) memset(sub, 0, 2 * SFO_SUB_REGIONS * sizeof(uint32_t));
   if (plan->btype == 0) {
     dst[0] = (uint8_t)bfinal; /* BFINAL, BTYPE=00, 5 pad bits */
     dst[1] = (uint8_t)(n & 0xFF);
@@ -755,8 +759,10 @@ static void emit_chunk(const uint8_t* data, uint32_t n, const uint32_t* tokens,
   uint32_t llc[288], dc[32];
   sfo_canonical_codes(ll_lens, 288, llc);
   sfo_canonical_codes(d_lens, 32, dc);
-  uint32_t nreg = (n + p->region_bytes - 1) / p->region_bytes;
-  for (uint32_t r = 0; r < nreg; r++)
+  uint32_t nreg = (n + p->region_bytes - 1) / p->region_bytes, seen = 0;
+  for (uint32_t r = 0; r < nreg; r++) {
+    if (sub && r < SFO_SUB_REGIONS) { sub[2 * r] = (uint32_t)w.bitpos; sub[2 * r + 1] = seen; }
+    seen += ntok[r];
     for (uint32_t k = 0; k < ntok[r]; k++) {
       uint32_t t = tokens[(size_t)r * p->region_bytes + k];
       if (t & SFO_TOK_MATCH) {
@@ -770,6 +776,8 @@ static void emit_chunk(const uint8_t* data, uint32_t n, const uint32_t* tokens,
         put_bits(&w, rev_bits(llc[t], ll_lens[t]), ll_lens[t]);
       }
     }
+  }
+  for (uint32_t r = nreg; sub && r < SFO_SUB_REGIONS; r++) { sub[2 * r] = (uint32_t)w.bitpos; sub[2 * r + 1] = seen; }
   put_bits(&w, rev_bits(llc[256], ll_lens[256]), ll_lens[256]);
   if (!bfinal) {
     /* byte-align with an empty non-final stored block: 000, pad, 00 00 FF FF */
@@ -838,6 +846,11 @@ uint32_t sfo_adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b)
 
 int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,
                  const sfo_params* p) {
+  return sfo_compress_indexed(src, n, dst, cap, out_len, p, NULL, NULL);
+}
+
+int sfo_compress_indexed(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,
+                         const sfo_params* p, uint64_t* index, uint32_t* subindex) {
   if (p->container) {
     if (p->container > 2 || !p->final_stream) return -1;
     static const uint8_t zhdr[2] = {0x78, 0x9C};
@@ -847,8 +860,12 @@ int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t*
     sfo_params raw = *p;
     raw.container = 0;
     size_t body = 0;
-    int rc = sfo_compress(src, n, dst + h, cap - h - t, &body, &raw);
+    int rc = sfo_compress_indexed(src, n, dst + h, cap - h - t, &body, &raw, index, subindex);
     if (rc) return rc;
+    if (index) {
+      size_t nch = n ? (n + p->chunk_bytes - 1) / p->chunk_bytes : 1;
+      for (size_t c = 0; c <= nch; c++) index[c] += h; /* offsets into the wrapped stream */
+    }
     memcpy(dst, p->container == 1 ? zhdr : ghdr, h);
     uint8_t* tr = dst + h + body;
     if (p->container == 1) {
@@ -888,11 +905,14 @@ int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t*
     sfo_plan_chunk(ll, d, cn, is_last, p, &plan);
     if (off + plan.out_bytes > cap) { rc = -2; goto out; }
     memset(tmp, 0, plan.out_bytes + 8);
-    emit_chunk(data, cn, tokens, ntok, p, &plan, is_last, tmp);
+    if (index) index[c] = off;
+    emit_chunk(data, cn, tokens, ntok, p, &plan, is_last, tmp,
+               subindex ? subindex + c * 2 * SFO_SUB_REGIONS : NULL);
     memcpy(dst + off, tmp, plan.out_bytes);
     off += plan.out_bytes;
   }
   *out_len = off;
+  if (index) index[nchunks] = off;
 out:
   free(tmp);
   free(tokens);

@@ -121,6 +121,16 @@ uint32_t sfo_adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b)
 int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,
                  const sfo_params* p);
 
+/* Same stream, plus what makes it decodable in parallel (the GPU decoder's inputs):
+ *  index    [nchunks + 1]: first stream byte of every chunk's block, then the end of the last one;
+ *  subindex [nchunks][SFO_SUB_REGIONS][2] (NULL: not wanted; needs region_bytes * SFO_SUB_REGIONS >=
+ *           chunk_bytes): per parse region {bit offset of its first token code from the chunk's first
+ *           byte, tokens before it}; regions past the data name the end-of-block code / token total;
+ *           all zero for a stored chunk. */
+#define SFO_SUB_REGIONS 32u
+int sfo_compress_indexed(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,
+                         const sfo_params* p, uint64_t* index, uint32_t* subindex);
+
 /* stage n1: per-position best match for one chunk; len16[i] in {0, min_match..258} */
 void sfo_match_chunk(const uint8_t* data, uint32_t n, const sfo_params* p, uint16_t* len16,
                      uint16_t* dist16);

@@ -14,12 +14,14 @@ SEGMENT_BYTES = 32768
 STRATEGY = {"auto": 0, "stored": 1, "fixed": 2, "dynamic": 3}
 CONTAINER = {"raw": 0, "zlib": 1, "gzip": 2}
 DBG_NTOK, DBG_TOKENS, DBG_HIST, DBG_PLAN, DBG_LENS, DBG_OFFSETS, DBG_STAMPS = range(7)
+DBG_SUBINDEX = 7
+SUBINDEX_WORDS = 64
 
 # every symbol include/starflate_hip.h declares
 EXPORTS = [
     "sfh_default_options", "sfh_device_count", "sfh_get_device_props", "sfh_create", "sfh_destroy", "sfh_last_error",
     "sfh_compress_bound", "sfh_compress", "sfh_compress_device", "sfh_compress_device_async",
-    "sfh_index_entries", "sfh_copy_index", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms",
+    "sfh_index_entries", "sfh_copy_index", "sfh_copy_subindex", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms",
     "sfh_inflate_stage_name", "sfh_checksum_device", "sfh_crc32_combine", "sfh_adler32_combine",
     "sfh_set_profiling", "sfh_last_stage_ms", "sfh_stage_name", "sfh_debug_read",
 ]
@@ -83,9 +85,11 @@ def lib():
     L.sfh_index_entries.restype = sz
     L.sfh_copy_index.argtypes = [vp, vp, sz, C.c_int, vp]
     L.sfh_copy_index.restype = C.c_int
-    L.sfh_decompress_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.POINTER(C.c_uint32), vp]
+    L.sfh_copy_subindex.argtypes = [vp, vp, sz, C.c_int, vp]
+    L.sfh_copy_subindex.restype = C.c_int
+    L.sfh_decompress_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, C.POINTER(C.c_uint32), vp]
     L.sfh_decompress_device.restype = C.c_int
-    L.sfh_decompress.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.POINTER(C.c_uint32)]
+    L.sfh_decompress.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, C.POINTER(C.c_uint32)]
     L.sfh_decompress.restype = C.c_int
     L.sfh_last_inflate_ms.argtypes = [vp, C.POINTER(C.c_float * INFLATE_NSTAGES)]
     L.sfh_last_inflate_ms.restype = C.c_int

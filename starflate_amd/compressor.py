@@ -116,9 +116,28 @@ class Compressor:
         self._check(self._lib.sfh_copy_index(self._h, idx.data_ptr(), n, 1, C.c_void_p(s)))
         return idx
 
-    def decompress_tensor(self, stream, index, out_n, out=None, hip_stream=None):
+    def last_subindex(self, device=None):
+        """Sub-index of the last compress call (32 x {bit offset, tokens before} per segment): numpy uint32
+        array [segments, 32, 2], or (device given) an int32 tensor of that shape on the CUDA device."""
+        nseg = self._lib.sfh_index_entries(self._h) - 1
+        if nseg < 0:
+            raise StarflateError(-1, "no compress call on this context yet")
+        words = nseg * _capi.SUBINDEX_WORDS
+        if device is None:
+            sub = np.empty((nseg, 32, 2), dtype=np.uint32)
+            self._check(self._lib.sfh_copy_subindex(self._h, sub.ctypes.data, words, 0, None))
+            return sub
+        import torch
+
+        sub = torch.empty((nseg, 32, 2), dtype=torch.int32, device=device)
+        s = torch.cuda.current_stream(sub.device).cuda_stream
+        self._check(self._lib.sfh_copy_subindex(self._h, sub.data_ptr(), words, 1, C.c_void_p(s)))
+        return sub
+
+    def decompress_tensor(self, stream, index, out_n, out=None, hip_stream=None, subindex=None):
         """stream: 1-D uint8 CUDA tensor (exactly the compressed bytes); index: int64 CUDA tensor of segments + 1
-        offsets; out_n: decompressed size.  Returns (out tensor, DecompressStatus int, 0 = Success)."""
+        offsets; subindex: optional int32 CUDA tensor [segments, 32, 2] (last_subindex); out_n: decompressed size.
+        Returns (out tensor, DecompressStatus int, 0 = Success)."""
         import torch
 
         self._check_tensor(stream)
@@ -132,17 +151,25 @@ class Compressor:
             raise ValueError("out is smaller than out_n")
         st = C.c_uint32(0)
         s = torch.cuda.current_stream(stream.device).cuda_stream if hip_stream is None else hip_stream
-        self._check(self._lib.sfh_decompress_device(self._h, stream.data_ptr(), stream.numel(), index.data_ptr(), nseg,
+        if subindex is not None and not (subindex.is_cuda and subindex.dtype == torch.int32 and subindex.is_contiguous()
+                                         and subindex.numel() == nseg * _capi.SUBINDEX_WORDS):
+            raise ValueError("subindex must be a contiguous int32 CUDA tensor of segments * 64 words")
+        self._check(self._lib.sfh_decompress_device(self._h, stream.data_ptr(), stream.numel(), index.data_ptr(),
+                                                    subindex.data_ptr() if subindex is not None else None, nseg,
                                                     out.data_ptr() if out_n else None, int(out_n), C.byref(st), C.c_void_p(s)))
         return out[:out_n], st.value
 
-    def decompress(self, data, index, out_n):
-        """Host buffers: bytes-like stream + numpy uint64 index -> (bytes, DecompressStatus int)."""
+    def decompress(self, data, index, out_n, subindex=None):
+        """Host buffers: bytes-like stream + numpy uint64 index [+ numpy uint32 sub-index] -> (bytes, DecompressStatus int)."""
         src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         idx = np.ascontiguousarray(index, dtype=np.uint64)
         dst = np.empty(max(int(out_n), 1), dtype=np.uint8)
         st = C.c_uint32(0)
-        self._check(self._lib.sfh_decompress(self._h, src.ctypes.data, src.size, idx.ctypes.data, idx.size - 1,
+        sub = None if subindex is None else np.ascontiguousarray(subindex, dtype=np.uint32)
+        if sub is not None and sub.size != (idx.size - 1) * _capi.SUBINDEX_WORDS:
+            raise ValueError("subindex must hold segments * 64 words")
+        self._check(self._lib.sfh_decompress(self._h, src.ctypes.data, src.size, idx.ctypes.data,
+                                             sub.ctypes.data if sub is not None else None, idx.size - 1,
                                              dst.ctypes.data if out_n else None, int(out_n), C.byref(st)))
         return (dst[:out_n].tobytes() if st.value == 0 else b""), st.value
 
@@ -189,6 +216,7 @@ class Compressor:
             _capi.DBG_LENS: ((nchunks, 320), np.uint8),
             _capi.DBG_OFFSETS: ((nchunks,), np.uint64),
             _capi.DBG_STAMPS: ((2, nchunks, 8), np.uint64),  # [0] k_lz77 phases, [1] k_plan phases
+            _capi.DBG_SUBINDEX: ((nchunks, 32, 2), np.uint32),
         }
         shape, dt = shapes[what]
         a = np.empty(shape, dtype=dt)

@@ -20,6 +20,8 @@ struct sfh_ctx {
   uint32_t* d_value = nullptr;   // result slot of sfh_checksum_device; [2] for the decoder's status
   uint64_t* d_index = nullptr;   // staging for the host-buffer decoder
   size_t d_index_cap = 0;
+  uint32_t* d_sub = nullptr;
+  size_t d_sub_cap = 0;
   hipEvent_t ev_inf[SFH_INFLATE_NSTAGES + 1] = {};
   bool ev_inf_valid = false;
   uint8_t* d_in = nullptr;       // staging for the host-buffer entry point
@@ -54,6 +56,8 @@ void free_ws(sfh_ctx* c) {
   (void)hipFree(c->ws.offsets);
   (void)hipFree(c->ws.stamps);
   (void)hipFree(c->ws.seginfo);
+  (void)hipFree(c->ws.rtok);
+  (void)hipFree(c->ws.subidx);
   uint32_t* keep = c->ws.sums;  // sized on its own (ensure_sums)
   c->ws = sf::Workspace{};
   c->ws.sums = keep;
@@ -83,7 +87,9 @@ int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
       (e = hipMalloc(&ctx->ws.plan, nc * sizeof(sf::ChunkPlan))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.codes, nc * sizeof(sf::ChunkCodes))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.offsets, (nc + 1) * sizeof(uint64_t))) != hipSuccess ||
-      (e = hipMalloc(&ctx->ws.seginfo, nc * sizeof(sf::SegInfo))) != hipSuccess) {
+      (e = hipMalloc(&ctx->ws.seginfo, nc * sizeof(sf::SegInfo))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.rtok, nc * sf::kSubRegions * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.subidx, nc * 2 * sf::kSubRegions * sizeof(uint32_t))) != hipSuccess) {
     free_ws(ctx);
     return fail(ctx, SFH_E_NOMEM, "workspace hipMalloc", e);
   }
@@ -115,6 +121,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   sfh_options o;
   if (opt) o = *opt; else sfh_default_options(&o);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  (void)hipGetLastError();  // launches are checked with hipGetLastError(): drop whatever an earlier caller on this thread left
   const uint32_t nchunks = chunks_of(n);
   int rc = ensure_ws(ctx, nchunks);
   if (!rc && o.container) rc = ensure_sums(ctx, nchunks);
@@ -219,6 +226,7 @@ void sfh_destroy(sfh_ctx* ctx) {
   (void)hipFree(ctx->d_total);
   (void)hipFree(ctx->d_value);
   (void)hipFree(ctx->d_index);
+  (void)hipFree(ctx->d_sub);
   for (int k = 0; k <= SFH_INFLATE_NSTAGES; ++k)
     if (ctx->ev_inf[k]) (void)hipEventDestroy(ctx->ev_inf[k]);
   (void)hipFree(ctx->d_in);
@@ -301,14 +309,27 @@ int sfh_copy_index(sfh_ctx* ctx, uint64_t* dst, size_t entries, int dst_on_devic
   return SFH_OK;
 }
 
-int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const uint64_t* d_index, size_t nseg,
-                          void* d_dst, size_t dst_n, uint32_t* status, void* stream) {
+int sfh_copy_subindex(sfh_ctx* ctx, uint32_t* dst, size_t words, int dst_on_device, void* stream) {
+  if (!ctx || !dst || !ctx->index_valid || words != (size_t)ctx->last_chunks * SFH_SUBINDEX_WORDS)
+    return fail(ctx, SFH_E_INVALID_ARG, "sub-index: no compress call yet, or words != segments * 64", hipSuccess);
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  SF_HIP(hipMemcpyAsync(dst, ctx->ws.subidx, words * sizeof(uint32_t),
+                        dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s), "copy sub-index");
+  SF_HIP(hipStreamSynchronize(s), "stream sync");
+  return SFH_OK;
+}
+
+int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const uint64_t* d_index,
+                          const uint32_t* d_subindex, size_t nseg, void* d_dst, size_t dst_n, uint32_t* status,
+                          void* stream) {
   if (!ctx || !d_src || !d_index || !status || (!d_dst && dst_n)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
-  if (((uintptr_t)d_src & 3) || ((uintptr_t)d_index & 7) || ((uintptr_t)d_dst & 15))
-    return fail(ctx, SFH_E_INVALID_ARG, "device pointer alignment (src 4, index 8, dst 16)", hipSuccess);
+  if (((uintptr_t)d_src & 3) || ((uintptr_t)d_index & 7) || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_subindex & 3))
+    return fail(ctx, SFH_E_INVALID_ARG, "device pointer alignment (src 4, index 8, dst 16, sub-index 4)", hipSuccess);
   if (dst_n > ((size_t)1 << 44) || nseg != (size_t)chunks_of(dst_n))
     return fail(ctx, SFH_E_INVALID_ARG, "nseg != ceil(dst_n / 32768)", hipSuccess);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  (void)hipGetLastError();  // see enqueue()
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int rc = ensure_ws(ctx, (uint32_t)nseg);
   if (rc) return rc;
@@ -316,8 +337,12 @@ int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const u
   ctx->last_chunks = (uint32_t)nseg;
   const bool prof = ctx->profiling != 0;
   if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[0], s), "event");
-  SF_HIP(sf::launch_inflate_tokens((const uint8_t*)d_src, src_n, d_index, (uint32_t)nseg, dst_n, ctx->ws.tokens,
-                                   ctx->ws.seginfo, s), "launch k_inflate_tokens");
+  if (d_subindex)
+    SF_HIP(sf::launch_inflate_tokens_sub((const uint8_t*)d_src, src_n, d_index, d_subindex, (uint32_t)nseg, dst_n,
+                                         ctx->ws.tokens, ctx->ws.seginfo, s), "launch k_inflate_tokens_sub");
+  else
+    SF_HIP(sf::launch_inflate_tokens((const uint8_t*)d_src, src_n, d_index, (uint32_t)nseg, dst_n, ctx->ws.tokens,
+                                     ctx->ws.seginfo, s), "launch k_inflate_tokens");
   if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[1], s), "event");
   SF_HIP(sf::launch_inflate_bytes((const uint8_t*)d_src, src_n, (uint32_t)nseg, ctx->ws.tokens, ctx->ws.seginfo,
                                   (uint8_t*)d_dst, s), "launch k_inflate_bytes");
@@ -332,8 +357,8 @@ int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const u
   return SFH_OK;
 }
 
-int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* index, size_t nseg, void* dst,
-                   size_t dst_n, uint32_t* status) {
+int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* index, const uint32_t* subindex,
+                   size_t nseg, void* dst, size_t dst_n, uint32_t* status) {
   if (!ctx || !src || !index || !status || (!dst && dst_n)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   const size_t in_need = src_n ? src_n : 16, out_need = dst_n ? dst_n : 16;
@@ -353,15 +378,27 @@ int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* 
   }
   if (ctx->d_index_cap < nseg + 1) {
     (void)hipFree(ctx->d_index);
+  (void)hipFree(ctx->d_sub);
     ctx->d_index = nullptr;
     ctx->d_index_cap = 0;
     if (hipMalloc(&ctx->d_index, (nseg + 1) * sizeof(uint64_t)) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "index staging", hipSuccess);
     ctx->d_index_cap = nseg + 1;
   }
+  if (subindex && ctx->d_sub_cap < nseg * SFH_SUBINDEX_WORDS) {
+    (void)hipFree(ctx->d_sub);
+    ctx->d_sub = nullptr;
+    ctx->d_sub_cap = 0;
+    if (hipMalloc(&ctx->d_sub, nseg * SFH_SUBINDEX_WORDS * sizeof(uint32_t)) != hipSuccess)
+      return fail(ctx, SFH_E_NOMEM, "sub-index staging", hipSuccess);
+    ctx->d_sub_cap = nseg * SFH_SUBINDEX_WORDS;
+  }
   hipStream_t s = ctx->stream;
   if (src_n) SF_HIP(hipMemcpyAsync(ctx->d_in, src, src_n, hipMemcpyHostToDevice, s), "H2D");
   SF_HIP(hipMemcpyAsync(ctx->d_index, index, (nseg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s), "H2D index");
-  int rc = sfh_decompress_device(ctx, ctx->d_in, src_n, ctx->d_index, nseg, ctx->d_out, dst_n, status, s);
+  if (subindex)
+    SF_HIP(hipMemcpyAsync(ctx->d_sub, subindex, nseg * SFH_SUBINDEX_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, s), "H2D sub-index");
+  int rc = sfh_decompress_device(ctx, ctx->d_in, src_n, ctx->d_index, subindex ? ctx->d_sub : nullptr, nseg, ctx->d_out,
+                                 dst_n, status, s);
   if (rc) return rc;
   if (*status == 0 && dst_n) {
     SF_HIP(hipMemcpyAsync(dst, ctx->d_out, dst_n, hipMemcpyDeviceToHost, s), "D2H");
@@ -387,6 +424,7 @@ int sfh_checksum_device(sfh_ctx* ctx, const void* d_src, size_t n, uint32_t kind
   if ((uintptr_t)d_src & 15) return fail(ctx, SFH_E_INVALID_ARG, "device pointer alignment (src 16)", hipSuccess);
   if (n > ((size_t)1 << 44)) return fail(ctx, SFH_E_INVALID_ARG, "input too large", hipSuccess);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  (void)hipGetLastError();  // see enqueue()
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   const uint32_t nchunks = chunks_of(n);
   int rc = ensure_sums(ctx, nchunks);
@@ -429,6 +467,7 @@ int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes) {
     case SFH_DBG_HIST: p = ctx->ws.hist; avail = nc * sf::kHistStride * 4; break;
     case SFH_DBG_PLAN: p = ctx->ws.plan; avail = nc * sizeof(sf::ChunkPlan); break;
     case SFH_DBG_OFFSETS: p = ctx->ws.offsets; avail = nc * 8; break;
+    case SFH_DBG_SUBINDEX: p = ctx->ws.subidx; avail = nc * SFH_SUBINDEX_WORDS * 4; break;
     case SFH_DBG_STAMPS: p = ctx->ws.stamps; avail = p ? nc * 128 : 0; break;
     case SFH_DBG_LENS: {
       if (bytes > nc * 320) return SFH_E_INVALID_ARG;

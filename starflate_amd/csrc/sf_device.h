@@ -26,7 +26,9 @@ constexpr uint32_t kCap = 16;           // match-time compare width; longer matc
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kFar4 = 4096;        // a match of exactly 4 bytes beyond this distance is not used
 constexpr uint32_t kSkipSlack = 128;    // stored fast path: first 8 KiB with >= 8192-128 tokens => no further search
+constexpr uint32_t kSubRegions = kChunk / kRegion;  // 32 sub-index entries per chunk
 constexpr uint32_t kTokMatch = 0x80000000u;  // token: bit31 match, 16..23 len-3, 0..14 dist-1
+constexpr uint32_t kTokRegion = 0x40000000u; // k_lz77 -> k_emit only: first token of a parse region, region index in 24..28
 
 constexpr uint32_t kChecksumAdler32 = 1;  // = SFH_ZLIB
 constexpr uint32_t kChecksumCrc32 = 2;    // = SFH_GZIP
@@ -69,6 +71,8 @@ struct Workspace {
   uint64_t* stamps;   // [nchunks][8], diagnostic build only (SFH_K1_STAMPS=1), else null
   uint32_t* sums;     // [nchunks] checksum partials (container modes / sfh_checksum_device)
   SegInfo* seginfo;   // [nchunks] decoder only
+  uint32_t* rtok;     // [nchunks][32] tokens before each 1024-byte parse region (K1 -> K4)
+  uint32_t* subidx;   // [nchunks][32][2] sub-index: {bit offset of the region's first code, tokens before it}
 };
 
 struct Options {
@@ -99,6 +103,8 @@ hipError_t launch_wrap(const uint32_t* sums, uint32_t nchunks, uint64_t n, uint3
 hipError_t init_inflate_kernels();
 hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint64_t* index, uint32_t nseg, uint64_t dst_n,
                                  uint32_t* tokens, SegInfo* info, hipStream_t s);
+hipError_t launch_inflate_tokens_sub(const uint8_t* src, uint64_t src_n, const uint64_t* index, const uint32_t* subidx,
+                                     uint32_t nseg, uint64_t dst_n, uint32_t* tokens, SegInfo* info, hipStream_t s);
 hipError_t launch_inflate_bytes(const uint8_t* src, uint64_t src_n, uint32_t nseg, const uint32_t* tokens, SegInfo* info,
                                 uint8_t* dst, hipStream_t s);
 hipError_t launch_inflate_status(const SegInfo* info, uint32_t nseg, uint32_t* d_result, hipStream_t s);

@@ -204,7 +204,8 @@ SF_HD uint32_t decode_symbol(const uint8_t* m, const BitReader& br, uint32_t& sy
   return 0;
 }
 
-// Token sink: groups four tokens into one 16-byte store (the GPU lanes write 128 KiB apart).
+// Token sinks.  Aligned: groups four tokens into one 16-byte store (the lane-per-segment kernel's lanes write
+// 128 KiB apart).  Plain: one dword per token (region lanes start at arbitrary token indices).
 struct alignas(16) Tok4 {
   uint32_t a, b, c, d;
 };
@@ -217,9 +218,7 @@ struct TokenSink {
     if (k == 0) q0 = t;
     else if (k == 1) q1 = t;
     else if (k == 2) q2 = t;
-    else {
-      *reinterpret_cast<Tok4*>(out + (n & ~3u)) = Tok4{q0, q1, q2, t};  // one dwordx4 store
-    }
+    else *reinterpret_cast<Tok4*>(out + (n & ~3u)) = Tok4{q0, q1, q2, t};  // one dwordx4 store
     ++n;
   }
   SF_HD void flush() {
@@ -230,6 +229,138 @@ struct TokenSink {
     if (k > 2) p[2] = q2;
   }
 };
+struct PlainSink {
+  uint32_t* out;
+  uint32_t n;
+  SF_HD void put(uint32_t t) { out[n++] = t; }
+  SF_HD void flush() {}
+};
+
+// Code lengths of a fixed (type 1, src/decompress.cpp:25-40) or dynamic (type 2, :253-367) block into the
+// tables of `m`; for type 2 the header is read from `br`.  Returns a status.
+SF_HD uint32_t read_tables(BitReader& br, uint8_t* m, uint32_t type) {
+  uint8_t* lens = m + kOffLens;
+  if (type == 1) {
+    for (uint32_t s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+    for (uint32_t s = 0; s < 32; ++s) lens[288 + s] = 5;
+  } else {
+    br.refill();
+    if (br.bitpos + 14 > br.nbits) return kSrcTooSmall;
+    const uint32_t hlit = br.get(5) + 257, hdist = br.get(5) + 1, hclen = br.get(4) + 4;
+    if (br.bitpos + 3ull * hclen > br.nbits) return kSrcTooSmall;
+    uint8_t* cl = m + kOffDFast;  // the distance tables are built after the header: borrow their memory
+    for (uint32_t k = 0; k < 19; ++k) cl[k] = 0;
+    for (uint32_t k = 0; k < hclen; ++k) {
+      br.refill();
+      // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (src/decompress.cpp:250-251)
+      const uint32_t order = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 8 + ((k - 4) >> 1);
+      cl[order] = (uint8_t)br.get(3);
+    }
+    // code-length code: counts and sorted symbols (<= 7 bits), canonical walk per symbol
+    uint8_t* ccnt = m + kOffDSym;      // u8[8]
+    uint8_t* csym = m + kOffDSym + 8;  // u8[19]
+    for (uint32_t l = 0; l < 8; ++l) ccnt[l] = 0;
+    for (uint32_t s = 0; s < 19; ++s) ccnt[cl[s]]++;
+    ccnt[0] = 0;
+    {
+      uint32_t at = 0;
+      for (uint32_t l = 1; l < 8; ++l)
+        for (uint32_t s = 0; s < 19; ++s)
+          if (cl[s] == l) csym[at++] = (uint8_t)s;
+    }
+    const uint32_t total = hlit + hdist;
+    uint32_t i = 0, prev = 0;
+    while (i < total) {
+      br.refill();
+      if (br.overrun()) return kSrcTooSmall;
+      uint32_t bits = (uint32_t)br.buf, code = 0, first = 0, index = 0, sym = 19, used = 0;
+      for (uint32_t l = 1; l <= 7; ++l) {
+        code |= bits & 1u;
+        bits >>= 1;
+        const uint32_t c = ccnt[l];
+        if (code < first + c) { sym = csym[index + (code - first)]; used = l; break; }
+        index += c;
+        first = (first + c) << 1;
+        code <<= 1;
+      }
+      if (sym > 18) return kError;
+      br.drop(used);
+      if (sym < 16) {
+        lens[i++] = (uint8_t)sym;
+        prev = sym;
+      } else {
+        uint32_t rep, val = 0;
+        if (sym == 16) {
+          if (i == 0) return kError;  // nothing to repeat (src/decompress.cpp:278)
+          val = prev;
+          rep = 3 + br.get(2);
+        } else if (sym == 17) {
+          rep = 3 + br.get(3);
+        } else {
+          rep = 11 + br.get(7);
+        }
+        if (i + rep > total) return kError;  // run past the last length
+        for (uint32_t k = 0; k < rep; ++k) lens[i++] = (uint8_t)val;
+        prev = val;
+      }
+    }
+    if (br.overrun()) return kSrcTooSmall;
+    // move the distance lengths to their fixed place [288..) so both layouts look alike (downwards: the
+    // ranges may overlap and the destination is the higher one)
+    if (hlit < 288) {
+      for (uint32_t s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];
+      for (uint32_t s = hlit; s < 288; ++s) lens[s] = 0;
+    }
+    for (uint32_t s = hdist; s < 32; ++s) lens[288 + s] = 0;
+  }
+  build_tables<true>(m, 0, 288);
+  build_tables<false>(m, 288, 32);
+  return kOk;
+}
+
+// Symbol loop (src/decompress.cpp:122-187) until the end-of-block code or, if sooner, until `end_bit` bits of
+// the segment are consumed (a region lane stops where the next region starts).  out_pos: bytes of the segment
+// produced before / after; out_limit: where this caller's output must end at the latest.
+template <class Sink>
+SF_HD uint32_t decode_symbols(BitReader& br, const uint8_t* m, Sink& sink, uint32_t& out_pos, uint32_t out_limit,
+                              uint64_t end_bit, bool& hit_eob) {
+  hit_eob = false;
+  while (br.bitpos < end_bit) {
+    br.refill();
+    uint32_t sym;
+    const uint32_t l = decode_symbol<true>(m, br, sym);
+    if (l == 0) return kInvalidLitOrLen;
+    br.drop(l);
+    if (sym < 256) {
+      if (out_pos >= out_limit) return kDstTooSmall;
+      sink.put(sym);
+      ++out_pos;
+      continue;
+    }
+    if (sym == 256) {
+      hit_eob = true;
+      break;
+    }
+    if (sym > 285) return kInvalidLitOrLen;
+    uint32_t lbase, lextra;
+    length_info(sym, lbase, lextra);
+    const uint32_t len = lbase + br.get(lextra);
+    br.refill();
+    uint32_t dsym;
+    const uint32_t dl = decode_symbol<false>(m, br, dsym);
+    if (dl == 0 || dsym > 29) return kInvalidDistance;
+    br.drop(dl);
+    uint32_t dbase, dextra;
+    distance_info(dsym, dbase, dextra);
+    const uint32_t dist = dbase + br.get(dextra);
+    if (dist > out_pos) return kInvalidDistance;  // src/decompress.cpp:178
+    if (len > out_limit - out_pos) return kDstTooSmall;
+    sink.put(kTokMatchBit | ((len - 3) << 16) | (dist - 1));
+    out_pos += len;
+    if (br.overrun()) return kSrcTooSmall;
+  }
+  return br.overrun() ? (uint32_t)kSrcTooSmall : (uint32_t)kOk;
+}
 
 // Decodes the blocks of one segment: stream bytes [seg_begin, seg_end) of `src`, which must produce exactly
 // out_n (<= 32768) bytes.  Tokens go to tokens[0..ntok).  `m`: kLaneBytes of scratch.
@@ -284,119 +415,10 @@ SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t 
       br.seek(data_at + len);
       continue;
     }
-    if (type == 1) {
-      // fixed: src/decompress.cpp:25-40
-      uint8_t* lens = m + kOffLens;
-      for (uint32_t s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-      for (uint32_t s = 0; s < 32; ++s) lens[288 + s] = 5;
-    } else {
-      // dynamic: src/decompress.cpp:314-367
-      br.refill();
-      if (br.bitpos + 14 > br.nbits) { status = kSrcTooSmall; break; }
-      const uint32_t hlit = br.get(5) + 257, hdist = br.get(5) + 1, hclen = br.get(4) + 4;
-      if (br.bitpos + 3ull * hclen > br.nbits) { status = kSrcTooSmall; break; }
-      uint8_t* cl = m + kOffDFast;  // the distance tables are built after the header: borrow their memory
-      for (uint32_t k = 0; k < 19; ++k) cl[k] = 0;
-      for (uint32_t k = 0; k < hclen; ++k) {
-        br.refill();
-        // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (src/decompress.cpp:250-251)
-        const uint32_t order = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 8 + ((k - 4) >> 1);
-        cl[order] = (uint8_t)br.get(3);
-      }
-      // code-length code: counts and sorted symbols (<= 7 bits), canonical walk per symbol
-      uint8_t* ccnt = m + kOffDSym;        // u8[8]
-      uint8_t* csym = m + kOffDSym + 8;    // u8[19]
-      for (uint32_t l = 0; l < 8; ++l) ccnt[l] = 0;
-      for (uint32_t s = 0; s < 19; ++s) ccnt[cl[s]]++;
-      ccnt[0] = 0;
-      {
-        uint32_t at = 0;
-        for (uint32_t l = 1; l < 8; ++l)
-          for (uint32_t s = 0; s < 19; ++s)
-            if (cl[s] == l) csym[at++] = (uint8_t)s;
-      }
-      uint8_t* lens = m + kOffLens;
-      const uint32_t total = hlit + hdist;
-      uint32_t i = 0, prev = 0;
-      while (i < total && status == kOk) {
-        br.refill();
-        if (br.overrun()) { status = kSrcTooSmall; break; }
-        uint32_t bits = (uint32_t)br.buf, code = 0, first = 0, index = 0, sym = 19, used = 0;
-        for (uint32_t l = 1; l <= 7; ++l) {
-          code |= bits & 1u;
-          bits >>= 1;
-          const uint32_t c = ccnt[l];
-          if (code < first + c) { sym = csym[index + (code - first)]; used = l; break; }
-          index += c;
-          first = (first + c) << 1;
-          code <<= 1;
-        }
-        if (sym > 18) { status = kError; break; }
-        br.drop(used);
-        if (sym < 16) {
-          lens[i++] = (uint8_t)sym;
-          prev = sym;
-        } else {
-          uint32_t rep, val = 0;
-          if (sym == 16) {
-            if (i == 0) { status = kError; break; }  // nothing to repeat (src/decompress.cpp:278)
-            val = prev;
-            rep = 3 + br.get(2);
-          } else if (sym == 17) {
-            rep = 3 + br.get(3);
-          } else {
-            rep = 11 + br.get(7);
-          }
-          if (i + rep > total) { status = kError; break; }  // run past the last length
-          for (uint32_t k = 0; k < rep; ++k) lens[i++] = (uint8_t)val;
-          prev = val;
-        }
-      }
-      if (status != kOk) break;
-      if (br.overrun()) { status = kSrcTooSmall; break; }
-      // move the distance lengths to their fixed place [288..) so both layouts look alike (downwards: the
-      // ranges may overlap and the destination is the higher one)
-      if (hlit < 288) {
-        for (uint32_t s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];
-        for (uint32_t s = hlit; s < 288; ++s) lens[s] = 0;
-      }
-      for (uint32_t s = hdist; s < 32; ++s) lens[288 + s] = 0;
-    }
-    build_tables<true>(m, 0, 288);
-    build_tables<false>(m, 288, 32);
-    // symbol loop: src/decompress.cpp:122-187
-    for (;;) {
-      br.refill();
-      uint32_t sym;
-      const uint32_t l = decode_symbol<true>(m, br, sym);
-      if (l == 0) { status = kInvalidLitOrLen; break; }
-      br.drop(l);
-      if (sym < 256) {
-        if (out_pos >= out_n) { status = kDstTooSmall; break; }
-        sink.put(sym);
-        ++out_pos;
-        continue;
-      }
-      if (sym == 256) break;
-      if (sym > 285) { status = kInvalidLitOrLen; break; }
-      uint32_t lbase, lextra;
-      length_info(sym, lbase, lextra);
-      const uint32_t len = lbase + br.get(lextra);
-      br.refill();
-      uint32_t dsym;
-      const uint32_t dl = decode_symbol<false>(m, br, dsym);
-      if (dl == 0 || dsym > 29) { status = kInvalidDistance; break; }
-      br.drop(dl);
-      uint32_t dbase, dextra;
-      distance_info(dsym, dbase, dextra);
-      const uint32_t dist = dbase + br.get(dextra);
-      if (dist > out_pos) { status = kInvalidDistance; break; }   // src/decompress.cpp:178
-      if (len > out_n - out_pos) { status = kDstTooSmall; break; }
-      sink.put(kTokMatchBit | ((len - 3) << 16) | (dist - 1));
-      out_pos += len;
-      if (br.overrun()) { status = kSrcTooSmall; break; }
-    }
-    if (status == kOk && br.overrun()) status = kSrcTooSmall;
+    status = read_tables(br, m, type);
+    if (status != kOk) break;
+    bool eob;
+    status = decode_symbols(br, m, sink, out_pos, out_n, ~0ull, eob);
   }
   if (status == kOk && out_pos != out_n) status = kSrcTooSmall;  // the index promised more bytes
   if (status == kOk && r.raw && sink.n != 0) status = kDstTooSmall;
@@ -404,6 +426,72 @@ SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t 
   r.status = status;
   r.ntok = sink.n;
   return r;
+}
+
+// ---- sub-indexed segments (streams of this library: one block per segment, 32 parse regions of 1024 bytes
+// ---- whose first token codes are located by the sub-index) ----
+
+// First lane of a segment: block header and code tables.  raw != 0: stored segment (bytes at raw_off).
+// hdr_end: bit offset, from the segment's first byte, of the first token code.
+SF_HD uint32_t open_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end, uint32_t out_n,
+                            uint8_t* m, uint32_t& raw, uint64_t& raw_off, uint64_t& hdr_end) {
+  raw = 0;
+  raw_off = 0;
+  hdr_end = 0;
+  if (seg_begin > seg_end || seg_end > src_n) return kSrcTooSmall;
+  BitReader br;
+  br.base = src;
+  br.src_n = src_n;
+  br.bitpos = 0;
+  br.nbits = 8 * (seg_end - seg_begin);
+  br.seek(seg_begin);
+  if (br.nbits < 3) return kInvalidBlockHeader;
+  br.refill();
+  br.drop(1);  // BFINAL: the segment ends with its block either way
+  const uint32_t type = br.get(2);
+  if (type == 3) return kInvalidBlockHeader;
+  if (type == 0) {
+    br.drop(5);
+    if (br.nbits < 40) return kSrcTooSmall;
+    const uint32_t len = br.get(16);
+    br.refill();
+    const uint32_t nlen = br.get(16);
+    if ((len ^ nlen) != 0xFFFFu) return kNoCompressionLenMismatch;
+    if (40 + 8ull * len > br.nbits) return kSrcTooSmall;
+    if (len != out_n) return len > out_n ? kDstTooSmall : kSrcTooSmall;
+    raw = 1;
+    raw_off = seg_begin + 5;
+    return kOk;
+  }
+  const uint32_t st = read_tables(br, m, type);
+  hdr_end = br.bitpos;
+  return st;
+}
+
+// One region lane: token codes from bit `bit_begin` of the segment up to `bit_end` (or to the end-of-block code
+// when until_eob), which must produce exactly the bytes [out_begin, out_end) of the segment.
+SF_HD uint32_t decode_region(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end, uint64_t bit_begin,
+                             uint64_t bit_end, bool until_eob, uint32_t out_begin, uint32_t out_end, uint32_t* tokens,
+                             const uint8_t* m, uint32_t& ntok) {
+  ntok = 0;
+  BitReader br;
+  br.base = src;
+  br.src_n = src_n;
+  br.nbits = 8 * (seg_end - seg_begin);
+  if (bit_begin > br.nbits || (!until_eob && (bit_end < bit_begin || bit_end > br.nbits))) return kError;
+  br.seek(seg_begin + (bit_begin >> 3));
+  br.bitpos = bit_begin & ~7ull;
+  br.refill();
+  br.drop((uint32_t)(bit_begin & 7));
+  PlainSink sink{tokens, 0};
+  uint32_t out_pos = out_begin;
+  bool eob;
+  const uint32_t st = decode_symbols(br, m, sink, out_pos, out_end, until_eob ? ~0ull : bit_end, eob);
+  ntok = sink.n;
+  if (st != kOk) return st;
+  if (out_pos != out_end) return kError;                    // the sub-index and the stream disagree
+  if (until_eob ? !eob : (eob || br.bitpos != bit_end)) return kError;
+  return kOk;
 }
 
 }  // namespace inflate

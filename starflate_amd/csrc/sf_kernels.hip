@@ -128,7 +128,8 @@ template <bool STAMPS>
 __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
                                                      uint32_t* __restrict__ tokens,
                                                      uint32_t* __restrict__ ntok_out,
-                                                     uint32_t* __restrict__ hist_out, uint32_t lazy,
+                                                     uint32_t* __restrict__ hist_out,
+                                                     uint32_t* __restrict__ rtok_out, uint32_t lazy,
                                                      uint32_t fast_skip, uint64_t* __restrict__ stamps) {
   uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t st_t = 0;
@@ -201,9 +202,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
       const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;
       for (uint32_t rel = t; rel < qn; rel += K1_THREADS) {
         const uint32_t b = s_bytes[qb + rel];
-        tk[total + rel] = b;
+        tk[total + rel] = (rel & (kRegion - 1)) == 0 ? (b | kTokRegion | (((qb + rel) / kRegion) << 24)) : b;
         atomicAdd(&s_hist[b], 1u);
       }
+      if (t < kQRegions) rtok_out[chunk * kSubRegions + qb / kRegion + t] = total + (t * kRegion < qn ? t * kRegion : qn);
       total += qn;
       continue;
     }
@@ -453,6 +455,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
       s_segpre[2 * lane] = incl - c0 - c1;
       s_segpre[2 * lane + 1] = incl - c1;
       if (lane == 63) s_misc[0] = incl;
+      // tokens before each 1024-byte parse region: where the decoder's region lanes start (sub-index)
+      if ((lane & (kRegion / 128 - 1)) == 0) rtok_out[chunk * kSubRegions + qb / kRegion + lane / (kRegion / 128)] = total + incl - c0 - c1;
     }
     __syncthreads();
     stamp(4);
@@ -496,6 +500,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
               tok = lit[j];
               atomicAdd(&s_hist[tok], 1u);
             }
+            const uint32_t rel = (wave * kIter + j0 + j) * 64 + lane;
+            if ((rel & (kRegion - 1)) == 0) tok |= kTokRegion | (((qb + rel) / kRegion) << 24);  // first token of a parse region
             tk[idx] = tok;
           }
         }
@@ -510,6 +516,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
   __syncthreads();
   for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) hist_out[(uint64_t)chunk * kHistStride + idx] = s_hist[idx];
   if (t == 0) ntok_out[chunk] = total;
+  {
+    const uint32_t covered = ((n + kQuarter - 1) / kQuarter) * kQRegions;  // regions of the quarters that ran
+    if (t < kSubRegions && t >= covered) rtok_out[chunk * kSubRegions + t] = total;
+  }
   stamp(6);
   if constexpr (STAMPS) {
     if (t == 0)
@@ -999,11 +1009,14 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
                                                      const ChunkPlan* __restrict__ plan,
                                                      const ChunkCodes* __restrict__ codes,
                                                      const uint64_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ rtok,
+                                                     uint32_t* __restrict__ subidx,
                                                      uint8_t* __restrict__ dst) {
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[K4_STAGE_WORDS];
   __shared__ uint32_t s_lcode[288];
   __shared__ uint32_t s_dcode[32];
   __shared__ uint32_t s_wtot[2][K4_WAVES];
+  __shared__ uint32_t s_rtok[kSubRegions];
 
   const uint32_t t = threadIdx.x, lane = t & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
@@ -1014,8 +1027,10 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
   const uint32_t n_raw = (uint32_t)((n_total - cbase) < (uint64_t)kChunk ? (n_total - cbase) : kChunk);
   const ChunkCodes& C = codes[chunk];
 
+  uint32_t* const sub = subidx + (uint64_t)chunk * 2 * kSubRegions;  // {bit offset, tokens before} per region
   if (P.btype == 0) {
     // stored block: BFINAL/BTYPE byte, LEN, NLEN, raw bytes (src/decompress.cpp:416-436 inverse)
+    if (t < 2 * kSubRegions) sub[t] = 0;
     uint8_t* o = dst + off;
     if (t == 0) {
       o[0] = (uint8_t)(C.header[0] & 1u);
@@ -1057,6 +1072,11 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
   }
   if (t < 288) s_lcode[t] = C.lcode[t];
   if (t < 32) s_dcode[t] = C.dcode[t];
+  if (t < kSubRegions) {
+    const uint32_t r0 = rtok[(uint64_t)chunk * kSubRegions + t];
+    s_rtok[t] = r0;
+    sub[2 * t + 1] = r0;
+  }
   __syncthreads();
   {
     uint8_t* sb = reinterpret_cast<uint8_t*>(s_stage) + sh;
@@ -1099,6 +1119,15 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
     // the thread's four codes are contiguous in the stream: gather them in a 64-bit window
     // and OR whole words, instead of one to three atomics per token
     const uint32_t pos = running + pre + incl - mine;
+    {
+      // k_lz77 flags the first token of every 1024-byte parse region: its bit offset is the sub-index entry
+      uint32_t pk = pos;
+#pragma unroll
+      for (uint32_t k = 0; k < K4_TPT; ++k) {
+        if ((tok[k] & kTokRegion) && i0 + k < ntok) sub[2 * ((tok[k] >> 24) & 31u)] = pk - 8 * sh;
+        pk += nb[k];
+      }
+    }
     uint32_t wi = pos >> 5, ab = pos & 31;
     uint64_t acc = 0;
     auto put = [&](uint32_t v32, uint32_t n) {
@@ -1123,6 +1152,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
     running += all;
   }
   __syncthreads();
+  if (t < kSubRegions && s_rtok[t] >= ntok) sub[2 * t] = running - 8 * sh;  // regions past the data: the end-of-block code
   if (t == 0) {
     // end of block, then (unless this is the stream's final block) an empty stored
     // block 000 / pad / 00 00 FF FF to byte-align the next chunk
@@ -1176,10 +1206,10 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
   const uint32_t K1_LDS = sf::K1_LDS + extra;
   if (ws.stamps)
     hipLaunchKernelGGL(k_lz77<true>, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
-                       ws.hist, opt.lazy, opt.fast_skip, ws.stamps);
+                       ws.hist, ws.rtok, opt.lazy, opt.fast_skip, ws.stamps);
   else
     hipLaunchKernelGGL(k_lz77<false>, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
-                       ws.hist, opt.lazy, opt.fast_skip, (uint64_t*)nullptr);
+                       ws.hist, ws.rtok, opt.lazy, opt.fast_skip, (uint64_t*)nullptr);
   return hipGetLastError();
 }
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,
@@ -1195,7 +1225,7 @@ hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, uin
 hipError_t launch_emit(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
                        uint8_t* dst, hipStream_t s) {
   hipLaunchKernelGGL(k_emit, dim3(nchunks), dim3(K4_THREADS), 0, s, src, n, nchunks, ws.tokens, ws.ntok,
-                     ws.plan, ws.codes, ws.offsets, dst);
+                     ws.plan, ws.codes, ws.offsets, ws.rtok, ws.subidx, dst);
   return hipGetLastError();
 }
 

@@ -78,6 +78,9 @@ def lib():
         L.sfo_compress_bound.restype = C.c_size_t
         L.sfo_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Params)]
         L.sfo_compress.restype = C.c_int
+        L.sfo_compress_indexed.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                           C.POINTER(Params), C.c_void_p, C.c_void_p]
+        L.sfo_compress_indexed.restype = C.c_int
         L.sfo_crc32.argtypes = [C.c_void_p, C.c_size_t]
         L.sfo_crc32.restype = C.c_uint32
         L.sfo_adler32.argtypes = [C.c_void_p, C.c_size_t]
@@ -139,6 +142,23 @@ def compress(data, params=None):
     if rc:
         raise RuntimeError(f"sfo_compress rc={rc}")
     return dst[: n.value].copy()
+
+
+def compress_indexed(data, params=None):
+    """-> (stream, index uint64[nchunks+1], subindex uint32[nchunks, 32, 2])"""
+    p = params or default_params()
+    s = _u8(data)
+    cap = lib().sfo_compress_bound(s.size, C.byref(p))
+    dst = np.zeros(cap, dtype=np.uint8)
+    nch = max(1, (s.size + p.chunk_bytes - 1) // p.chunk_bytes)
+    index = np.zeros(nch + 1, dtype=np.uint64)
+    sub = np.zeros((nch, 32, 2), dtype=np.uint32)
+    n = C.c_size_t(0)
+    rc = lib().sfo_compress_indexed(_ptr(s) if s.size else None, s.size, _ptr(dst), cap, C.byref(n), C.byref(p),
+                                    _ptr(index), _ptr(sub))
+    if rc:
+        raise RuntimeError(f"sfo_compress_indexed rc={rc}")
+    return dst[: n.value].copy(), index, sub
 
 
 def crc32(data):

@@ -34,21 +34,25 @@ def _inputs(starfleet):
     }
 
 
-def _gpu_roundtrip(compressor, data, **kw):
+def _gpu_roundtrip(compressor, data, use_sub=False, **kw):
     import torch
 
-    src = torch.from_numpy(data).cuda() if data.size else torch.empty(0, dtype=torch.uint8, device="cuda")
+    src = torch.from_numpy(data.copy()).cuda() if data.size else torch.empty(0, dtype=torch.uint8, device="cuda")
     out, n = compressor.compress_tensor(src, **kw)
     index = compressor.last_index(device="cuda")
+    sub = compressor.last_subindex(device="cuda") if use_sub else None
     stream = out[:n].clone()
-    back, status = compressor.decompress_tensor(stream, index, data.size)
+    back, status = compressor.decompress_tensor(stream, index, data.size, subindex=sub)
     return stream.cpu().numpy(), index.cpu().numpy().astype(np.uint64), back.cpu().numpy(), status
 
 
+@pytest.mark.parametrize("use_sub", [False, True])
 @pytest.mark.parametrize("strategy", ["auto", "stored", "fixed", "dynamic"])
-def test_inflate_own_streams_equals_reference_decoder(compressor, starfleet, strategy):
+def test_inflate_own_streams_equals_reference_decoder(compressor, starfleet, strategy, use_sub):
+    """use_sub: 32 region lanes per segment located by the sub-index (k_inflate_tokens_sub) instead of one lane per
+    segment (k_inflate_tokens); same bytes either way."""
     for name, data in _inputs(starfleet).items():
-        stream, index, back, status = _gpu_roundtrip(compressor, data, strategy=strategy)
+        stream, index, back, status = _gpu_roundtrip(compressor, data, use_sub=use_sub, strategy=strategy)
         assert status == 0, (name, status)
         st, w, ref = O.decompress(stream, data.size)  # the reference restatement on the same stream
         assert st == 0 and w == data.size
@@ -56,6 +60,33 @@ def test_inflate_own_streams_equals_reference_decoder(compressor, starfleet, str
         nseg = max(1, (data.size + CHUNK - 1) // CHUNK)
         assert index.size == nseg + 1 and index[0] == 0 and index[-1] == stream.size
         assert np.all(np.diff(index.astype(np.int64)) > 0)
+
+
+@pytest.mark.parametrize("strategy", ["auto", "fixed", "dynamic", "stored"])
+def test_index_and_subindex_equal_oracle(compressor, starfleet, strategy):
+    """The side information is part of the specification: chunk offsets and, per 1024-byte parse region, the bit
+    offset of its first token code and the tokens before it -- bit-exact with sfo_compress_indexed."""
+    for name, data in _inputs(starfleet).items():
+        got = np.frombuffer(compressor.compress(data, strategy=strategy), np.uint8)
+        idx, sub = compressor.last_index(), compressor.last_subindex()
+        want, widx, wsub = O.compress_indexed(data, O.default_params(strategy=_capi.STRATEGY[strategy]))
+        assert np.array_equal(got, want), name
+        assert np.array_equal(idx, widx), name
+        assert np.array_equal(sub, wsub), (name, np.argwhere(sub != wsub)[:4])
+
+
+def test_wrong_subindex_is_an_error_not_wrong_output(compressor, starfleet):
+    data = np.frombuffer(starfleet, np.uint8)
+    stream = compressor.compress(data, strategy="dynamic")
+    idx, sub = compressor.last_index(), compressor.last_subindex()
+    assert compressor.decompress(stream, idx, data.size, subindex=sub) == (data.tobytes(), 0)
+    for where, delta in (((1, 7, 0), 1), ((2, 0, 0), 3), ((0, 31, 1), 1), ((3, 12, 1), 5), ((1, 3, 0), 1 << 20)):
+        bad = sub.copy()
+        bad[where] += np.uint32(delta)
+        out, st = compressor.decompress(stream, idx, data.size, subindex=bad)
+        assert st != 0 and out == b"", (where, st)
+    zero = np.zeros_like(sub)
+    assert compressor.decompress(stream, idx, data.size, subindex=zero)[1] != 0
 
 
 def test_decoder_tokens_equal_compressor_tokens(compressor):
@@ -76,7 +107,7 @@ def test_decoder_tokens_equal_compressor_tokens(compressor):
     assert np.array_equal(ntok_c, ntok_d)
     for c in range(nch):
         k = int(ntok_c[c])
-        assert np.array_equal(tok_c[c, :k], tok_d[c, :k]), c
+        assert np.array_equal(tok_c[c, :k] & np.uint32(0x80FFFFFF), tok_d[c, :k]), c  # minus the region-start flags
 
 
 @pytest.mark.parametrize("container", ["zlib", "gzip"])
@@ -147,11 +178,15 @@ def test_inflate_large_roundtrip_and_timing(compressor):
     out, n = compressor.compress_tensor(src)
     index = compressor.last_index(device="cuda")
     stream = out[:n].clone()
+    sub = compressor.last_subindex(device="cuda")
     compressor.set_profiling(True)
     back, status = compressor.decompress_tensor(stream, index, data.size)
     assert status == 0 and torch.equal(back, src)
     ms = compressor.inflate_ms()
+    back3, status3 = compressor.decompress_tensor(stream, index, data.size, subindex=sub)
+    assert status3 == 0 and torch.equal(back3, src)
+    ms_sub = compressor.inflate_ms()
     compressor.set_profiling(False)
-    print("inflate 64 MiB:", ms)
+    print("inflate 64 MiB:", ms, "with sub-index:", ms_sub)
     back2, status2 = compressor.decompress_tensor(stream, index, data.size)  # deterministic
     assert status2 == 0 and torch.equal(back2, back)

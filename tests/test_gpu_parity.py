@@ -75,7 +75,12 @@ def test_stage_parity(compressor, starfleet):
         t, nt = O.parse_chunk(d, p, ln, ds)
         flat = np.concatenate([t[r * p.region_bytes: r * p.region_bytes + nt[r]] for r in range(nt.size)])
         assert ntok[c] == flat.size, f"chunk {c}: ntok"
-        assert np.array_equal(toks[c, : flat.size], flat), f"chunk {c}: tokens"
+        # bit 30 + bits 24..28 are k_lz77 -> k_emit transport only: "first token of parse region r" (sub-index)
+        assert np.array_equal(toks[c, : flat.size] & np.uint32(0x80FFFFFF), flat), f"chunk {c}: tokens"
+        starts = np.concatenate([[0], np.cumsum(nt)[:-1]]).astype(np.int64)
+        flagged = np.flatnonzero(toks[c, : flat.size] & np.uint32(0x40000000))
+        assert np.array_equal(flagged, starts[nt > 0]), f"chunk {c}: region flags"
+        assert np.array_equal((toks[c, flagged] >> 24) & 31, np.flatnonzero(nt > 0)), f"chunk {c}: region ids"
         ll, dd = O.histogram(t, nt, p.region_bytes)
         assert np.array_equal(hist[c, :286], ll) and np.array_equal(hist[c, 288:318], dd), f"chunk {c}: hist"
         pl = O.plan_chunk(ll, dd, d.size, c + 1 == nchunks, p)
