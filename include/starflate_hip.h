@@ -132,7 +132,8 @@ int sfh_copy_index(sfh_ctx* ctx, uint64_t* dst, size_t entries, int dst_on_devic
 #define SFH_SUBINDEX_WORDS 64u
 int sfh_copy_subindex(sfh_ctx* ctx, uint32_t* dst, size_t words, int dst_on_device, void* stream);
 
-/* Device buffers (d_src 4-byte, d_index 8-byte, d_dst 16-byte aligned; d_subindex 4-byte aligned or NULL).
+/* Device buffers (d_src 4-byte, d_index 8-byte, d_dst 16-byte aligned; d_subindex 4-byte aligned or NULL;
+ * d_src readable up to the next multiple of 4 bytes, as any device allocation is).
  * nseg must be ceil(dst_n / 32768)
  * (1 for dst_n = 0); segment i decodes stream bytes [index[i], index[i+1]) into dst[i*32768 ...) and must
  * produce exactly that many bytes.  Returns SFH_OK when the kernels ran; *status is then the reference's

@@ -7,8 +7,8 @@
 //
 //   k_inflate_tokens  the bit-serial half.  Huffman decoding cannot be split inside a segment, so the SIMT
 //                     mapping is one LANE per segment: 64 segments per wave, each lane running
-//                     decode_segment() (sf_inflate_core.h) with its own code tables in a 2,148-byte slice
-//                     of LDS (137 KiB per workgroup) and its own 64-bit bit buffer fed by dword loads one
+//                     decode_segment() (sf_inflate_core.h) with its own code tables in a 2,308-byte slice
+//                     of LDS (144 KiB per workgroup) and its own 64-bit bit buffer fed by dword loads one
 //                     refill ahead.  Output: the k_lz77 token format, four tokens per 16-byte store.
 //   k_inflate_bytes   the byte-copy half (src/decompress.cpp:157-187,388-398), one 1024-thread workgroup per
 //                     segment, 96 KiB of LDS: a workgroup prefix sum over the token lengths places every
@@ -26,9 +26,11 @@ namespace sf {
 namespace {
 
 constexpr uint32_t KT_LANES = 64;
-constexpr uint32_t KT_LDS = KT_LANES * inflate::kLaneBytes;
-constexpr uint32_t KB_THREADS = 1024;
-constexpr uint32_t KB_LDS = 3 * kChunk + 128;  // pointers (u16) + bytes + scan scratch
+constexpr uint32_t KT_LDS = KT_LANES * inflate::LaneLayout::kBytes;
+constexpr uint32_t KB_THREADS = 512;
+constexpr uint32_t KB_TPT = 2;     // tokens per thread per step
+constexpr uint32_t KB_SPAN = 3968;  // output bytes per step (pointer array); 4 workgroups of 40 KiB per CU
+constexpr uint32_t KB_LDS = kChunk + 2 * KB_SPAN + 64;
 constexpr uint32_t KB_SHORT = 16;  // a thread writes this many pointers of its match itself, the wave the rest
 
 __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __restrict__ src, uint64_t src_n,
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __re
   const uint64_t obase = (uint64_t)seg * kChunk;
   const uint32_t out_n = dst_n > obase ? (uint32_t)(dst_n - obase < kChunk ? dst_n - obase : kChunk) : 0u;
   const inflate::SegmentResult r = inflate::decode_segment(src, src_n, lo, hi, out_n, tokens + (uint64_t)seg * kChunk,
-                                                           s_tables + threadIdx.x * inflate::kLaneBytes);
+                                                           s_tables + threadIdx.x * inflate::LaneLayout::kBytes);
   SegInfo si;
   si.status = r.status;
   si.ntok = r.ntok;
@@ -52,66 +54,134 @@ __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __re
   info[seg] = si;
 }
 
+// Wave-cooperative version of inflate::build_tables for the SharedLayout: same counts, sorted symbols and
+// one-read tables, built by 64 lanes with ballots instead of by one lane with loops.
+template <bool WIDE>
+__device__ __forceinline__ void build_tables_wave(uint8_t* m, uint32_t lane) {
+  using L = inflate::SharedLayout;
+  constexpr uint32_t off_cnt = WIDE ? L::kOffCntL : L::kOffCntD, off_sym = WIDE ? L::kOffSymL : L::kOffSymD;
+  constexpr uint32_t off_fast = WIDE ? L::kOffFastL : L::kOffFastD, fast_bits = WIDE ? L::kFastL : L::kFastD;
+  constexpr uint32_t n = WIDE ? 288 : 32, nblk = (n + 63) / 64, fast_n = 1u << fast_bits;
+  const uint8_t* lens = m + L::kOffLens + (WIDE ? 0 : 288);
+  const uint64_t lt_mask = (1ull << lane) - 1;
+  uint32_t myl[nblk];
+#pragma unroll
+  for (uint32_t b = 0; b < nblk; ++b) {
+    const uint32_t s = b * 64 + lane;
+    myl[b] = s < n ? (lens[s] & 15u) : 0u;
+  }
+  {
+    uint32_t* f32 = reinterpret_cast<uint32_t*>(m + off_fast);
+#pragma nounroll
+    for (uint32_t k = lane; k < fast_n / 2; k += 64) f32[k] = 0;
+  }
+  __syncthreads();  // the code lengths are read, the fast table (which lent its start to the header parse) is clear
+  uint32_t code = 0, index = 0;  // uniform: first code / first sorted slot of the current length
+#pragma nounroll
+  for (uint32_t l = 1; l <= 15; ++l) {
+    uint32_t cnt_l = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < nblk; ++b) {
+      const uint64_t mask = __ballot(myl[b] == l);
+      if (myl[b] == l) {
+        const uint32_t rank = cnt_l + (uint32_t)__popcll(mask & lt_mask);  // symbols of one length in symbol order
+        const uint32_t s = b * 64 + lane;
+        inflate::st16(m, off_sym + 2 * (index + rank), s);
+        if (l <= fast_bits) {
+          const uint32_t c = (code + rank) & ((1u << l) - 1u);  // an over-subscribed code cannot index past the table
+          const uint32_t rev = __builtin_bitreverse32(c) >> (32 - l);
+#pragma nounroll
+          for (uint32_t e = rev; e < fast_n; e += 1u << l) inflate::st16(m, off_fast + 2 * e, (s << 4) | l);
+        }
+      }
+      cnt_l += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) inflate::st16(m, off_cnt + 2 * l, cnt_l);
+    index += cnt_l;
+    code = (code + cnt_l) << 1;
+  }
+  if (lane == 0) inflate::st16(m, off_cnt, 0);
+}
+
 // Streams of this library: one block per segment and a sub-index naming, for each of the 32 parse regions
 // (1024 bytes of output; k_lz77 never lets a match cross them), the bit offset of the region's first token
-// code and the number of tokens before it (k_emit writes both).  One wave per segment: lane 0 reads the block
-// header and builds the code tables once, in LDS; lanes 0..31 then decode one region each, 32 bit streams of
-// the same block side by side, writing tokens at their compact positions.  The sub-index is checked against the
-// stream (first code right after the header, every lane ends exactly where the next begins, exact byte and
-// token counts): a wrong sub-index is an error, never wrong output.
-__global__ __launch_bounds__(64) void k_inflate_tokens_sub(const uint8_t* __restrict__ src, uint64_t src_n,
-                                                          const uint64_t* __restrict__ index,
-                                                          const uint32_t* __restrict__ subidx, uint64_t dst_n,
-                                                          uint32_t* __restrict__ tokens, SegInfo* __restrict__ info) {
-  __shared__ __align__(16) uint8_t s_tab[inflate::kLaneBytes + 12];
-  __shared__ uint32_t s_open[2];
-  __shared__ uint64_t s_open64[2];
-  const uint32_t seg = blockIdx.x, lane = threadIdx.x;
-  const uint64_t lo = index[seg], hi = index[seg + 1];
+// code and the number of tokens before it (k_emit writes both).  One wave takes TWO segments, 32 lanes each:
+// lanes 0 and 32 read the two block headers side by side, all 64 lanes build each segment's code tables
+// (10-bit literal/length and 8-bit distance one-read tables: a longer code is a rarity), then every lane
+// decodes one region, 64 bit streams side by side, writing tokens at their compact positions.  The kernel is
+// bound by instruction issue (a few hundred VALU instructions per token), so full waves matter more than
+// occupancy.  The sub-index is checked against the stream (first code right after the header, every lane ends
+// exactly where the next begins, exact byte and token counts): a wrong sub-index is an error, never wrong output.
+__global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __restrict__ src, uint64_t src_n,
+                                                             const uint64_t* __restrict__ index,
+                                                             const uint32_t* __restrict__ subidx, uint32_t nseg,
+                                                             uint64_t dst_n, uint32_t* __restrict__ tokens,
+                                                             SegInfo* __restrict__ info) {
+  using L = inflate::SharedLayout;
+  __shared__ __align__(16) uint8_t s_tab[2][L::kBytes];
+  __shared__ uint32_t s_tokbuf[64][9];  // 8 waiting tokens per region lane (+1: bank spread)
+  __shared__ uint32_t s_open[2][2];
+  __shared__ uint64_t s_open64[2][2];
+  const uint32_t lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
+  const uint32_t seg = 2 * blockIdx.x + half;
+  const bool live = seg < nseg;
+  const uint64_t lo = live ? index[seg] : 0, hi = live ? index[seg + 1] : 0;
   const uint64_t obase = (uint64_t)seg * kChunk;
-  const uint32_t out_n = dst_n > obase ? (uint32_t)(dst_n - obase < kChunk ? dst_n - obase : kChunk) : 0u;
-  if (lane == 0) {
-    uint32_t raw;
-    uint64_t raw_off, hdr_end;
-    s_open[0] = inflate::open_segment(src, src_n, lo, hi, out_n, s_tab, raw, raw_off, hdr_end);
-    s_open[1] = raw;
-    s_open64[0] = raw_off;
-    s_open64[1] = hdr_end;
+  const uint32_t out_n = (live && dst_n > obase) ? (uint32_t)(dst_n - obase < kChunk ? dst_n - obase : kChunk) : 0u;
+  if (hl == 0) {
+    uint32_t raw = 0;
+    uint64_t raw_off = 0, hdr_end = 0;
+    s_open[half][0] = live ? inflate::open_segment<L>(src, src_n, lo, hi, out_n, s_tab[half], false, raw, raw_off, hdr_end)
+                           : (uint32_t)inflate::kError;
+    s_open[half][1] = raw;
+    s_open64[half][0] = raw_off;
+    s_open64[half][1] = hdr_end;
   }
   __syncthreads();
-  uint32_t status = s_open[0];
-  const uint32_t raw = s_open[1];
-  uint32_t ntok = 0;
-  if (status == inflate::kOk && !raw) {
-    const uint32_t* sub = subidx + (uint64_t)seg * 2 * kSubRegions;
-    uint32_t st = inflate::kOk, n = 0, tok0 = 0;
-    if (lane < kSubRegions) {
-      const uint32_t bit0 = sub[2 * lane];
-      tok0 = sub[2 * lane + 1];
-      const uint32_t bit1 = lane + 1 < kSubRegions ? sub[2 * lane + 2] : 0u;
-      const uint32_t tok1 = lane + 1 < kSubRegions ? sub[2 * lane + 3] : 0u;
-      const uint32_t ob = lane * kRegion < out_n ? lane * kRegion : out_n;
-      const uint32_t oe = (lane + 1) * kRegion < out_n ? (lane + 1) * kRegion : out_n;
-      if ((lane == 0 && bit0 != s_open64[1]) || tok0 > ob) {
-        st = inflate::kError;  // (tokens before a region) <= (bytes before it) also bounds the token stores
-      } else {
-        st = inflate::decode_region(src, src_n, lo, hi, bit0, bit1, lane + 1 == kSubRegions, ob, oe,
-                                    tokens + (uint64_t)seg * kChunk + tok0, s_tab, n);
-        if (st == inflate::kOk && lane + 1 < kSubRegions && tok0 + n != tok1) st = inflate::kError;
-      }
+#pragma unroll
+  for (uint32_t h = 0; h < 2; ++h) {
+    if (s_open[h][0] == inflate::kOk && !s_open[h][1]) {  // uniform
+      build_tables_wave<true>(s_tab[h], lane);
+      build_tables_wave<false>(s_tab[h], lane);
     }
-    const uint64_t failed = __ballot(st != inflate::kOk);
-    if (failed) status = __builtin_amdgcn_readlane(st, __builtin_amdgcn_readfirstlane(__builtin_ctzll(failed)));
-    ntok = __builtin_amdgcn_readlane(tok0 + n, kSubRegions - 1);
   }
-  if (lane == 0) {
-    SegInfo si;
-    si.status = status;
-    si.ntok = ntok;
-    si.raw = raw;
-    si.out_n = out_n;
-    si.raw_off = s_open64[0];
-    info[seg] = si;
+  __syncthreads();
+  uint32_t status = s_open[half][0];
+  const uint32_t raw = s_open[half][1];
+  uint32_t st = inflate::kOk, n = 0, tok0 = 0;
+  const bool decode = live && status == inflate::kOk && !raw;
+  if (decode) {
+    const uint32_t* sub = subidx + (uint64_t)seg * 2 * kSubRegions;
+    const uint32_t bit0 = sub[2 * hl];
+    tok0 = sub[2 * hl + 1];
+    const uint32_t bit1 = hl + 1 < kSubRegions ? sub[2 * hl + 2] : 0u;
+    const uint32_t tok1 = hl + 1 < kSubRegions ? sub[2 * hl + 3] : 0u;
+    const uint32_t ob = hl * kRegion < out_n ? hl * kRegion : out_n;
+    const uint32_t oe = (hl + 1) * kRegion < out_n ? (hl + 1) * kRegion : out_n;
+    if ((hl == 0 && bit0 != s_open64[half][1]) || tok0 > ob) {
+      st = inflate::kError;  // (tokens before a region) <= (bytes before it) also bounds the token stores
+    } else {
+      st = inflate::decode_region<L>(src, src_n, lo, hi, bit0, bit1, hl + 1 == kSubRegions, ob, oe,
+                                     tokens + (uint64_t)seg * kChunk + tok0, s_tab[half], n, s_tokbuf[lane]);
+      if (st == inflate::kOk && hl + 1 < kSubRegions && tok0 + n != tok1) st = inflate::kError;
+    }
+  }
+  // per segment: first failing region in stream order, token total from the last region lane
+  const uint64_t failed = __ballot(decode && st != inflate::kOk);
+#pragma unroll
+  for (uint32_t h = 0; h < 2; ++h) {
+    const uint64_t fh = (failed >> (32 * h)) & 0xFFFFFFFFull;
+    const uint32_t first_st = fh ? (uint32_t)__builtin_amdgcn_readlane(st, __builtin_amdgcn_readfirstlane(__builtin_ctzll(fh)) + 32 * h) : 0u;
+    const uint32_t total = __builtin_amdgcn_readlane(tok0 + n, 32 * h + 31);
+    if (lane == 32 * h && live) {
+      SegInfo si;
+      si.status = status != inflate::kOk ? status : (fh ? first_st : (uint32_t)inflate::kOk);
+      si.ntok = (status == inflate::kOk && !raw) ? total : 0u;
+      si.raw = raw;
+      si.out_n = out_n;
+      si.raw_off = s_open64[half][0];
+      info[seg] = si;
+    }
   }
 }
 
@@ -133,18 +203,21 @@ __device__ __forceinline__ uint32_t load_word_guarded(const uint8_t* base, uint6
   return v;
 }
 
-// The byte-copy half.  A match copies bytes that may themselves come from a match, so a serial decoder
-// (src/decompress.cpp:157-187,388-398) is a chain of dependent copies.  Here every output byte gets a
-// pointer instead -- a literal points to itself, byte k of a match to the byte `distance` before it -- and
-// pointer jumping (ptr[j] = ptr[ptr[j]]) resolves all chains of a segment at once in at most log2(32768)
-// barrier-separated rounds, however the matches nest or overlap; then every byte reads its literal.
+// The byte-copy half (src/decompress.cpp:157-187,388-398).  Tokens are placed in steps of up to 1024 tokens /
+// 3968 output bytes by a workgroup prefix sum.  A match byte whose source lies before the step is final already
+// and is copied at once; one whose source lies inside the step gets a 16-bit pointer to it, and pointer jumping
+// (ptr[j] = ptr[ptr[j]], barrier-separated rounds, at most log2(3968)) takes every such byte to a final one,
+// however the matches of the step nest or overlap themselves; then the byte is fetched.  40 KiB of LDS (the
+// 32 KiB window + one step of pointers), so four workgroups share a CU and hide each other's barriers.
 __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __restrict__ src, uint64_t src_n,
                                                               const uint32_t* __restrict__ tokens,
                                                               SegInfo* __restrict__ info, uint8_t* __restrict__ dst) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
-  uint16_t* s_ptr = reinterpret_cast<uint16_t*>(s_dyn);          // [32768]
-  uint8_t* s_byte = s_dyn + 2 * kChunk;                          // [32768] literals, then the output
-  uint32_t* s_wtot = reinterpret_cast<uint32_t*>(s_dyn + 3 * kChunk);  // [16] wave totals, [16] flag
+  uint8_t* s_out = s_dyn;                                               // [32768] the segment's output window
+  uint16_t* s_ptr = reinterpret_cast<uint16_t*>(s_dyn + kChunk);       // [KB_SPAN] step-relative source, or kFinal
+  uint32_t* s_w = reinterpret_cast<uint32_t*>(s_dyn + kChunk + 2 * KB_SPAN);  // [8] wave totals, [2] next step
+  uint32_t* s_next = s_w + KB_THREADS / 64;
+  constexpr uint32_t kFinal = 0xFFFFu;
   const uint32_t seg = blockIdx.x, t = threadIdx.x, lane = t & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const SegInfo si = info[seg];
@@ -168,95 +241,136 @@ __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __r
     return;
   }
 
-  // ---- tokens -> pointers: 1024 tokens per step, a workgroup prefix sum places them ----
   const uint32_t ntok = si.ntok;
   const uint32_t* tk = tokens + (uint64_t)seg * kChunk;
-  uint32_t pos0 = 0;
+  uint32_t tok_base = 0, pos0 = 0;  // uniform: first token / output byte of the step
   bool bad = false;
-  for (uint32_t g0 = 0; g0 < ntok; g0 += KB_THREADS) {
-    const uint32_t idx = g0 + t;
-    const bool valid = idx < ntok;
-    const uint32_t tok = valid ? tk[idx] : 0u;
-    const bool is_m = valid && (tok >> 31);
-    const uint32_t len = valid ? (is_m ? ((tok >> 16) & 0xFFu) + 3u : 1u) : 0u;
-    const uint32_t incl = wave_scan_incl(len, lane);
-    if (lane == 63) s_wtot[wave] = incl;
+  if (t == 0) {
+    s_next[0] = 0;  // tokens placed by the step
+    s_next[1] = 0;  // where its output ends
+  }
+  while (tok_base < ntok) {
+    // ---- place up to two tokens per thread ----
+    const uint32_t i0 = tok_base + KB_TPT * t;
+    const bool vA = i0 < ntok, vB = i0 + 1 < ntok;
+    const uint32_t tokA = vA ? tk[i0] : 0u, tokB = vB ? tk[i0 + 1] : 0u;
+    const bool mA = vA && (tokA >> 31), mB = vB && (tokB >> 31);
+    const uint32_t lenA = vA ? (mA ? ((tokA >> 16) & 0xFFu) + 3u : 1u) : 0u;
+    const uint32_t lenB = vB ? (mB ? ((tokB >> 16) & 0xFFu) + 3u : 1u) : 0u;
+    const uint32_t incl = wave_scan_incl(lenA + lenB, lane);
+    if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    uint32_t pre = 0, all = 0;
+    uint32_t pre = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < KB_THREADS / 64; ++w) {
-      const uint32_t v = s_wtot[w];
-      if (w < wave) pre += v;
-      all += v;
-    }
-    const uint32_t start = pos0 + pre + incl - len;
-    const uint32_t dist = (tok & 0x7FFFu) + 1u;
+    for (uint32_t w = 0; w < KB_THREADS / 64; ++w)
+      if (w < wave) pre += s_w[w];
+    const uint32_t startA = pos0 + pre + incl - lenA - lenB, startB = startA + lenA;
+    const uint32_t limit = pos0 + KB_SPAN < out_n ? pos0 + KB_SPAN : out_n;
+    // the tokens that end inside the span form a prefix of the step (the first always fits: 258 <= KB_SPAN)
+    const bool fA = vA && startA + lenA <= limit, fB = vB && startB + lenB <= limit;
+    const uint32_t distA = (tokA & 0x7FFFu) + 1u, distB = (tokB & 0x7FFFu) + 1u;
     // k_inflate_tokens has validated every token; this keeps a corrupted token buffer inside the window
-    if ((is_m && dist > start) || (valid && start + len > out_n)) bad = true;
-    else if (valid) {
-      if (!is_m) {
-        s_ptr[start] = (uint16_t)start;
-        s_byte[start] = (uint8_t)tok;
-      } else {
-        const uint32_t from = start - dist;
-        const uint32_t n0 = len < KB_SHORT ? len : KB_SHORT;
-        // a source byte placed by an earlier step already carries a resolved (or at least shortened) pointer:
-        // adopt it, so that the jumping below only has to untangle chains inside one step
-        for (uint32_t k = 0; k < n0; ++k) {
-          const uint32_t sp = from + k;
-          s_ptr[start + k] = sp < pos0 ? s_ptr[sp] : (uint16_t)sp;
+    if ((fA && mA && distA > startA) || (fB && mB && distB > startB) || (vA && startA + lenA > out_n) ||
+        (vB && startB + lenB > out_n))
+      bad = true;
+    {
+      // where the next step starts: the fitting tokens are a prefix, so their count and the largest end say it
+      const uint32_t nfit_w = (uint32_t)__popcll(__ballot(fA)) + (uint32_t)__popcll(__ballot(fB));
+      uint32_t fmax = fB ? startB + lenB : (fA ? startA + lenA : 0u);
+#pragma unroll
+      for (uint32_t o2 = 32; o2; o2 >>= 1) {
+        const uint32_t u = __shfl_xor(fmax, o2);
+        fmax = u > fmax ? u : fmax;
+      }
+      if (lane == 0 && nfit_w) {
+        atomicAdd(&s_next[0], nfit_w);
+        atomicMax(&s_next[1], fmax);
+      }
+    }
+    // ---- paint: literals, final copies, step-relative pointers ----
+    auto paint = [&](bool fit, bool is_m, uint32_t tok, uint32_t start, uint32_t len, uint32_t dist) {
+      if (fit && !bad) {
+        const uint32_t rel = start - pos0;
+        if (!is_m) {
+          s_out[start] = (uint8_t)tok;
+          s_ptr[rel] = (uint16_t)kFinal;
+        } else {
+          const uint32_t from = start - dist;
+          const uint32_t n0 = len < KB_SHORT ? len : KB_SHORT;
+          for (uint32_t k = 0; k < n0; ++k) {
+            const uint32_t sp = from + k;
+            if (sp < pos0) {
+              s_out[start + k] = s_out[sp];
+              s_ptr[rel + k] = (uint16_t)kFinal;
+            } else {
+              s_ptr[rel + k] = (uint16_t)(sp - pos0);
+            }
+          }
         }
       }
-    }
-    // the long tails, one match after the other by the whole wave
-    uint64_t rest = __ballot(is_m && !bad && len > KB_SHORT);
-    while (rest) {
-      const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
-      rest &= rest - 1;
-      const uint32_t s0 = __builtin_amdgcn_readlane(start, l);
-      const uint32_t d0 = __builtin_amdgcn_readlane(dist, l);
-      const uint32_t n = __builtin_amdgcn_readlane(len, l);
-      for (uint32_t k = KB_SHORT + lane; k < n; k += 64) {
-        const uint32_t sp = s0 + k - d0;
-        s_ptr[s0 + k] = sp < pos0 ? s_ptr[sp] : (uint16_t)sp;
+      uint64_t rest = __ballot(fit && !bad && is_m && len > KB_SHORT);
+      while (rest) {
+        const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
+        rest &= rest - 1;
+        const uint32_t s0 = __builtin_amdgcn_readlane(start, l);
+        const uint32_t d0 = __builtin_amdgcn_readlane(dist, l);
+        const uint32_t n = __builtin_amdgcn_readlane(len, l);
+        for (uint32_t k = KB_SHORT + lane; k < n; k += 64) {
+          const uint32_t sp = s0 + k - d0;
+          if (sp < pos0) {
+            s_out[s0 + k] = s_out[sp];
+            s_ptr[s0 - pos0 + k] = (uint16_t)kFinal;
+          } else {
+            s_ptr[s0 - pos0 + k] = (uint16_t)(sp - pos0);
+          }
+        }
       }
+    };
+    paint(fA, mA, tokA, startA, lenA, distA);
+    paint(fB, mB, tokB, startB, lenB, distB);
+    if (__syncthreads_or(bad)) {
+      if (t == 0) info[seg].status = inflate::kError;
+      return;
     }
-    pos0 += all;
-    __syncthreads();  // s_wtot is rewritten by the next step
+    const uint32_t next_tok = tok_base + s_next[0], next_pos = s_next[1];
+    const uint32_t span_n = next_pos - pos0;
+    // ---- pointer jumping inside the step; a pointer only ever moves to an ancestor, so in place is fine ----
+    for (;;) {  // ends: every change moves a pointer to a strictly smaller index
+      bool changed = false;
+      for (uint32_t j = t; j < span_n; j += KB_THREADS) {
+        const uint32_t p = s_ptr[j];
+        if (p != kFinal) {
+          const uint32_t q = s_ptr[p];
+          if (q != kFinal) {
+            s_ptr[j] = (uint16_t)q;
+            changed = true;
+          }
+        }
+      }
+      if (!__syncthreads_or(changed)) break;
+    }
+    for (uint32_t j = t; j < span_n; j += KB_THREADS) {
+      const uint32_t p = s_ptr[j];
+      if (p != kFinal) s_out[pos0 + j] = s_out[pos0 + p];  // p is final since the paint phase
+    }
+    if (t == 0) {
+      s_next[0] = 0;
+      s_next[1] = 0;
+    }
+    __syncthreads();
+    tok_base = next_tok;
+    pos0 = next_pos;
   }
-  if (__syncthreads_or(bad || pos0 != out_n)) {
+  if (pos0 != out_n) {
     if (t == 0) info[seg].status = inflate::kError;
     return;
   }
-
-  // ---- pointer jumping, in place: a pointer only ever moves to an ancestor, so mixed old/new reads are fine ----
-  for (uint32_t round = 0; round < 16; ++round) {
-    bool changed = false;
-#pragma unroll 4
-    for (uint32_t j = t; j < out_n; j += KB_THREADS) {
-      const uint32_t p = s_ptr[j];
-      if (p != j) {
-        const uint32_t q = s_ptr[p];
-        if (q != p) {
-          s_ptr[j] = (uint16_t)q;
-          changed = true;
-        }
-      }
-    }
-    if (!__syncthreads_or(changed)) break;
-  }
-  // every pointer now names a literal position; literal positions keep their own byte, so in place is safe
-  for (uint32_t j = t; j < out_n; j += KB_THREADS) {
-    const uint32_t p = s_ptr[j];
-    if (p != j) s_byte[j] = s_byte[p];
-  }
-  __syncthreads();
-  const uint4* w16 = reinterpret_cast<const uint4*>(s_byte);
+  const uint4* w16 = reinterpret_cast<const uint4*>(s_out);
   uint4* o16 = reinterpret_cast<uint4*>(o);
   const uint32_t nq = out_n / 16;
   for (uint32_t k = t; k < nq; k += KB_THREADS) o16[k] = w16[k];
   const uint32_t done = 16 * nq;
-  if (t < out_n - done) o[done + t] = s_byte[done + t];
+  if (t < out_n - done) o[done + t] = s_out[done + t];
 }
 
 constexpr uint32_t KS_THREADS = 1024;
@@ -299,7 +413,8 @@ hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint6
 
 hipError_t launch_inflate_tokens_sub(const uint8_t* src, uint64_t src_n, const uint64_t* index, const uint32_t* subidx,
                                      uint32_t nseg, uint64_t dst_n, uint32_t* tokens, SegInfo* info, hipStream_t s) {
-  hipLaunchKernelGGL(k_inflate_tokens_sub, dim3(nseg), dim3(64), 0, s, src, src_n, index, subidx, dst_n, tokens, info);
+  hipLaunchKernelGGL(k_inflate_tokens_sub, dim3((nseg + 1) / 2), dim3(64), 0, s, src, src_n, index, subidx, nseg, dst_n,
+                     tokens, info);
   return hipGetLastError();
 }
 

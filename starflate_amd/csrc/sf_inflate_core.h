@@ -39,18 +39,25 @@ enum : uint32_t {
 };
 
 constexpr uint32_t kTokMatchBit = 0x80000000u;
-constexpr uint32_t kFastBits = 9;   // literal/length codes up to 9 bits: one table read
-constexpr uint32_t kDFastBits = 7;  // distance codes up to 7 bits: one table read
 
-// per-segment table memory (byte offsets); 537 dwords: an odd stride spreads the lanes over the LDS banks
-constexpr uint32_t kOffFast = 0;      // u16[512]: (symbol << 4) | code bits, 0 = longer code
-constexpr uint32_t kOffLSym = 1024;   // u16[288]: literal/length symbols sorted by (code bits, symbol)
-constexpr uint32_t kOffLCnt = 1600;   // u16[16] : codes per length
-constexpr uint32_t kOffDFast = 1632;  // u8[128] : (symbol << 3) | code bits, 0 = longer code
-constexpr uint32_t kOffDSym = 1760;   // u8[32]
-constexpr uint32_t kOffDCnt = 1792;   // u16[16]
-constexpr uint32_t kOffLens = 1824;   // u8[320] : code lengths while a header is parsed
-constexpr uint32_t kLaneBytes = 2148;
+// Table memory of one segment (byte offsets).  Both code tables: `fast` u16[1 << bits] indexed by the next
+// stream bits, entry (symbol << 4) | code bits, 0 = longer code or none; `sym` u16[] symbols sorted by
+// (code bits, symbol) and `cnt` u16[16] codes per length for the bit-serial walk of longer codes; `lens` u8[320]
+// code lengths (literal/length at 0, distance at 288).  While a dynamic header is parsed the literal/length
+// fast table is not built yet and lends its first 160 bytes to the code-length code.
+struct LaneLayout {  // k_inflate_tokens: one segment per LANE, 64 of these per workgroup
+  static constexpr uint32_t kFastL = 9, kFastD = 7;
+  static constexpr uint32_t kOffFastL = 0, kOffSymL = 1024, kOffCntL = 1600, kOffFastD = 1632, kOffSymD = 1888,
+                            kOffCntD = 1952, kOffLens = 1984;
+  static constexpr uint32_t kBytes = 2308;  // 577 dwords: an odd stride spreads the lanes over the LDS banks
+};
+struct SharedLayout {  // k_inflate_tokens_sub: one segment per WAVE, its 32 region lanes share the tables
+  static constexpr uint32_t kFastL = 10, kFastD = 8;
+  static constexpr uint32_t kOffFastL = 0, kOffSymL = 2048, kOffCntL = 2624, kOffFastD = 2656, kOffSymD = 3168,
+                            kOffCntD = 3232, kOffLens = 3264;
+  static constexpr uint32_t kBytes = 3584;
+};
+constexpr uint32_t kOffClLut = 32;  // u8[128] inside the (not yet built) literal/length fast table
 
 struct SegmentResult {
   uint32_t status;   // one of the values above
@@ -77,8 +84,8 @@ SF_HD void distance_info(uint32_t sym /*0..29*/, uint32_t& base, uint32_t& extra
 }
 
 struct BitReader {
-  const uint8_t* base;  // stream buffer, 4-byte aligned
-  uint64_t src_n;       // bytes in the buffer; nothing at or past it is read
+  const uint8_t* base;  // stream buffer, 4-byte aligned, readable up to the next multiple of 4 bytes
+  uint64_t src_n;       // bytes in the buffer (> 0); no dword starting at or past it is read
   uint64_t word;        // next dword to load
   uint64_t buf;
   uint32_t cnt;
@@ -86,13 +93,12 @@ struct BitReader {
   uint64_t bitpos;      // bits consumed since the segment began
   uint64_t nbits;       // bits the segment holds
 
+  // Branch-free on purpose: the refill loads one dword ahead of its use, and a branch around the load would
+  // make the compiler wait for it on the spot (a full memory round trip per refill).  Past the end the last
+  // dword repeats; only a truncated or corrupt stream gets that far, and it ends in an error status.
   SF_HD uint32_t load_word(uint64_t w) const {
-    const uint64_t b = 4 * w;
-    if (b + 4 <= src_n) return reinterpret_cast<const uint32_t*>(base)[w];
-    uint32_t v = 0;
-    for (uint32_t k = 0; k < 4; ++k)
-      if (b + k < src_n) v |= (uint32_t)base[b + k] << (8 * k);
-    return v;
+    const uint64_t last = (src_n - 1) >> 2;
+    return reinterpret_cast<const uint32_t*>(base)[w < last ? w : last];
   }
   SF_HD void seek(uint64_t byte) {  // bit accounting is left alone
     word = byte >> 2;
@@ -128,14 +134,15 @@ SF_HD uint32_t bit_reverse(uint32_t code, uint32_t len) {
   return r;
 }
 
-// Canonical code (huffman/src/table.hpp:177-216) from lens[0..n) (bytes at m + kOffLens + lens_at):
-// per-length counts, symbols sorted by (length, symbol), and the one-read table for codes <= fast_bits.
-// WIDE: literal/length alphabet (u16 entries / symbols), else distance alphabet (u8).
-template <bool WIDE>
-SF_HD void build_tables(uint8_t* m, uint32_t lens_at, uint32_t n) {
-  const uint32_t off_cnt = WIDE ? kOffLCnt : kOffDCnt, off_sym = WIDE ? kOffLSym : kOffDSym;
-  const uint32_t off_fast = WIDE ? kOffFast : kOffDFast, fast_bits = WIDE ? kFastBits : kDFastBits;
-  const uint8_t* lens = m + kOffLens + lens_at;
+// Canonical code (huffman/src/table.hpp:177-216) from the code lengths at L::kOffLens: per-length counts,
+// symbols sorted by (length, symbol), and the one-read table for codes up to the fast width.  Serial (one
+// lane); k_inflate_tokens_sub has a wave-cooperative version of the same tables.
+template <class L, bool WIDE>
+SF_HD void build_tables(uint8_t* m) {
+  constexpr uint32_t off_cnt = WIDE ? L::kOffCntL : L::kOffCntD, off_sym = WIDE ? L::kOffSymL : L::kOffSymD;
+  constexpr uint32_t off_fast = WIDE ? L::kOffFastL : L::kOffFastD, fast_bits = WIDE ? L::kFastL : L::kFastD;
+  constexpr uint32_t n = WIDE ? 288 : 32;
+  const uint8_t* lens = m + L::kOffLens + (WIDE ? 0 : 288);
   for (uint32_t l = 0; l < 16; ++l) st16(m, off_cnt + 2 * l, 0);
   for (uint32_t s = 0; s < n; ++s) {
     const uint32_t l = lens[s] & 15u;
@@ -155,21 +162,17 @@ SF_HD void build_tables(uint8_t* m, uint32_t lens_at, uint32_t n) {
 #pragma unroll
     for (uint32_t k = 1; k < 16; ++k)
       if (k == l) { at = offs[k]; offs[k] = at + 1; }
-    if (WIDE) st16(m, off_sym + 2 * at, s); else m[off_sym + at] = (uint8_t)s;
+    st16(m, off_sym + 2 * at, s);
   }
-  const uint32_t fast_n = 1u << fast_bits;
-  for (uint32_t k = 0; k < fast_n; ++k) {
-    if (WIDE) st16(m, off_fast + 2 * k, 0); else m[off_fast + k] = 0;
-  }
+  constexpr uint32_t fast_n = 1u << fast_bits;
+  for (uint32_t k = 0; k < fast_n; ++k) st16(m, off_fast + 2 * k, 0);
   uint32_t code = 0, idx = 0;
   for (uint32_t l = 1; l <= fast_bits; ++l) {
     const uint32_t c = ld16(m, off_cnt + 2 * l);
     for (uint32_t j = 0; j < c; ++j, ++idx, ++code) {
-      const uint32_t sym = WIDE ? ld16(m, off_sym + 2 * idx) : m[off_sym + idx];
+      const uint32_t sym = ld16(m, off_sym + 2 * idx);
       const uint32_t rev = bit_reverse(code & ((1u << l) - 1u), l);  // an over-subscribed code cannot index past the table
-      for (uint32_t e = rev; e < fast_n; e += 1u << l) {
-        if (WIDE) st16(m, off_fast + 2 * e, (sym << 4) | l); else m[off_fast + e] = (uint8_t)((sym << 3) | l);
-      }
+      for (uint32_t e = rev; e < fast_n; e += 1u << l) st16(m, off_fast + 2 * e, (sym << 4) | l);
     }
     code <<= 1;
   }
@@ -177,24 +180,23 @@ SF_HD void build_tables(uint8_t* m, uint32_t lens_at, uint32_t n) {
 
 // One symbol.  Returns its code length (0: no code matches the next bits) and the symbol in `sym`.
 // The caller has refilled: >= 15 bits are buffered (bits past the end of the input read as zero).
-template <bool WIDE>
+template <class L, bool WIDE>
 SF_HD uint32_t decode_symbol(const uint8_t* m, const BitReader& br, uint32_t& sym) {
-  const uint32_t fast_bits = WIDE ? kFastBits : kDFastBits;
-  const uint32_t e = WIDE ? ld16(m, kOffFast + 2 * br.peek(fast_bits)) : m[kOffDFast + br.peek(fast_bits)];
+  constexpr uint32_t fast_bits = WIDE ? L::kFastL : L::kFastD, off_fast = WIDE ? L::kOffFastL : L::kOffFastD;
+  const uint32_t e = ld16(m, off_fast + 2 * br.peek(fast_bits));
   if (e) {
-    sym = WIDE ? e >> 4 : e >> 3;
-    return WIDE ? (e & 15u) : (e & 7u);
+    sym = e >> 4;
+    return e & 15u;
   }
   // longer code: canonical bit-serial walk (one table row per length), rare
-  const uint32_t off_cnt = WIDE ? kOffLCnt : kOffDCnt, off_sym = WIDE ? kOffLSym : kOffDSym;
+  constexpr uint32_t off_cnt = WIDE ? L::kOffCntL : L::kOffCntD, off_sym = WIDE ? L::kOffSymL : L::kOffSymD;
   uint32_t bits = (uint32_t)br.buf, code = 0, first = 0, index = 0;
   for (uint32_t l = 1; l <= 15; ++l) {
     code |= bits & 1u;
     bits >>= 1;
     const uint32_t c = ld16(m, off_cnt + 2 * l);
     if (code < first + c) {
-      const uint32_t at = index + (code - first);
-      sym = WIDE ? ld16(m, off_sym + 2 * at) : m[off_sym + at];
+      sym = ld16(m, off_sym + 2 * (index + (code - first)));
       return l;
     }
     index += c;
@@ -221,6 +223,7 @@ struct TokenSink {
     else *reinterpret_cast<Tok4*>(out + (n & ~3u)) = Tok4{q0, q1, q2, t};  // one dwordx4 store
     ++n;
   }
+  SF_HD void tick() {}
   SF_HD void flush() {
     const uint32_t k = n & 3u;
     uint32_t* p = out + (n & ~3u);
@@ -233,102 +236,122 @@ struct PlainSink {
   uint32_t* out;
   uint32_t n;
   SF_HD void put(uint32_t t) { out[n++] = t; }
+  SF_HD void tick() {}
   SF_HD void flush() {}
 };
-
-// Code lengths of a fixed (type 1, src/decompress.cpp:25-40) or dynamic (type 2, :253-367) block into the
-// tables of `m`; for type 2 the header is read from `br`.  Returns a status.
-SF_HD uint32_t read_tables(BitReader& br, uint8_t* m, uint32_t type) {
-  uint8_t* lens = m + kOffLens;
-  if (type == 1) {
-    for (uint32_t s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-    for (uint32_t s = 0; s < 32; ++s) lens[288 + s] = 5;
-  } else {
-    br.refill();
-    if (br.bitpos + 14 > br.nbits) return kSrcTooSmall;
-    const uint32_t hlit = br.get(5) + 257, hdist = br.get(5) + 1, hclen = br.get(4) + 4;
-    if (br.bitpos + 3ull * hclen > br.nbits) return kSrcTooSmall;
-    uint8_t* cl = m + kOffDFast;  // the distance tables are built after the header: borrow their memory
-    for (uint32_t k = 0; k < 19; ++k) cl[k] = 0;
-    for (uint32_t k = 0; k < hclen; ++k) {
-      br.refill();
-      // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (src/decompress.cpp:250-251)
-      const uint32_t order = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 8 + ((k - 4) >> 1);
-      cl[order] = (uint8_t)br.get(3);
-    }
-    // code-length code: counts and sorted symbols (<= 7 bits), canonical walk per symbol
-    uint8_t* ccnt = m + kOffDSym;      // u8[8]
-    uint8_t* csym = m + kOffDSym + 8;  // u8[19]
-    for (uint32_t l = 0; l < 8; ++l) ccnt[l] = 0;
-    for (uint32_t s = 0; s < 19; ++s) ccnt[cl[s]]++;
-    ccnt[0] = 0;
-    {
-      uint32_t at = 0;
-      for (uint32_t l = 1; l < 8; ++l)
-        for (uint32_t s = 0; s < 19; ++s)
-          if (cl[s] == l) csym[at++] = (uint8_t)s;
-    }
-    const uint32_t total = hlit + hdist;
-    uint32_t i = 0, prev = 0;
-    while (i < total) {
-      br.refill();
-      if (br.overrun()) return kSrcTooSmall;
-      uint32_t bits = (uint32_t)br.buf, code = 0, first = 0, index = 0, sym = 19, used = 0;
-      for (uint32_t l = 1; l <= 7; ++l) {
-        code |= bits & 1u;
-        bits >>= 1;
-        const uint32_t c = ccnt[l];
-        if (code < first + c) { sym = csym[index + (code - first)]; used = l; break; }
-        index += c;
-        first = (first + c) << 1;
-        code <<= 1;
-      }
-      if (sym > 18) return kError;
-      br.drop(used);
-      if (sym < 16) {
-        lens[i++] = (uint8_t)sym;
-        prev = sym;
-      } else {
-        uint32_t rep, val = 0;
-        if (sym == 16) {
-          if (i == 0) return kError;  // nothing to repeat (src/decompress.cpp:278)
-          val = prev;
-          rep = 3 + br.get(2);
-        } else if (sym == 17) {
-          rep = 3 + br.get(3);
-        } else {
-          rep = 11 + br.get(7);
-        }
-        if (i + rep > total) return kError;  // run past the last length
-        for (uint32_t k = 0; k < rep; ++k) lens[i++] = (uint8_t)val;
-        prev = val;
-      }
-    }
-    if (br.overrun()) return kSrcTooSmall;
-    // move the distance lengths to their fixed place [288..) so both layouts look alike (downwards: the
-    // ranges may overlap and the destination is the higher one)
-    if (hlit < 288) {
-      for (uint32_t s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];
-      for (uint32_t s = hlit; s < 288; ++s) lens[s] = 0;
-    }
-    for (uint32_t s = hdist; s < 32; ++s) lens[288 + s] = 0;
+// Region lanes: tokens wait in an 8-entry LDS buffer of the lane and leave for global memory every 8th loop
+// iteration, all lanes at once.  (On CDNA loads and stores share one counter, vmcnt: with a token store in
+// flight every refill of the bit buffer would wait a full memory round trip.)
+struct BufferedSink {
+  uint32_t* out;
+  uint32_t* buf;  // 8 dwords, this lane's
+  uint32_t n, flushed, iter;
+  SF_HD void put(uint32_t t) { buf[n++ - flushed] = t; }
+  SF_HD void tick() {
+    if ((++iter & 7u) == 0) flush();
   }
-  build_tables<true>(m, 0, 288);
-  build_tables<false>(m, 288, 32);
+  SF_HD void flush() {
+    _Pragma("nounroll") for (uint32_t k = flushed; k < n; ++k) out[k] = buf[k - flushed];
+    flushed = n;
+  }
+};
+
+// Code lengths of a fixed (type 1, src/decompress.cpp:25-40) or dynamic (type 2, :253-367) block into
+// L::kOffLens; for type 2 the header is read from `br`.  Returns a status.
+template <class L>
+SF_HD uint32_t read_lengths(BitReader& br, uint8_t* m, uint32_t type) {
+  uint8_t* lens = m + L::kOffLens;
+  if (type == 1) {
+    _Pragma("nounroll") for (uint32_t s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+    _Pragma("nounroll") for (uint32_t s = 0; s < 32; ++s) lens[288 + s] = 5;
+    return kOk;
+  }
+  br.refill();
+  if (br.bitpos + 14 > br.nbits) return kSrcTooSmall;
+  const uint32_t hlit = br.get(5) + 257, hdist = br.get(5) + 1, hclen = br.get(4) + 4;
+  if (br.bitpos + 3ull * hclen > br.nbits) return kSrcTooSmall;
+  uint64_t clp = 0;  // the 19 code-length code lengths, 3 bits each
+  _Pragma("nounroll") for (uint32_t k = 0; k < hclen; ++k) {
+    br.refill();
+    // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (src/decompress.cpp:250-251)
+    const uint32_t order = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 8 + ((k - 4) >> 1);
+    clp |= (uint64_t)br.get(3) << (3 * order);
+  }
+  // 7-bit lookup table of the code-length code: (symbol << 3) | code bits, 0 = no code
+  uint8_t* lut = m + L::kOffFastL + kOffClLut;
+  _Pragma("nounroll") for (uint32_t e = 0; e < 128; ++e) lut[e] = 0;
+  {
+    uint32_t code = 0;
+    _Pragma("nounroll") for (uint32_t l = 1; l <= 7; ++l) {
+      _Pragma("nounroll") for (uint32_t s = 0; s < 19; ++s)
+        if (((clp >> (3 * s)) & 7u) == l) {
+          const uint32_t rev = bit_reverse(code & ((1u << l) - 1u), l);
+          _Pragma("nounroll") for (uint32_t e = rev; e < 128; e += 1u << l) lut[e] = (uint8_t)((s << 3) | l);
+          ++code;
+        }
+      code <<= 1;
+    }
+  }
+  const uint32_t total = hlit + hdist;
+  uint32_t i = 0, prev = 0;
+  while (i < total) {
+    br.refill();
+    if (br.overrun()) return kSrcTooSmall;
+    const uint32_t e = lut[br.peek(7)];
+    if (e == 0) return kError;
+    br.drop(e & 7u);
+    const uint32_t sym = e >> 3;
+    if (sym < 16) {
+      lens[i++] = (uint8_t)sym;
+      prev = sym;
+    } else {
+      uint32_t rep, val = 0;
+      if (sym == 16) {
+        if (i == 0) return kError;  // nothing to repeat (src/decompress.cpp:278)
+        val = prev;
+        rep = 3 + br.get(2);
+      } else if (sym == 17) {
+        rep = 3 + br.get(3);
+      } else {
+        rep = 11 + br.get(7);
+      }
+      if (i + rep > total) return kError;  // run past the last length
+      _Pragma("nounroll") for (uint32_t k = 0; k < rep; ++k) lens[i++] = (uint8_t)val;
+      prev = val;
+    }
+  }
+  if (br.overrun()) return kSrcTooSmall;
+  // move the distance lengths to their fixed place [288..) so both layouts look alike (downwards: the
+  // ranges may overlap and the destination is the higher one)
+  if (hlit < 288) {
+    _Pragma("nounroll") for (uint32_t s = hdist; s-- > 0;) lens[288 + s] = lens[hlit + s];
+    _Pragma("nounroll") for (uint32_t s = hlit; s < 288; ++s) lens[s] = 0;
+  }
+  _Pragma("nounroll") for (uint32_t s = hdist; s < 32; ++s) lens[288 + s] = 0;
+  return kOk;
+}
+
+template <class L>
+SF_HD uint32_t read_tables(BitReader& br, uint8_t* m, uint32_t type) {
+  const uint32_t st = read_lengths<L>(br, m, type);
+  if (st != kOk) return st;
+  build_tables<L, true>(m);
+  build_tables<L, false>(m);
   return kOk;
 }
 
 // Symbol loop (src/decompress.cpp:122-187) until the end-of-block code or, if sooner, until `end_bit` bits of
 // the segment are consumed (a region lane stops where the next region starts).  out_pos: bytes of the segment
 // produced before / after; out_limit: where this caller's output must end at the latest.
-template <class Sink>
+template <class L, class Sink>
 SF_HD uint32_t decode_symbols(BitReader& br, const uint8_t* m, Sink& sink, uint32_t& out_pos, uint32_t out_limit,
                               uint64_t end_bit, bool& hit_eob) {
   hit_eob = false;
   while (br.bitpos < end_bit) {
+    sink.tick();
     br.refill();
     uint32_t sym;
-    const uint32_t l = decode_symbol<true>(m, br, sym);
+    const uint32_t l = decode_symbol<L, true>(m, br, sym);
     if (l == 0) return kInvalidLitOrLen;
     br.drop(l);
     if (sym < 256) {
@@ -347,7 +370,7 @@ SF_HD uint32_t decode_symbols(BitReader& br, const uint8_t* m, Sink& sink, uint3
     const uint32_t len = lbase + br.get(lextra);
     br.refill();
     uint32_t dsym;
-    const uint32_t dl = decode_symbol<false>(m, br, dsym);
+    const uint32_t dl = decode_symbol<L, false>(m, br, dsym);
     if (dl == 0 || dsym > 29) return kInvalidDistance;
     br.drop(dl);
     uint32_t dbase, dextra;
@@ -363,12 +386,16 @@ SF_HD uint32_t decode_symbols(BitReader& br, const uint8_t* m, Sink& sink, uint3
 }
 
 // Decodes the blocks of one segment: stream bytes [seg_begin, seg_end) of `src`, which must produce exactly
-// out_n (<= 32768) bytes.  Tokens go to tokens[0..ntok).  `m`: kLaneBytes of scratch.
+// out_n (<= 32768) bytes.  Tokens go to tokens[0..ntok).  `m`: LaneLayout::kBytes of scratch.
 SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end,
                                    uint32_t out_n, uint32_t* tokens, uint8_t* m) {
   SegmentResult r{kOk, 0, 0, 0};
   if (seg_begin > seg_end || seg_end > src_n) {
     r.status = kSrcTooSmall;
+    return r;
+  }
+  if (seg_begin == seg_end) {
+    r.status = kInvalidBlockHeader;  // no header bits at all (src/decompress.cpp:370-373)
     return r;
   }
   BitReader br;
@@ -415,10 +442,10 @@ SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t 
       br.seek(data_at + len);
       continue;
     }
-    status = read_tables(br, m, type);
+    status = read_tables<LaneLayout>(br, m, type);
     if (status != kOk) break;
     bool eob;
-    status = decode_symbols(br, m, sink, out_pos, out_n, ~0ull, eob);
+    status = decode_symbols<LaneLayout>(br, m, sink, out_pos, out_n, ~0ull, eob);
   }
   if (status == kOk && out_pos != out_n) status = kSrcTooSmall;  // the index promised more bytes
   if (status == kOk && r.raw && sink.n != 0) status = kDstTooSmall;
@@ -431,14 +458,16 @@ SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t 
 // ---- sub-indexed segments (streams of this library: one block per segment, 32 parse regions of 1024 bytes
 // ---- whose first token codes are located by the sub-index) ----
 
-// First lane of a segment: block header and code tables.  raw != 0: stored segment (bytes at raw_off).
-// hdr_end: bit offset, from the segment's first byte, of the first token code.
+// First lane of a segment: block header and code lengths (build: and the tables, serially).  raw != 0: stored
+// segment (bytes at raw_off).  hdr_end: bit offset, from the segment's first byte, of the first token code.
+template <class L>
 SF_HD uint32_t open_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end, uint32_t out_n,
-                            uint8_t* m, uint32_t& raw, uint64_t& raw_off, uint64_t& hdr_end) {
+                            uint8_t* m, bool build, uint32_t& raw, uint64_t& raw_off, uint64_t& hdr_end) {
   raw = 0;
   raw_off = 0;
   hdr_end = 0;
   if (seg_begin > seg_end || seg_end > src_n) return kSrcTooSmall;
+  if (seg_begin == seg_end) return kInvalidBlockHeader;
   BitReader br;
   br.base = src;
   br.src_n = src_n;
@@ -463,31 +492,40 @@ SF_HD uint32_t open_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_beg
     raw_off = seg_begin + 5;
     return kOk;
   }
-  const uint32_t st = read_tables(br, m, type);
+  const uint32_t st = build ? read_tables<L>(br, m, type) : read_lengths<L>(br, m, type);
   hdr_end = br.bitpos;
   return st;
 }
 
 // One region lane: token codes from bit `bit_begin` of the segment up to `bit_end` (or to the end-of-block code
 // when until_eob), which must produce exactly the bytes [out_begin, out_end) of the segment.
+template <class L>
 SF_HD uint32_t decode_region(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end, uint64_t bit_begin,
                              uint64_t bit_end, bool until_eob, uint32_t out_begin, uint32_t out_end, uint32_t* tokens,
-                             const uint8_t* m, uint32_t& ntok) {
+                             const uint8_t* m, uint32_t& ntok, uint32_t* lane_buf = nullptr) {
   ntok = 0;
   BitReader br;
   br.base = src;
   br.src_n = src_n;
   br.nbits = 8 * (seg_end - seg_begin);
-  if (bit_begin > br.nbits || (!until_eob && (bit_end < bit_begin || bit_end > br.nbits))) return kError;
+  if (br.nbits == 0 || bit_begin > br.nbits || (!until_eob && (bit_end < bit_begin || bit_end > br.nbits))) return kError;
   br.seek(seg_begin + (bit_begin >> 3));
   br.bitpos = bit_begin & ~7ull;
   br.refill();
   br.drop((uint32_t)(bit_begin & 7));
-  PlainSink sink{tokens, 0};
   uint32_t out_pos = out_begin;
   bool eob;
-  const uint32_t st = decode_symbols(br, m, sink, out_pos, out_end, until_eob ? ~0ull : bit_end, eob);
-  ntok = sink.n;
+  uint32_t st;
+  if (lane_buf) {
+    BufferedSink sink{tokens, lane_buf, 0, 0, 0};
+    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0ull : bit_end, eob);
+    sink.flush();
+    ntok = sink.n;
+  } else {
+    PlainSink sink{tokens, 0};
+    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0ull : bit_end, eob);
+    ntok = sink.n;
+  }
   if (st != kOk) return st;
   if (out_pos != out_end) return kError;                    // the sub-index and the stream disagree
   if (until_eob ? !eob : (eob || br.bitpos != bit_end)) return kError;

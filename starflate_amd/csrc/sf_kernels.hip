@@ -500,8 +500,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
               tok = lit[j];
               atomicAdd(&s_hist[tok], 1u);
             }
-            const uint32_t rel = (wave * kIter + j0 + j) * 64 + lane;
-            if ((rel & (kRegion - 1)) == 0) tok |= kTokRegion | (((qb + rel) / kRegion) << 24);  // first token of a parse region
+            // first token of a parse region (its position is always a token start): only lane 0 of every 16th
+            // segment can be one -- the segment test is uniform, so 15 of 16 segments skip this entirely
+            const uint32_t sgq = wave * kIter + j0 + j;
+            if ((sgq & (kRegion / 64 - 1)) == 0 && lane == 0) tok |= kTokRegion | (((qb + sgq * 64) / kRegion) << 24);
             tk[idx] = tok;
           }
         }
@@ -1119,8 +1121,9 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
     // the thread's four codes are contiguous in the stream: gather them in a 64-bit window
     // and OR whole words, instead of one to three atomics per token
     const uint32_t pos = running + pre + incl - mine;
-    {
-      // k_lz77 flags the first token of every 1024-byte parse region: its bit offset is the sub-index entry
+    if ((tok[0] | tok[1] | tok[2] | tok[3]) & kTokRegion) {
+      // k_lz77 flags the first token of every 1024-byte parse region (32 per chunk): its bit offset is the
+      // sub-index entry
       uint32_t pk = pos;
 #pragma unroll
       for (uint32_t k = 0; k < K4_TPT; ++k) {

@@ -12,7 +12,7 @@ extern "C" {
 unsigned sfi_decode_segment(const unsigned char* src, unsigned long long src_n, unsigned long long seg_begin,
                             unsigned long long seg_end, unsigned out_n, unsigned* tokens_out, unsigned* ntok,
                             unsigned* raw, unsigned long long* raw_off) {
-  alignas(16) static thread_local unsigned char mem[sf::inflate::kLaneBytes + 12];
+  alignas(16) static thread_local unsigned char mem[sf::inflate::LaneLayout::kBytes + 12];
   std::memset(mem, 0xA5, sizeof mem);  // stale table contents must not matter
   const auto r = sf::inflate::decode_segment(src, src_n, seg_begin, seg_end, out_n, tokens_out, mem);
   *ntok = r.ntok;
@@ -26,11 +26,11 @@ unsigned sfi_decode_segment(const unsigned char* src, unsigned long long src_n, 
 unsigned sfi_decode_segment_sub(const unsigned char* src, unsigned long long src_n, unsigned long long seg_begin,
                                 unsigned long long seg_end, unsigned out_n, const unsigned* sub /*[32][2]*/,
                                 unsigned* tokens_out, unsigned* ntok, unsigned* raw, unsigned long long* raw_off) {
-  alignas(16) static thread_local unsigned char mem[sf::inflate::kLaneBytes + 12];
+  alignas(16) static thread_local unsigned char mem[sf::inflate::LaneLayout::kBytes + 12];
   std::memset(mem, 0x5A, sizeof mem);
   uint64_t hdr_end = 0, roff = 0;
   uint32_t is_raw = 0;
-  unsigned st = sf::inflate::open_segment(src, src_n, seg_begin, seg_end, out_n, mem, is_raw, roff, hdr_end);
+  unsigned st = sf::inflate::open_segment<sf::inflate::LaneLayout>(src, src_n, seg_begin, seg_end, out_n, mem, true, is_raw, roff, hdr_end);
   *raw = is_raw;
   *raw_off = roff;
   *ntok = 0;
@@ -40,7 +40,7 @@ unsigned sfi_decode_segment_sub(const unsigned char* src, unsigned long long src
     const unsigned ob = r * 1024 < out_n ? r * 1024 : out_n, oe = (r + 1) * 1024 < out_n ? (r + 1) * 1024 : out_n;
     if (sub[2 * r + 1] > ob) return sf::inflate::kError;
     uint32_t n = 0;
-    st = sf::inflate::decode_region(src, src_n, seg_begin, seg_end, sub[2 * r], r < 31 ? sub[2 * r + 2] : 0, r == 31, ob, oe,
+    st = sf::inflate::decode_region<sf::inflate::LaneLayout>(src, src_n, seg_begin, seg_end, sub[2 * r], r < 31 ? sub[2 * r + 2] : 0, r == 31, ob, oe,
                                     tokens_out + sub[2 * r + 1], mem, n);
     if (!st && r < 31 && sub[2 * r + 1] + n != sub[2 * r + 3]) st = sf::inflate::kError;
     if (r == 31) *ntok = sub[2 * r + 1] + n;

@@ -10,7 +10,8 @@ import sys
 
 
 def short(name):
-    return name.split("(")[0].replace("sf::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("sf::", "")
+    return name.split("(")[0]
 
 
 def main():
