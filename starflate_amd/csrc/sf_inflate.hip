@@ -10,12 +10,12 @@
 //                     decode_segment() (sf_inflate_core.h) with its own code tables in a 2,308-byte slice
 //                     of LDS (144 KiB per workgroup) and its own 64-bit bit buffer fed by dword loads one
 //                     refill ahead.  Output: the k_lz77 token format, four tokens per 16-byte store.
-//   k_inflate_bytes   the byte-copy half (src/decompress.cpp:157-187,388-398), one 1024-thread workgroup per
-//                     segment, 96 KiB of LDS: a workgroup prefix sum over the token lengths places every
-//                     token; each output byte gets a 16-bit pointer (a literal to itself, a match byte to the
-//                     byte `distance` before it); pointer jumping resolves all copy chains at once in <= 15
-//                     barrier-separated rounds, whatever the nesting or overlap; every byte then fetches its
-//                     literal and the window leaves with 16-byte stores.  A segment that is one stored block
+//   k_inflate_bytes   the byte-copy half (src/decompress.cpp:157-187,388-398), one 512-thread workgroup per
+//                     segment, the 32 KiB output window in LDS, steps of <= 1024 tokens / 3968 bytes: a
+//                     workgroup prefix sum places the tokens, every thread then takes BYTES (token found by
+//                     bitmap + popcount): sources before the step are final and copied at once, sources
+//                     inside it become 16-bit pointers that pointer jumping resolves in a few barrier-
+//                     separated rounds, whatever the nesting or overlap.  A segment that is one stored block
 //                     is copied straight from the stream.
 //   k_inflate_status  first non-zero segment status in stream order = what the serial decoder would report.
 #include "sf_device.h"
@@ -29,9 +29,8 @@ constexpr uint32_t KT_LANES = 64;
 constexpr uint32_t KT_LDS = KT_LANES * inflate::LaneLayout::kBytes;
 constexpr uint32_t KB_THREADS = 512;
 constexpr uint32_t KB_TPT = 2;     // tokens per thread per step
-constexpr uint32_t KB_SPAN = 3968;  // output bytes per step (pointer array); 4 workgroups of 40 KiB per CU
-constexpr uint32_t KB_LDS = kChunk + 2 * KB_SPAN + 64;
-constexpr uint32_t KB_SHORT = 16;  // a thread writes this many pointers of its match itself, the wave the rest
+constexpr uint32_t KB_SPAN = 3968;  // output bytes per step (pointer array)
+constexpr uint32_t KB_LDS = kChunk + 2 * KB_SPAN + 4 * KB_THREADS * KB_TPT + 8 * (KB_SPAN / 32) + 64;
 
 __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __restrict__ src, uint64_t src_n,
                                                             const uint64_t* __restrict__ index, uint32_t nseg,
@@ -204,20 +203,28 @@ __device__ __forceinline__ uint32_t load_word_guarded(const uint8_t* base, uint6
 }
 
 // The byte-copy half (src/decompress.cpp:157-187,388-398).  Tokens are placed in steps of up to 1024 tokens /
-// 3968 output bytes by a workgroup prefix sum.  A match byte whose source lies before the step is final already
-// and is copied at once; one whose source lies inside the step gets a 16-bit pointer to it, and pointer jumping
-// (ptr[j] = ptr[ptr[j]], barrier-separated rounds, at most log2(3968)) takes every such byte to a final one,
-// however the matches of the step nest or overlap themselves; then the byte is fetched.  40 KiB of LDS (the
-// 32 KiB window + one step of pointers), so four workgroups share a CU and hide each other's barriers.
+// 3968 output bytes by a workgroup prefix sum; a bitmap of token starts plus per-word popcount prefixes then
+// lets every THREAD TAKE BYTES, not tokens: byte j finds its token with two broadcast reads and a popcount, so
+// all lanes work whatever the match lengths are.  A match byte whose source lies before the step is final
+// already and is copied at once; one whose source lies inside the step gets a 16-bit pointer to it, and pointer
+// jumping (ptr[j] = ptr[ptr[j]], barrier-separated rounds, at most log2(3968)) takes every such byte to a final
+// one, however the matches of the step nest or overlap themselves; then the byte is fetched.  45 KiB of LDS (the
+// 32 KiB window + one step of pointers and token records): three workgroups share a CU and hide each other's
+// barriers.
 __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __restrict__ src, uint64_t src_n,
                                                               const uint32_t* __restrict__ tokens,
                                                               SegInfo* __restrict__ info, uint8_t* __restrict__ dst) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
-  uint8_t* s_out = s_dyn;                                               // [32768] the segment's output window
-  uint16_t* s_ptr = reinterpret_cast<uint16_t*>(s_dyn + kChunk);       // [KB_SPAN] step-relative source, or kFinal
-  uint32_t* s_w = reinterpret_cast<uint32_t*>(s_dyn + kChunk + 2 * KB_SPAN);  // [8] wave totals, [2] next step
+  uint8_t* s_out = s_dyn;                                          // [32768] the segment's output window
+  uint16_t* s_ptr = reinterpret_cast<uint16_t*>(s_dyn + kChunk);  // [KB_SPAN] step-relative source, or kFinal
+  uint32_t* s_tinfo = reinterpret_cast<uint32_t*>(s_dyn + kChunk + 2 * KB_SPAN);  // [1024] start | match | byte or dist-1
+  uint32_t* s_mark = s_tinfo + KB_THREADS * KB_TPT;                // [KB_SPAN / 32] bit: a token starts here
+  uint32_t* s_wpre = s_mark + KB_SPAN / 32;                        // [KB_SPAN / 32] tokens starting before the word
+  uint32_t* s_w = s_wpre + KB_SPAN / 32;                           // [8] wave totals, [2] next step
   uint32_t* s_next = s_w + KB_THREADS / 64;
   constexpr uint32_t kFinal = 0xFFFFu;
+  constexpr uint32_t kWords = KB_SPAN / 32;
+  static_assert(kWords <= 128 && KB_SPAN % 32 == 0, "one wave scans the bitmap, two words per lane");
   const uint32_t seg = blockIdx.x, t = threadIdx.x, lane = t & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const SegInfo si = info[seg];
@@ -249,11 +256,13 @@ __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __r
     s_next[0] = 0;  // tokens placed by the step
     s_next[1] = 0;  // where its output ends
   }
+  if (t < kWords) s_mark[t] = 0;
+  uint32_t nextA = KB_TPT * t < ntok ? tk[KB_TPT * t] : 0u, nextB = KB_TPT * t + 1 < ntok ? tk[KB_TPT * t + 1] : 0u;
   while (tok_base < ntok) {
-    // ---- place up to two tokens per thread ----
+    // ---- place up to two tokens per thread (loaded while the previous step was being resolved) ----
     const uint32_t i0 = tok_base + KB_TPT * t;
     const bool vA = i0 < ntok, vB = i0 + 1 < ntok;
-    const uint32_t tokA = vA ? tk[i0] : 0u, tokB = vB ? tk[i0 + 1] : 0u;
+    const uint32_t tokA = nextA, tokB = nextB;
     const bool mA = vA && (tokA >> 31), mB = vB && (tokB >> 31);
     const uint32_t lenA = vA ? (mA ? ((tokA >> 16) & 0xFFu) + 3u : 1u) : 0u;
     const uint32_t lenB = vB ? (mB ? ((tokB >> 16) & 0xFFu) + 3u : 1u) : 0u;
@@ -287,76 +296,92 @@ __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __r
         atomicMax(&s_next[1], fmax);
       }
     }
-    // ---- paint: literals, final copies, step-relative pointers ----
-    auto paint = [&](bool fit, bool is_m, uint32_t tok, uint32_t start, uint32_t len, uint32_t dist) {
-      if (fit && !bad) {
-        const uint32_t rel = start - pos0;
-        if (!is_m) {
-          s_out[start] = (uint8_t)tok;
-          s_ptr[rel] = (uint16_t)kFinal;
-        } else {
-          const uint32_t from = start - dist;
-          const uint32_t n0 = len < KB_SHORT ? len : KB_SHORT;
-          for (uint32_t k = 0; k < n0; ++k) {
-            const uint32_t sp = from + k;
-            if (sp < pos0) {
-              s_out[start + k] = s_out[sp];
-              s_ptr[rel + k] = (uint16_t)kFinal;
-            } else {
-              s_ptr[rel + k] = (uint16_t)(sp - pos0);
-            }
-          }
-        }
-      }
-      uint64_t rest = __ballot(fit && !bad && is_m && len > KB_SHORT);
-      while (rest) {
-        const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
-        rest &= rest - 1;
-        const uint32_t s0 = __builtin_amdgcn_readlane(start, l);
-        const uint32_t d0 = __builtin_amdgcn_readlane(dist, l);
-        const uint32_t n = __builtin_amdgcn_readlane(len, l);
-        for (uint32_t k = KB_SHORT + lane; k < n; k += 64) {
-          const uint32_t sp = s0 + k - d0;
-          if (sp < pos0) {
-            s_out[s0 + k] = s_out[sp];
-            s_ptr[s0 - pos0 + k] = (uint16_t)kFinal;
-          } else {
-            s_ptr[s0 - pos0 + k] = (uint16_t)(sp - pos0);
-          }
-        }
-      }
-    };
-    paint(fA, mA, tokA, startA, lenA, distA);
-    paint(fB, mB, tokB, startB, lenB, distB);
+    // token records and the bitmap of token starts (step-relative)
+    if (fA && !bad) {
+      const uint32_t r = startA - pos0;
+      s_tinfo[KB_TPT * t] = r | (mA ? 0x1000u | ((distA - 1u) << 16) : (tokA & 0xFFu) << 16);
+      atomicOr(&s_mark[r >> 5], 1u << (r & 31));
+    }
+    if (fB && !bad) {
+      const uint32_t r = startB - pos0;
+      s_tinfo[KB_TPT * t + 1] = r | (mB ? 0x1000u | ((distB - 1u) << 16) : (tokB & 0xFFu) << 16);
+      atomicOr(&s_mark[r >> 5], 1u << (r & 31));
+    }
     if (__syncthreads_or(bad)) {
       if (t == 0) info[seg].status = inflate::kError;
       return;
     }
     const uint32_t next_tok = tok_base + s_next[0], next_pos = s_next[1];
     const uint32_t span_n = next_pos - pos0;
+    {
+      const uint32_t n0 = next_tok + KB_TPT * t;  // the next step's tokens: in flight during paint and jumping
+      nextA = n0 < ntok ? tk[n0] : 0u;
+      nextB = n0 + 1 < ntok ? tk[n0 + 1] : 0u;
+    }
+    if (wave == 0) {
+      // tokens starting before each bitmap word: one wave, two words per lane
+      const uint32_t a = 2 * lane < kWords ? (uint32_t)__popc(s_mark[2 * lane]) : 0u;
+      const uint32_t b2 = 2 * lane + 1 < kWords ? (uint32_t)__popc(s_mark[2 * lane + 1]) : 0u;
+      const uint32_t inc2 = wave_scan_incl(a + b2, lane);
+      if (2 * lane < kWords) s_wpre[2 * lane] = inc2 - a - b2;
+      if (2 * lane + 1 < kWords) s_wpre[2 * lane + 1] = inc2 - b2;
+    }
+    __syncthreads();
+    // ---- every thread takes bytes: find the token, then literal / final copy / step-relative pointer ----
+#pragma unroll
+    for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i) {
+      const uint32_t j = t + KB_THREADS * i;
+      if (j < span_n) {
+        const uint32_t w = j >> 5;
+        const uint32_t idx = s_wpre[w] + (uint32_t)__popc(s_mark[w] & (0xFFFFFFFFu >> (31u - (j & 31u)))) - 1u;
+        const uint32_t ti = s_tinfo[idx];
+        if (!(ti & 0x1000u)) {
+          s_out[pos0 + j] = (uint8_t)(ti >> 16);
+          s_ptr[j] = (uint16_t)kFinal;
+        } else {
+          const uint32_t dist = (ti >> 16) + 1u;
+          if (dist > j) {  // source before the step: final
+            s_out[pos0 + j] = s_out[pos0 + j - dist];
+            s_ptr[j] = (uint16_t)kFinal;
+          } else {
+            s_ptr[j] = (uint16_t)(j - dist);
+          }
+        }
+      }
+    }
+    __syncthreads();
     // ---- pointer jumping inside the step; a pointer only ever moves to an ancestor, so in place is fine ----
     for (;;) {  // ends: every change moves a pointer to a strictly smaller index
       bool changed = false;
-      for (uint32_t j = t; j < span_n; j += KB_THREADS) {
-        const uint32_t p = s_ptr[j];
-        if (p != kFinal) {
-          const uint32_t q = s_ptr[p];
-          if (q != kFinal) {
-            s_ptr[j] = (uint16_t)q;
-            changed = true;
+#pragma unroll
+      for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i) {
+        const uint32_t j = t + KB_THREADS * i;
+        if (j < span_n) {
+          const uint32_t p = s_ptr[j];
+          if (p != kFinal) {
+            const uint32_t q = s_ptr[p];
+            if (q != kFinal) {
+              s_ptr[j] = (uint16_t)q;
+              changed = true;
+            }
           }
         }
       }
       if (!__syncthreads_or(changed)) break;
     }
-    for (uint32_t j = t; j < span_n; j += KB_THREADS) {
-      const uint32_t p = s_ptr[j];
-      if (p != kFinal) s_out[pos0 + j] = s_out[pos0 + p];  // p is final since the paint phase
+#pragma unroll
+    for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i) {
+      const uint32_t j = t + KB_THREADS * i;
+      if (j < span_n) {
+        const uint32_t p = s_ptr[j];
+        if (p != kFinal) s_out[pos0 + j] = s_out[pos0 + p];  // p is final since the paint phase
+      }
     }
     if (t == 0) {
       s_next[0] = 0;
       s_next[1] = 0;
     }
+    if (t < kWords) s_mark[t] = 0;
     __syncthreads();
     tok_base = next_tok;
     pos0 = next_pos;
