@@ -213,7 +213,8 @@ def main():
         dp = _c.device_props(local_rank)
         roofline["device"] = {"name": dp["name"], "arch": dp["arch"], "compute_units": dp["compute_units"],
                               "memory_clock_khz": dp["memory_clock_khz"], "memory_bus_bits": dp["memory_bus_bits"],
-                              "hbm_peak_from_props_GBs": round(2 * dp["memory_clock_khz"] * 1e3 * dp["memory_bus_bits"] / 8 / 1e9, 1)}
+                              # HBM3E moves 8 Gb/s per pin = 4 transfers per reported 2 GHz memory clock
+                              "hbm_peak_from_props_GBs": round(4 * dp["memory_clock_khz"] * 1e3 * dp["memory_bus_bits"] / 8 / 1e9, 1)}
     except Exception as e:  # noqa: BLE001
         roofline["device"] = {"error": str(e)}
     kern_total_ms = sum(stage_ms.values())

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <span>
 #include <utility>
+#include <vector>
 
 namespace starflate {
 
@@ -37,6 +38,15 @@ struct compress_options {
 };
 
 inline auto compress_bound(std::size_t n) -> std::size_t { return sfh_compress_bound(n); }
+
+/// What makes a stream of this library decodable in parallel (on the GPU): the first stream byte of every
+/// 32 KiB segment plus the end of the last one, and optionally, per segment, 32 x {bit offset of a parse region's
+/// first token code, tokens before it}.  Side information: the stream itself is plain DEFLATE.
+struct stream_index {
+  std::vector<std::uint64_t> offsets;  // segments + 1
+  std::vector<std::uint32_t> regions;  // segments * 64, or empty
+  [[nodiscard]] auto segments() const -> std::size_t { return offsets.empty() ? 0 : offsets.size() - 1; }
+};
 
 namespace detail {
 inline auto to_status(int rc) -> CompressStatus {
@@ -83,6 +93,33 @@ class compressor {
     const int rc = sfh_compress(ctx_, src.data(), src.size(), dst.data(), dst.size(), &n, &c);
     if (rc != SFH_OK) return compat::unexpected{detail::to_status(rc)};
     return n;
+  }
+  /// index of the last compress call on this object (with_regions: also the per-region sub-index)
+  auto index(bool with_regions = true) -> compat::expected<stream_index, CompressStatus> {
+    if (!ctx_) return compat::unexpected{init_};
+    stream_index ix;
+    const std::size_t n = sfh_index_entries(ctx_);
+    if (n == 0) return compat::unexpected{CompressStatus::InvalidArgument};
+    ix.offsets.resize(n);
+    int rc = sfh_copy_index(ctx_, ix.offsets.data(), n, 0, nullptr);
+    if (rc == SFH_OK && with_regions) {
+      ix.regions.resize((n - 1) * SFH_SUBINDEX_WORDS);
+      rc = sfh_copy_subindex(ctx_, ix.regions.data(), ix.regions.size(), 0, nullptr);
+    }
+    if (rc != SFH_OK) return compat::unexpected{detail::to_status(rc)};
+    return ix;
+  }
+  /// decompress() on the GPU for an indexed stream: same statuses as the serial one (src/decompress.hpp:13-23),
+  /// reported for the first failing segment in stream order.  dst.size() is the exact output size.
+  /// A problem on the device side (no device, allocation) is DecompressStatus::Error.
+  auto decompress(std::span<const std::byte> src, std::span<std::byte> dst, const stream_index& ix) -> DecompressStatus {
+    if (!ctx_ || ix.offsets.size() < 2 || (!ix.regions.empty() && ix.regions.size() != ix.segments() * SFH_SUBINDEX_WORDS))
+      return DecompressStatus::Error;
+    std::uint32_t st = 0;
+    const int rc = sfh_decompress(ctx_, src.data(), src.size(), ix.offsets.data(), ix.regions.empty() ? nullptr : ix.regions.data(),
+                                  ix.segments(), dst.data(), dst.size(), &st);
+    if (rc != SFH_OK || st > 7) return DecompressStatus::Error;
+    return static_cast<DecompressStatus>(st);
   }
   /// device pointers (src 16-byte aligned), optional hipStream_t
   auto compress_device(const void* d_src, std::size_t n, void* d_dst, std::size_t cap, const compress_options& opt = {},

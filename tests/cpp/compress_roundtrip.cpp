@@ -70,6 +70,43 @@ auto main(int argc, char** argv) -> int {
     const auto r2 = gpu.compress(html, comp, opt);
     if (r2 || r2.error() != CompressStatus::InvalidArgument) { std::printf("expected InvalidArgument\n"); ++fail; }
   }
+  // the GPU decoder through the C++ API: index from the compressor, same bytes as the serial decoder, with and
+  // without the region sub-index; a corrupted stream reports the serial decoder's status
+  for (const bool regions : {true, false}) {
+    for (const auto& in : inputs) {
+      std::vector<std::byte> comp(compress_bound(in.size()));
+      const auto n = gpu.compress(in, comp);
+      const auto ix = gpu.index(regions);
+      if (!n || !ix) { std::printf("compress/index failed\n"); ++fail; continue; }
+      comp.resize(*n);
+      std::vector<std::byte> back(in.size()), serial(in.size());
+      const auto st = gpu.decompress(comp, back, *ix);
+      const auto st2 = decompress(comp, serial);
+      if (st != DecompressStatus::Success || st2 != DecompressStatus::Success || back != in || back != serial) {
+        std::printf("GPU decompress failed: regions %d size %zu status %d\n", int(regions), in.size(), static_cast<int>(st));
+        ++fail;
+      }
+    }
+  }
+  {
+    compress_options opt;
+    opt.strategy = BlockStrategy::Stored;
+    std::vector<std::byte> comp(compress_bound(html.size()));
+    const auto n = gpu.compress(html, comp, opt);
+    const auto ix = gpu.index(false);
+    if (n && ix) {
+      comp.resize(*n);
+      comp[static_cast<std::size_t>(ix->offsets[1]) + 3] ^= std::byte{1};  // NLEN of the second stored block
+      std::vector<std::byte> back(html.size());
+      if (gpu.decompress(comp, back, *ix) != DecompressStatus::NoCompressionLenMismatch ||
+          decompress(comp, back) != DecompressStatus::NoCompressionLenMismatch) {
+        std::printf("expected NoCompressionLenMismatch from both decoders\n");
+        ++fail;
+      }
+    } else {
+      ++fail;
+    }
+  }
   // too-small destination: status, no exception
   std::vector<std::byte> tiny(8);
   const auto r = gpu.compress(html, tiny);
