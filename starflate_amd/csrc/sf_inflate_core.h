@@ -83,26 +83,38 @@ SF_HD void distance_info(uint32_t sym /*0..29*/, uint32_t& base, uint32_t& extra
   base = 1 + ((2 + (sym & 1)) << extra);
 }
 
+// Bit positions inside a segment are 32-bit: a segment yields at most 32 KiB, so its bits are capped at 2^31
+// (anything longer is padding or garbage and ends in a status either way).
 struct BitReader {
-  const uint8_t* base;  // stream buffer, 4-byte aligned, readable up to the next multiple of 4 bytes
-  uint64_t src_n;       // bytes in the buffer (> 0); no dword starting at or past it is read
-  uint64_t word;        // next dword to load
+  const uint32_t* seg32;  // dword holding the segment's first byte (the buffer is 4-byte aligned and readable
+                          // up to the next multiple of 4 bytes)
+  uint32_t last;          // index, from seg32, of the last dword of the buffer: nothing past it is read
+  uint32_t word;          // index of the next dword to load
+  uint32_t first_byte;    // offset of the segment's first byte inside seg32[0]
   uint64_t buf;
   uint32_t cnt;
-  uint32_t next;        // dword `word - 1`, loaded one refill ahead of its use
-  uint64_t bitpos;      // bits consumed since the segment began
-  uint64_t nbits;       // bits the segment holds
+  uint32_t next;          // dword `word - 1`, loaded one refill ahead of its use
+  uint32_t bitpos;        // bits consumed since the segment began
+  uint32_t nbits;         // bits the segment holds
 
+  SF_HD void open(const uint8_t* base, uint64_t src_n /* > 0 */, uint64_t seg_begin, uint64_t seg_end) {
+    const uint64_t w0 = seg_begin >> 2, wl = (src_n - 1) >> 2;
+    seg32 = reinterpret_cast<const uint32_t*>(base) + w0;
+    last = wl - w0 < 0xFFFFFFF0ull ? (uint32_t)(wl - w0) : 0xFFFFFFF0u;
+    first_byte = (uint32_t)(seg_begin & 3);
+    const uint64_t nb = 8 * (seg_end - seg_begin);
+    nbits = nb < 0x80000000ull ? (uint32_t)nb : 0x80000000u;
+    bitpos = 0;
+    seek(0);
+  }
   // Branch-free on purpose: the refill loads one dword ahead of its use, and a branch around the load would
   // make the compiler wait for it on the spot (a full memory round trip per refill).  Past the end the last
   // dword repeats; only a truncated or corrupt stream gets that far, and it ends in an error status.
-  SF_HD uint32_t load_word(uint64_t w) const {
-    const uint64_t last = (src_n - 1) >> 2;
-    return reinterpret_cast<const uint32_t*>(base)[w < last ? w : last];
-  }
-  SF_HD void seek(uint64_t byte) {  // bit accounting is left alone
-    word = byte >> 2;
-    const uint32_t sh = 8 * (uint32_t)(byte & 3);
+  SF_HD uint32_t load_word(uint32_t w) const { return seg32[w < last ? w : last]; }
+  SF_HD void seek(uint32_t byte) {  // byte offset from the segment's first byte; bit accounting is left alone
+    const uint32_t b = byte + first_byte;
+    word = b >> 2;
+    const uint32_t sh = 8 * (b & 3);
     buf = (uint64_t)(load_word(word++) >> sh);
     cnt = 32 - sh;
     next = load_word(word++);
@@ -123,6 +135,12 @@ struct BitReader {
   SF_HD uint32_t get(uint32_t n) {
     const uint32_t v = peek(n);
     drop(n);
+    return v;
+  }
+  // `a` bits of a code, then a `b`-bit field: one shift of the buffer instead of two
+  SF_HD uint32_t drop_get(uint32_t a, uint32_t b) {
+    const uint32_t v = ((uint32_t)(buf >> a)) & ((1u << b) - 1u);
+    drop(a + b);
     return v;
   }
   SF_HD bool overrun() const { return bitpos > nbits; }
@@ -345,7 +363,7 @@ SF_HD uint32_t read_tables(BitReader& br, uint8_t* m, uint32_t type) {
 // produced before / after; out_limit: where this caller's output must end at the latest.
 template <class L, class Sink>
 SF_HD uint32_t decode_symbols(BitReader& br, const uint8_t* m, Sink& sink, uint32_t& out_pos, uint32_t out_limit,
-                              uint64_t end_bit, bool& hit_eob) {
+                              uint32_t end_bit, bool& hit_eob) {
   hit_eob = false;
   while (br.bitpos < end_bit) {
     sink.tick();
@@ -353,29 +371,29 @@ SF_HD uint32_t decode_symbols(BitReader& br, const uint8_t* m, Sink& sink, uint3
     uint32_t sym;
     const uint32_t l = decode_symbol<L, true>(m, br, sym);
     if (l == 0) return kInvalidLitOrLen;
-    br.drop(l);
     if (sym < 256) {
+      br.drop(l);
       if (out_pos >= out_limit) return kDstTooSmall;
       sink.put(sym);
       ++out_pos;
       continue;
     }
     if (sym == 256) {
+      br.drop(l);
       hit_eob = true;
       break;
     }
     if (sym > 285) return kInvalidLitOrLen;
     uint32_t lbase, lextra;
     length_info(sym, lbase, lextra);
-    const uint32_t len = lbase + br.get(lextra);
+    const uint32_t len = lbase + br.drop_get(l, lextra);
     br.refill();
     uint32_t dsym;
     const uint32_t dl = decode_symbol<L, false>(m, br, dsym);
     if (dl == 0 || dsym > 29) return kInvalidDistance;
-    br.drop(dl);
     uint32_t dbase, dextra;
     distance_info(dsym, dbase, dextra);
-    const uint32_t dist = dbase + br.get(dextra);
+    const uint32_t dist = dbase + br.drop_get(dl, dextra);
     if (dist > out_pos) return kInvalidDistance;  // src/decompress.cpp:178
     if (len > out_limit - out_pos) return kDstTooSmall;
     sink.put(kTokMatchBit | ((len - 3) << 16) | (dist - 1));
@@ -399,11 +417,7 @@ SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t 
     return r;
   }
   BitReader br;
-  br.base = src;
-  br.src_n = src_n;
-  br.bitpos = 0;
-  br.nbits = 8 * (seg_end - seg_begin);
-  br.seek(seg_begin);
+  br.open(src, src_n, seg_begin, seg_end);
   TokenSink sink{tokens, 0, 0, 0, 0};
   uint32_t out_pos = 0;
   uint32_t status = kOk;
@@ -427,9 +441,10 @@ SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t 
       br.refill();
       const uint32_t nlen = br.get(16);
       if ((len ^ nlen) != 0xFFFFu) { status = kNoCompressionLenMismatch; break; }
-      if (br.bitpos + 8ull * len > br.nbits) { status = kSrcTooSmall; break; }
+      if (br.bitpos + 8 * len > br.nbits) { status = kSrcTooSmall; break; }
       if (len > out_n - out_pos) { status = kDstTooSmall; break; }
-      const uint64_t data_at = seg_begin + (br.bitpos >> 3);
+      const uint32_t data_rel = br.bitpos >> 3;
+      const uint64_t data_at = seg_begin + data_rel;
       if (sink.n == 0 && out_pos == 0 && len == out_n && len != 0) {
         r.raw = 1;  // the whole segment is this block: the byte-copy kernel takes it from the stream
         r.raw_off = data_at;
@@ -438,14 +453,14 @@ SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t 
         for (uint32_t k = 0; k < len; ++k) sink.put(src[data_at + k]);
         out_pos += len;
       }
-      br.bitpos += 8ull * len;
-      br.seek(data_at + len);
+      br.bitpos += 8 * len;
+      br.seek(data_rel + len);
       continue;
     }
     status = read_tables<LaneLayout>(br, m, type);
     if (status != kOk) break;
     bool eob;
-    status = decode_symbols<LaneLayout>(br, m, sink, out_pos, out_n, ~0ull, eob);
+    status = decode_symbols<LaneLayout>(br, m, sink, out_pos, out_n, ~0u, eob);
   }
   if (status == kOk && out_pos != out_n) status = kSrcTooSmall;  // the index promised more bytes
   if (status == kOk && r.raw && sink.n != 0) status = kDstTooSmall;
@@ -469,11 +484,7 @@ SF_HD uint32_t open_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_beg
   if (seg_begin > seg_end || seg_end > src_n) return kSrcTooSmall;
   if (seg_begin == seg_end) return kInvalidBlockHeader;
   BitReader br;
-  br.base = src;
-  br.src_n = src_n;
-  br.bitpos = 0;
-  br.nbits = 8 * (seg_end - seg_begin);
-  br.seek(seg_begin);
+  br.open(src, src_n, seg_begin, seg_end);
   if (br.nbits < 3) return kInvalidBlockHeader;
   br.refill();
   br.drop(1);  // BFINAL: the segment ends with its block either way
@@ -486,7 +497,7 @@ SF_HD uint32_t open_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_beg
     br.refill();
     const uint32_t nlen = br.get(16);
     if ((len ^ nlen) != 0xFFFFu) return kNoCompressionLenMismatch;
-    if (40 + 8ull * len > br.nbits) return kSrcTooSmall;
+    if (40 + 8 * len > br.nbits) return kSrcTooSmall;
     if (len != out_n) return len > out_n ? kDstTooSmall : kSrcTooSmall;
     raw = 1;
     raw_off = seg_begin + 5;
@@ -500,30 +511,29 @@ SF_HD uint32_t open_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_beg
 // One region lane: token codes from bit `bit_begin` of the segment up to `bit_end` (or to the end-of-block code
 // when until_eob), which must produce exactly the bytes [out_begin, out_end) of the segment.
 template <class L>
-SF_HD uint32_t decode_region(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end, uint64_t bit_begin,
-                             uint64_t bit_end, bool until_eob, uint32_t out_begin, uint32_t out_end, uint32_t* tokens,
+SF_HD uint32_t decode_region(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end, uint32_t bit_begin,
+                             uint32_t bit_end, bool until_eob, uint32_t out_begin, uint32_t out_end, uint32_t* tokens,
                              const uint8_t* m, uint32_t& ntok, uint32_t* lane_buf = nullptr) {
   ntok = 0;
+  if (seg_begin >= seg_end || seg_end > src_n) return kError;
   BitReader br;
-  br.base = src;
-  br.src_n = src_n;
-  br.nbits = 8 * (seg_end - seg_begin);
-  if (br.nbits == 0 || bit_begin > br.nbits || (!until_eob && (bit_end < bit_begin || bit_end > br.nbits))) return kError;
-  br.seek(seg_begin + (bit_begin >> 3));
-  br.bitpos = bit_begin & ~7ull;
+  br.open(src, src_n, seg_begin, seg_end);
+  if (bit_begin > br.nbits || (!until_eob && (bit_end < bit_begin || bit_end > br.nbits))) return kError;
+  br.seek(bit_begin >> 3);
+  br.bitpos = bit_begin & ~7u;
   br.refill();
-  br.drop((uint32_t)(bit_begin & 7));
+  br.drop(bit_begin & 7u);
   uint32_t out_pos = out_begin;
   bool eob;
   uint32_t st;
   if (lane_buf) {
     BufferedSink sink{tokens, lane_buf, 0, 0, 0};
-    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0ull : bit_end, eob);
+    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0u : bit_end, eob);
     sink.flush();
     ntok = sink.n;
   } else {
     PlainSink sink{tokens, 0};
-    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0ull : bit_end, eob);
+    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0u : bit_end, eob);
     ntok = sink.n;
   }
   if (st != kOk) return st;

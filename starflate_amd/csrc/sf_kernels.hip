@@ -544,7 +544,6 @@ __device__ __forceinline__ void or_bits(uint32_t* stage, uint32_t bitpos, uint64
 
 struct PlanSmem {
   uint32_t freq[kHistStride];
-  uint32_t ukey[288];
   uint32_t key[288];
   uint32_t w[576];
   uint16_t parent[576];
