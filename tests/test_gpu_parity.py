@@ -228,3 +228,29 @@ def test_pipelined_rounds_over_rccl_single_rank(compressor):
         assert np.array_equal(stream, want)
     finally:
         dist.destroy_process_group()
+
+
+def test_fixture_tool_matches_reference_cli(starfleet, tmp_path):
+    """tools/deflate_compress_gpu.py has the switches of the reference's tools/deflate_compress.py (--src, --fixed)
+    and writes the same kind of fixture: raw DEFLATE on stdout, here bit-exact with the specification."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import GOLDEN, ROOT
+
+    src = os.path.join(GOLDEN, "starfleet.html")
+    data = np.frombuffer(starfleet, np.uint8)
+    for extra, strategy in (([], "auto"), (["--fixed"], "fixed")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "deflate_compress_gpu.py"), "--src", src] + extra,
+                             capture_output=True, timeout=300)
+        assert out.returncode == 0, out.stderr.decode()[-500:]
+        got = np.frombuffer(out.stdout, np.uint8)
+        assert np.array_equal(got, O.compress(data, _params(strategy)))
+        assert zlib.decompress(out.stdout, -15) == starfleet
+    npz = tmp_path / "ix.npz"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "deflate_compress_gpu.py"), "--src", src, "--gzip",
+                          "--index", str(npz)], capture_output=True, timeout=300)
+    assert out.returncode == 0 and zlib.decompress(out.stdout, 31) == starfleet
+    ix = np.load(npz)
+    assert int(ix["size"]) == data.size and ix["offsets"].size == 6 and ix["regions"].shape == (5, 32, 2)
