@@ -5,6 +5,7 @@
 #pragma once
 #include "starflate/compat/expected.hpp"
 #include "starflate/huffman/huffman.hpp"
+#include "starflate/huffman/lookup_decoder.hpp"
 
 #include <algorithm>
 #include <array>
@@ -76,9 +77,7 @@ inline constexpr std::array<std::uint8_t, 19> kCodeLengthOrder{16, 17, 18, 0, 8,
 /// n (<= 16) bits as an LSB-first integer; nullopt when fewer remain
 inline auto pop_bits(huffman::bit_span& bits, std::uint8_t n) -> std::optional<std::uint16_t> {
   if (std::ranges::size(bits) < n) return std::nullopt;
-  std::uint16_t r = 0;
-  auto it = bits.begin();
-  for (std::uint8_t i = 0; i < n; ++i, ++it) r = static_cast<std::uint16_t>(r | (std::uint16_t{bool(*it)} << i));
+  const auto r = static_cast<std::uint16_t>(bits.peek(n));  // the reference loops over the bits (src/decompress.cpp:94-114)
   bits.consume(n);
   return r;
 }
@@ -94,11 +93,16 @@ inline auto fixed_tables() -> const std::pair<dyn_table, dyn_table>& {
   return t;
 }
 
+/// Symbols are decoded through huffman::lookup_decoder (one array read for codes up to 9 / 7 bits, the
+/// reference's per-bit walk, src/decompress.cpp:122-187 via huffman/src/decode.hpp:83-102, for the rest): same
+/// results, a faster host-side checker.
 template <class Table>
 auto inflate_block(huffman::bit_span& bits, std::span<std::byte> dst, std::ptrdiff_t& written, const Table& lt,
                    const Table& dt) -> DecompressStatus {
+  const huffman::lookup_decoder<std::uint16_t, 9> fast_ll{lt};
+  const huffman::lookup_decoder<std::uint16_t, 7> fast_d{dt};
   for (;;) {
-    const auto ll = huffman::decode_one(lt, bits);
+    const auto ll = fast_ll.decode_one(lt, bits);
     if (!ll.has_value()) return DecompressStatus::InvalidLitOrLen;
     bits.consume(ll.encoded_size());
     const std::uint16_t sym = ll.symbol();
@@ -113,7 +117,7 @@ auto inflate_block(huffman::bit_span& bits, std::span<std::byte> dst, std::ptrdi
     const auto lx = pop_bits(bits, li.extra);
     if (!lx) return DecompressStatus::Error;
     const auto len = static_cast<std::uint16_t>(li.base + *lx);
-    const auto dd = huffman::decode_one(dt, bits);
+    const auto dd = fast_d.decode_one(dt, bits);
     if (!dd.has_value()) return DecompressStatus::InvalidDistance;
     bits.consume(dd.encoded_size());
     if (dd.symbol() >= kDistance.size()) return DecompressStatus::InvalidLitOrLen;

@@ -102,6 +102,17 @@ class bit_span : public std::ranges::view_interface<bit_span> {
   constexpr auto consume_to_byte_boundary() -> void {
     if (bit_offset_) consume(static_cast<std::size_t>(CHAR_BIT - bit_offset_));
   }
+  /// The first min(n, size()) bits as an integer, first bit in bit 0 (n <= 24).  Not in the reference's
+  /// bit_span: it feeds huffman::lookup_decoder, which replaces one table::find per bit by one array read.
+  [[nodiscard]] constexpr auto peek(std::uint8_t n) const -> std::uint32_t {
+    assert(n <= 24);
+    const std::size_t take = bit_size_ < n ? bit_size_ : n;
+    if (take == 0) return 0;
+    const std::size_t nbytes = (bit_offset_ + take + CHAR_BIT - 1) / CHAR_BIT;  // <= 4
+    std::uint32_t v = 0;
+    for (std::size_t k = 0; k < nbytes; ++k) v |= std::to_integer<std::uint32_t>(data_[k]) << (CHAR_BIT * k);
+    return (v >> bit_offset_) & ((std::uint32_t{1} << take) - 1U);
+  }
   /// @pre byte aligned
   [[nodiscard]] constexpr auto byte_data() const -> const std::byte* {
     assert(bit_offset_ == 0);

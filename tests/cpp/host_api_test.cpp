@@ -7,6 +7,7 @@
 #include "starflate/container.hpp"
 #include "starflate/decompress.hpp"
 #include "starflate/huffman/huffman.hpp"
+#include "starflate/huffman/lookup_decoder.hpp"
 
 #include <cstdio>
 #include <fstream>
@@ -225,6 +226,47 @@ static void test_decompress(const std::string& golden) {
   static_assert(static_cast<int>(DecompressStatus::InvalidDistance) == 7 && static_cast<int>(DecompressStatus::DstTooSmall) == 4);
 }
 
+// lookup_decoder must give exactly what the per-bit decode_one gives: every 16-bit pattern, at every length the
+// input may be cut to, for complete, incomplete and long-code tables
+template <std::uint8_t Bits, class Table>
+static void check_lookup(const Table& t) {
+  const huffman::lookup_decoder<std::uint16_t, Bits> fast{t};
+  for (std::uint32_t pat = 0; pat < (1U << 16U); pat += 7) {
+    const auto bytes = huffman::byte_array(pat & 0xFFU, (pat >> 8U) & 0xFFU, 0xA5);
+    for (const std::size_t nbits : {std::size_t{0}, std::size_t{1}, std::size_t{5}, std::size_t{9}, std::size_t{16}, std::size_t{21}}) {
+      for (const std::uint8_t off : {std::uint8_t{0}, std::uint8_t{3}}) {
+        const huffman::bit_span bits{bytes.data(), nbits, off};
+        const auto a = huffman::decode_one(t, bits);
+        const auto b = fast.decode_one(t, bits);
+        if (a.has_value() != b.has_value() || (a.has_value() && (a.symbol() != b.symbol() || a.encoded_size() != b.encoded_size()))) {
+          CHECK(false);
+          return;
+        }
+      }
+    }
+  }
+  CHECK(true);
+}
+
+static void test_lookup_decoder() {
+  using pairs = std::vector<std::pair<huffman::symbol_span<std::uint16_t>, std::uint8_t>>;
+  using sspan = huffman::symbol_span<std::uint16_t>;
+  // RFC 1951 3.2.2 example, the fixed literal/length code, a code with 12..15-bit members, an incomplete code
+  const pairs rfc{{sspan{0, 4}, 3}, {sspan{5}, 2}, {sspan{6}, 4}, {sspan{7}, 4}};
+  const pairs fixed{{sspan{0, 143}, 8}, {sspan{144, 255}, 9}, {sspan{256, 279}, 7}, {sspan{280, 287}, 8}};
+  const pairs deep{{sspan{0}, 1}, {sspan{1}, 2}, {sspan{2}, 3}, {sspan{3}, 4}, {sspan{4}, 5}, {sspan{5}, 6}, {sspan{6}, 7}, {sspan{7}, 8},
+                   {sspan{8}, 9}, {sspan{9}, 10}, {sspan{10}, 11}, {sspan{11}, 12}, {sspan{12}, 13}, {sspan{13}, 14}, {sspan{14, 15}, 15}};
+  const pairs incomplete{{sspan{3}, 2}, {sspan{9}, 5}};
+  for (const auto* p : {&rfc, &fixed, &deep, &incomplete}) {
+    const huffman::table<std::uint16_t> t{huffman::symbol_bitsize, *p};
+    check_lookup<9>(t);
+    check_lookup<7>(t);
+    check_lookup<1>(t);
+  }
+  const std::array<std::byte, 2> two{std::byte{0xFF}, std::byte{0x01}};
+  CHECK((huffman::bit_span{two.data(), 16}.peek(9) == 0x1FFU && huffman::bit_span{two.data(), 5, 6}.peek(9) == 0x07U));
+}
+
 static auto bytes_of(const char* s) -> std::vector<std::byte> {
   std::vector<std::byte> b;
   for (; *s != 0; ++s) b.push_back(static_cast<std::byte>(*s));
@@ -273,6 +315,7 @@ static void test_container(const std::string& golden, const std::string& wrapped
 auto main(int argc, char** argv) -> int {
   const std::string golden = argc > 1 ? argv[1] : "tests/golden";
   test_container(golden, argc > 2 ? argv[2] : "");
+  test_lookup_decoder();
   test_bit_and_code();
   test_bit_span();
   test_table_from_frequencies();
