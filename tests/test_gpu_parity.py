@@ -254,3 +254,35 @@ def test_fixture_tool_matches_reference_cli(starfleet, tmp_path):
     assert out.returncode == 0 and zlib.decompress(out.stdout, 31) == starfleet
     ix = np.load(npz)
     assert int(ix["size"]) == data.size and ix["offsets"].size == 6 and ix["regions"].shape == (5, 32, 2)
+
+
+def test_async_entry_point_and_independent_contexts():
+    """sfh_compress_device_async only enqueues (size left in device memory); two contexts on two streams run
+    side by side and give the bytes of the synchronous call."""
+    import torch
+
+    from starflate_amd import Compressor
+
+    a, b = Compressor(0), Compressor(0)
+    da = torch.from_numpy(synth.gen_text(9 * CHUNK + 5, seed=41)).cuda()
+    db = torch.from_numpy(synth.gen_mixed(1 << 20, seed=42, stripe=1 << 15)).cuda()
+    want_a, na = a.compress_tensor(da, container="gzip")
+    want_a = want_a[:na].clone()
+    want_b, nb = b.compress_tensor(db)
+    want_b = want_b[:nb].clone()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    oa = torch.zeros(a.compress_bound(da.numel()), dtype=torch.uint8, device="cuda")
+    ob = torch.zeros(b.compress_bound(db.numel()), dtype=torch.uint8, device="cuda")
+    za = torch.zeros(1, dtype=torch.int64, device="cuda")
+    zb = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):  # interleaved enqueues, no host synchronisation in between
+        a.compress_tensor_async(da, oa, za, stream=sa.cuda_stream, container="gzip")
+        b.compress_tensor_async(db, ob, zb, stream=sb.cuda_stream)
+    sa.synchronize()
+    sb.synchronize()
+    assert int(za.item()) == na and torch.equal(oa[:na], want_a)
+    assert int(zb.item()) == nb and torch.equal(ob[:nb], want_b)
+    assert zlib.decompress(oa[:na].cpu().numpy().tobytes(), 31) == da.cpu().numpy().tobytes()
+    a.close()
+    b.close()
