@@ -378,7 +378,6 @@ int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* 
   }
   if (ctx->d_index_cap < nseg + 1) {
     (void)hipFree(ctx->d_index);
-  (void)hipFree(ctx->d_sub);
     ctx->d_index = nullptr;
     ctx->d_index_cap = 0;
     if (hipMalloc(&ctx->d_index, (nseg + 1) * sizeof(uint64_t)) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "index staging", hipSuccess);
