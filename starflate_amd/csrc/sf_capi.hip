@@ -13,7 +13,7 @@ struct sfh_ctx {
   hipStream_t stream = nullptr;  // used when the caller passes no stream
   sf::Workspace ws{};
   uint32_t cap_chunks = 0;       // chunks the workspace can hold
-  uint32_t sums_cap = 0;         // chunks ws.sums can hold
+  size_t sums_cap = 0;           // bytes of ws.sums
   uint32_t last_chunks = 0;
   bool index_valid = false;      // ws.offsets holds the index of the last compress call
   uint64_t* d_total = nullptr;   // own result slot for the synchronous entry points
@@ -24,7 +24,7 @@ struct sfh_ctx {
   size_t d_sub_cap = 0;
   hipEvent_t ev_inf[SFH_INFLATE_NSTAGES + 1] = {};
   bool ev_inf_valid = false;
-  uint8_t* d_in = nullptr;       // staging for the host-buffer entry point
+  uint8_t* d_in = nullptr;       // staging for the host-buffer entry points (capacities in bytes)
   uint8_t* d_out = nullptr;
   size_t d_in_cap = 0, d_out_cap = 0;
   int profiling = 0;
@@ -47,6 +47,19 @@ int fail(sfh_ctx* c, int code, const char* what, hipError_t e) {
     if (_e != hipSuccess) return fail(ctx, SFH_E_HIP, what, _e); \
   } while (0)
 
+// Grow-only device staging buffer: *p holds at least `bytes` afterwards (*cap_bytes tracks it).
+template <class T>
+int grow(sfh_ctx* ctx, T** p, size_t* cap_bytes, size_t bytes, const char* what) {
+  if (*cap_bytes >= bytes) return SFH_OK;
+  (void)hipFree(*p);
+  *p = nullptr;
+  *cap_bytes = 0;
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) return fail(ctx, SFH_E_NOMEM, what, e);
+  *cap_bytes = bytes;
+  return SFH_OK;
+}
+
 void free_ws(sfh_ctx* c) {
   (void)hipFree(c->ws.tokens);
   (void)hipFree(c->ws.ntok);
@@ -66,14 +79,7 @@ void free_ws(sfh_ctx* c) {
 
 // checksum partials: 4 bytes per chunk, needed without the rest of the workspace by sfh_checksum_device
 int ensure_sums(sfh_ctx* ctx, uint32_t nchunks) {
-  if (nchunks <= ctx->sums_cap) return SFH_OK;
-  (void)hipFree(ctx->ws.sums);
-  ctx->ws.sums = nullptr;
-  ctx->sums_cap = 0;
-  hipError_t e = hipMalloc(&ctx->ws.sums, (size_t)nchunks * sizeof(uint32_t));
-  if (e != hipSuccess) return fail(ctx, SFH_E_NOMEM, "checksum scratch hipMalloc", e);
-  ctx->sums_cap = nchunks;
-  return SFH_OK;
+  return grow(ctx, &ctx->ws.sums, &ctx->sums_cap, (size_t)nchunks * sizeof(uint32_t), "checksum scratch");
 }
 
 int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
@@ -269,25 +275,13 @@ int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap,
   if (!ctx || (!src && n) || !dst || !out_n) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
   const size_t bound = sfh_compress_bound(n);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
-  const size_t in_need = n ? n : 16;
-  if (ctx->d_in_cap < in_need) {
-    (void)hipFree(ctx->d_in);
-    ctx->d_in = nullptr;
-    ctx->d_in_cap = 0;
-    if (hipMalloc(&ctx->d_in, in_need) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "input staging", hipSuccess);
-    ctx->d_in_cap = in_need;
-  }
-  if (ctx->d_out_cap < bound) {
-    (void)hipFree(ctx->d_out);
-    ctx->d_out = nullptr;
-    ctx->d_out_cap = 0;
-    if (hipMalloc(&ctx->d_out, bound) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "output staging", hipSuccess);
-    ctx->d_out_cap = bound;
-  }
+  int rc = grow(ctx, &ctx->d_in, &ctx->d_in_cap, n ? n : 16, "input staging");
+  if (!rc) rc = grow(ctx, &ctx->d_out, &ctx->d_out_cap, bound, "output staging");
+  if (rc) return rc;
   hipStream_t s = ctx->stream;
   if (n) SF_HIP(hipMemcpyAsync(ctx->d_in, src, n, hipMemcpyHostToDevice, s), "H2D");
   size_t total = 0;
-  int rc = sfh_compress_device(ctx, ctx->d_in, n, ctx->d_out, bound, &total, opt, s);
+  rc = sfh_compress_device(ctx, ctx->d_in, n, ctx->d_out, bound, &total, opt, s);
   if (rc) return rc;
   if (total > cap) return fail(ctx, SFH_E_DST_TOO_SMALL, "dst capacity below stream size", hipSuccess);
   SF_HIP(hipMemcpyAsync(dst, ctx->d_out, total, hipMemcpyDeviceToHost, s), "D2H");
@@ -361,43 +355,18 @@ int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* 
                    size_t nseg, void* dst, size_t dst_n, uint32_t* status) {
   if (!ctx || !src || !index || !status || (!dst && dst_n)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
-  const size_t in_need = src_n ? src_n : 16, out_need = dst_n ? dst_n : 16;
-  if (ctx->d_in_cap < in_need) {
-    (void)hipFree(ctx->d_in);
-    ctx->d_in = nullptr;
-    ctx->d_in_cap = 0;
-    if (hipMalloc(&ctx->d_in, in_need) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "input staging", hipSuccess);
-    ctx->d_in_cap = in_need;
-  }
-  if (ctx->d_out_cap < out_need) {
-    (void)hipFree(ctx->d_out);
-    ctx->d_out = nullptr;
-    ctx->d_out_cap = 0;
-    if (hipMalloc(&ctx->d_out, out_need) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "output staging", hipSuccess);
-    ctx->d_out_cap = out_need;
-  }
-  if (ctx->d_index_cap < nseg + 1) {
-    (void)hipFree(ctx->d_index);
-    ctx->d_index = nullptr;
-    ctx->d_index_cap = 0;
-    if (hipMalloc(&ctx->d_index, (nseg + 1) * sizeof(uint64_t)) != hipSuccess) return fail(ctx, SFH_E_NOMEM, "index staging", hipSuccess);
-    ctx->d_index_cap = nseg + 1;
-  }
-  if (subindex && ctx->d_sub_cap < nseg * SFH_SUBINDEX_WORDS) {
-    (void)hipFree(ctx->d_sub);
-    ctx->d_sub = nullptr;
-    ctx->d_sub_cap = 0;
-    if (hipMalloc(&ctx->d_sub, nseg * SFH_SUBINDEX_WORDS * sizeof(uint32_t)) != hipSuccess)
-      return fail(ctx, SFH_E_NOMEM, "sub-index staging", hipSuccess);
-    ctx->d_sub_cap = nseg * SFH_SUBINDEX_WORDS;
-  }
+  int rc = grow(ctx, &ctx->d_in, &ctx->d_in_cap, src_n ? src_n : 16, "input staging");
+  if (!rc) rc = grow(ctx, &ctx->d_out, &ctx->d_out_cap, dst_n ? dst_n : 16, "output staging");
+  if (!rc) rc = grow(ctx, &ctx->d_index, &ctx->d_index_cap, (nseg + 1) * sizeof(uint64_t), "index staging");
+  if (!rc && subindex) rc = grow(ctx, &ctx->d_sub, &ctx->d_sub_cap, nseg * SFH_SUBINDEX_WORDS * sizeof(uint32_t), "sub-index staging");
+  if (rc) return rc;
   hipStream_t s = ctx->stream;
   if (src_n) SF_HIP(hipMemcpyAsync(ctx->d_in, src, src_n, hipMemcpyHostToDevice, s), "H2D");
   SF_HIP(hipMemcpyAsync(ctx->d_index, index, (nseg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s), "H2D index");
   if (subindex)
     SF_HIP(hipMemcpyAsync(ctx->d_sub, subindex, nseg * SFH_SUBINDEX_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, s), "H2D sub-index");
-  int rc = sfh_decompress_device(ctx, ctx->d_in, src_n, ctx->d_index, subindex ? ctx->d_sub : nullptr, nseg, ctx->d_out,
-                                 dst_n, status, s);
+  rc = sfh_decompress_device(ctx, ctx->d_in, src_n, ctx->d_index, subindex ? ctx->d_sub : nullptr, nseg, ctx->d_out,
+                             dst_n, status, s);
   if (rc) return rc;
   if (*status == 0 && dst_n) {
     SF_HIP(hipMemcpyAsync(dst, ctx->d_out, dst_n, hipMemcpyDeviceToHost, s), "D2H");
