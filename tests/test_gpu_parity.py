@@ -342,3 +342,42 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
             idx, sub = compressor.last_index(), compressor.last_subindex()
             back, st = compressor.decompress(got, idx, data.size, subindex=sub)
             assert st == 0 and back == data.tobytes(), it
+
+
+def test_repeated_calls_do_not_leak_or_drift():
+    """200 calls of varying size on one context (growing and shrinking inputs, all entry points): device memory in
+    use by the library stays bounded by its largest call, results stay identical."""
+    import torch
+
+    from starflate_amd import Compressor
+
+    c = Compressor(0)
+    rng = np.random.default_rng(77)
+    text = synth.gen_text(8 << 20, seed=5)
+    ref = {}
+    sizes = [int(x) for x in rng.integers(0, 8 << 20, 40)] + [8 << 20, 0, 1, CHUNK]
+    torch.cuda.synchronize()
+    big = torch.from_numpy(text).cuda()
+    c.compress_tensor(big)  # the largest call sizes the workspace
+    c.compress(text)        # ... and the host staging buffers
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for it in range(200):
+        n = sizes[it % len(sizes)]
+        if it % 3 == 0:
+            got = c.compress(text[:n], container=["raw", "zlib", "gzip"][it % 9 // 3])
+            key = (n, it % 9 // 3, "h")
+        else:
+            out, nb = c.compress_tensor(big[:n].clone() if n else torch.empty(0, dtype=torch.uint8, device="cuda"))
+            got = out[:nb].cpu().numpy().tobytes()
+            key = (n, 0, "d")
+            if it % 5 == 0:
+                idx, sub = c.last_index(device="cuda"), c.last_subindex(device="cuda")
+                back, st = c.decompress_tensor(out[:nb].clone(), idx, n, subindex=sub)
+                assert st == 0 and torch.equal(back, big[:n])
+        assert ref.setdefault(key, got) == got
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), (free0, free1)  # nothing accumulates (torch's own cache aside)
+    c.close()
