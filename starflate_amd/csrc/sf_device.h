@@ -3,7 +3,7 @@
 // Pipeline (one HIP stream, four launches per call):
 //   K1 k_lz77   one 1024-thread workgroup per 32 KiB chunk: chunk + hash table +
 //               per-position (len,dist) in LDS; step-synchronous hash insertion,
-//               candidate compare, per-wave greedy/lazy parse, token + histogram out
+//               candidate compare, speculative lane-parallel greedy/lazy parse, token + histogram out
 //   K2 k_plan   one wave per chunk: length-limited Huffman lengths (ll, d, cl),
 //               canonical codes, dynamic header bits, block type, exact byte size
 //   K3 k_scan   exclusive scan of chunk byte sizes -> output offsets, total
@@ -12,6 +12,8 @@
 // With a zlib / gzip container two more launches (sf_checksum.hip):
 //   K5 k_checksum  one workgroup per chunk: Adler-32 / CRC-32 partial of the chunk's input bytes
 //   K6 k_wrap      one workgroup: fold the partials, write wrapper header + trailer
+// The decoder (sf_inflate.hip, sf_inflate_core.h) runs the other way: k_inflate_tokens[_sub] (Huffman codes ->
+// tokens), k_inflate_bytes (tokens -> bytes), k_inflate_status.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

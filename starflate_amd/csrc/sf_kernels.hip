@@ -53,17 +53,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 }
 
 // ---------------------------------------------------------------------------
-// K1: LZ77 match finding + parse + histogram.  One 256-thread workgroup per chunk, two
-// workgroups per CU (LDS <= 80 KiB): the chunk stays in LDS, per-position results only
+// K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per chunk, two
+// workgroups per CU (LDS <= 80 KiB, 64 VGPRs): the chunk stays in LDS, per-position results only
 // for the 8 KiB quarter in flight.  The CU has ONE scalar unit for all its waves, so the
-// hot loops are straight-line vector code: few waves, 4 positions per thread.
-//   match : step-synchronous hash insertion (kStep positions between two barriers), each
-//           thread owns 4 adjacent positions; branch-free compare of kCap bytes against
-//           the far candidate (before the barriers) and the near candidate (after)
-//   take  : SWAR pass flags positions whose match the greedy/lazy rule would take
-//   walk  : one LANE per kRegion-byte region follows the chain serially (regions are
-//           independent: matches never cross them), setting chain/match bit masks and
-//           extending capped matches to full length
+// hot loops are straight-line vector code.  Per quarter:
+//   match : 8 steps of step-synchronous hash insertion (kStep positions, one per thread, between
+//           two barriers); branch-free compare of kCap bytes against the far candidate (read
+//           before the insertion) and the near candidate (after)
+//   take  : one ballot per 64-position segment flags the positions whose match the greedy /
+//           lazy rule would take
+//   walk  : 32 LANES per kRegion-byte region follow the chain speculatively from 32 sub-region
+//           starts and reconcile with their predecessors' exits (regions are independent:
+//           matches never cross them); sets chain / match bit masks, extends capped matches
+//   segpre: tokens before every 64-position segment and before every region (sub-index)
 //   emit  : position-parallel: chain positions -> compact tokens + LDS histogram
 // ---------------------------------------------------------------------------
 #ifndef SF_K1_PPT
@@ -122,8 +124,8 @@ __device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, uint32_t a0, uint
 static_assert(kStep == 1024, "entry encoding");
 __device__ __forceinline__ uint32_t entry_pos(uint32_t v) { return v - 1u - 2u * (v & 1023u); }
 
-// STAMPS: diagnostic build only (sfh debug), s_memtime at phase boundaries into `stamps`
-// [chunk][8] = cycles in {stage, match, take+walk, emit, tail}; never used for timing claims.
+// STAMPS: diagnostic build only (SFH_K1_STAMPS=1), s_memtime at phase boundaries into `stamps`
+// [chunk][8] = cycles in {stage, match, take, walk, segpre, emit, tail}; never used for timing claims.
 template <bool STAMPS>
 __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
                                                      uint32_t* __restrict__ tokens,
