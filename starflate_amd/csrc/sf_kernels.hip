@@ -563,13 +563,14 @@ struct PlanSmem {
 // Length-limited Huffman code lengths; all 64 lanes call it.  Specification (DESIGN.md,
 // "code lengths"): two-queue Huffman, clamp, Kraft repair, lengths dealt longest-first
 // to the rarest symbols.
+template <uint32_t NG>  // 64-symbol groups the alphabet spans: 5 for literal/length, 1 for distance and code-length codes
 __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uint32_t maxbits,
                               uint8_t* lens, uint32_t lane) {
   // keys (freq << 9 | symbol) stay in registers: symbol g*64+lane in key[g]
-  uint32_t key[5], rank[5];
+  uint32_t key[NG], rank[NG];
   uint32_t mloc = 0;
 #pragma unroll
-  for (uint32_t g = 0; g < 5; ++g) {
+  for (uint32_t g = 0; g < NG; ++g) {
     const uint32_t s = g * 64 + lane;
     const uint32_t f = s < n ? freq[s] : 0u;
     key[g] = f ? ((f << 9) | s) : 0xFFFFFFFFu;
@@ -583,7 +584,7 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
   if (m == 0) return;
   if (m == 1) {
 #pragma unroll
-    for (uint32_t g = 0; g < 5; ++g)
+    for (uint32_t g = 0; g < NG; ++g)
       if (key[g] != 0xFFFFFFFFu) lens[g * 64 + lane] = 1;
     __syncthreads();
     return;
@@ -591,7 +592,7 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
   // rank sort ascending by (freq, symbol): every used key is broadcast once (v_readlane)
   // and counted by the lanes holding larger keys -- no LDS round trips
 #pragma unroll
-  for (uint32_t g2 = 0; g2 < 5; ++g2) {
+  for (uint32_t g2 = 0; g2 < NG; ++g2) {
     if (g2 * 64 >= n) break;
     uint64_t used = __ballot(key[g2] != 0xFFFFFFFFu);
     while (used) {
@@ -599,11 +600,11 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
       used &= used - 1;
       const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key[g2], (int)src);
 #pragma unroll
-      for (uint32_t g = 0; g < 5; ++g) rank[g] += kk < key[g];
+      for (uint32_t g = 0; g < NG; ++g) rank[g] += kk < key[g];
     }
   }
 #pragma unroll
-  for (uint32_t g = 0; g < 5; ++g)
+  for (uint32_t g = 0; g < NG; ++g)
     if (key[g] != 0xFFFFFFFFu) S.key[rank[g]] = key[g];
   __syncthreads();
   for (uint32_t k = lane; k < m; k += 64) S.w[k] = S.key[k] >> 9;
@@ -819,9 +820,9 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   __syncthreads();
 
   stamp();  // 0 load
-  build_lengths(S, S.freq, 286, 15, S.lens, lane);
+  build_lengths<5>(S, S.freq, 286, 15, S.lens, lane);
   stamp();  // 1 lit/len lengths
-  build_lengths(S, S.freq + kHistD, 30, 15, S.lens + 288, lane);
+  build_lengths<1>(S, S.freq + kHistD, 30, 15, S.lens + 288, lane);
   stamp();  // 2 distance lengths
 
   // body costs
@@ -862,7 +863,7 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   const uint32_t nitems = nl + nd;
   __syncthreads();
   stamp();  // 3 costs + RLE
-  build_lengths(S, S.clfreq, 19, 7, S.cl_lens, lane);
+  build_lengths<1>(S, S.clfreq, 19, 7, S.cl_lens, lane);
   canonical_codes(S.cl_lens, 19, S.cl_code, lane);
   __syncthreads();
   stamp();  // 4 code-length code
