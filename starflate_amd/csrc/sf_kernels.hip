@@ -657,13 +657,22 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
     }
   }
   __syncthreads();
-  for (uint32_t k = lane; k < m; k += 64) {
-    uint32_t c = 0, l = maxbits;
-    for (; l >= 1; --l) {
-      c += S.cnt[l];
-      if (k < c) break;
+  {
+    // lengths dealt longest-first to the rarest symbols: cumulative counts once, in registers
+    uint32_t cum[16];
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t l = 15; l >= 1; --l) {
+      c += l <= maxbits ? S.cnt[l] : 0u;
+      cum[l] = c;
     }
-    lens[S.key[k] & 511u] = (uint8_t)l;
+    for (uint32_t k = lane; k < m; k += 64) {
+      uint32_t l = 0;
+#pragma unroll
+      for (uint32_t q = 1; q <= 15; ++q)
+        if (k < cum[q]) l = q;  // cum is non-increasing in q: the last q with k < cum[q] is the largest such length
+      lens[S.key[k] & 511u] = (uint8_t)l;
+    }
   }
   __syncthreads();
 }
