@@ -87,9 +87,7 @@ constexpr uint32_t L_TABLE = L_DIST + 2 * kQuarter;          // u32[1<<kHashBits
 constexpr uint32_t L_HIST = L_TABLE + (4u << kHashBits);     // u32[320]
 constexpr uint32_t L_MARKS = L_HIST + 4 * kHistStride;       // u64[128] chain positions per 64-segment
 constexpr uint32_t L_MM = L_MARKS + 8 * kQSegs;              // u64[128] chain positions that are matches
-constexpr uint32_t L_SEGPRE = L_MM + 8 * kQSegs;             // u32[128] tokens before the segment
-constexpr uint32_t L_MISC = L_SEGPRE + 4 * kQSegs;           // u32[4]
-constexpr uint32_t K1_LDS = L_MISC + 16;
+constexpr uint32_t K1_LDS = L_MM + 8 * kQSegs;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
 static_assert(L_MARKS % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0 && L_LEN8 % 16 == 0, "LDS alignment");
 
@@ -155,8 +153,6 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
   uint32_t* s_marks32 = reinterpret_cast<uint32_t*>(smem + L_MARKS);
   uint64_t* s_marks = reinterpret_cast<uint64_t*>(smem + L_MARKS);
   uint64_t* s_mm = reinterpret_cast<uint64_t*>(smem + L_MM);
-  uint32_t* s_segpre = reinterpret_cast<uint32_t*>(smem + L_SEGPRE);
-  uint32_t* s_misc = reinterpret_cast<uint32_t*>(smem + L_MISC);
 
   const uint32_t t = threadIdx.x;
   // t >> 6 is wave-uniform, but only readfirstlane tells the compiler so
@@ -450,17 +446,19 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
     }
     __syncthreads();
     stamp(3);
-    // ---- tokens before each 64-position segment (wave 0: two segments per lane) ----
-    if (wave == 0) {
+    // ---- tokens before each 64-position segment: every wave scans the 128 popcounts itself (two segments
+    //      per lane, results stay in registers) -- no single-wave phase, no barrier before the emit pass ----
+    uint32_t preE, preO, qtotal;
+    {
       const uint32_t c0 = (uint32_t)__popcll(s_marks[2 * lane]), c1 = (uint32_t)__popcll(s_marks[2 * lane + 1]);
       const uint32_t incl = wave_incl_scan(c0 + c1, lane);
-      s_segpre[2 * lane] = incl - c0 - c1;
-      s_segpre[2 * lane + 1] = incl - c1;
-      if (lane == 63) s_misc[0] = incl;
+      preE = incl - c0 - c1;
+      preO = incl - c1;
+      qtotal = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       // tokens before each 1024-byte parse region: where the decoder's region lanes start (sub-index)
-      if ((lane & (kRegion / 128 - 1)) == 0) rtok_out[chunk * kSubRegions + qb / kRegion + lane / (kRegion / 128)] = total + incl - c0 - c1;
+      if (wave == 0 && (lane & (kRegion / 128 - 1)) == 0)
+        rtok_out[chunk * kSubRegions + qb / kRegion + lane / (kRegion / 128)] = total + preE;
     }
-    __syncthreads();
     stamp(4);
 
     // ---- emit: chain positions -> tokens (compact, chunk order) + histogram ----
@@ -478,7 +476,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
           const uint32_t sg = wave * kIter + j0 + j;
           marks[j] = s_marks[sg];
           mm[j] = s_mm[sg];
-          pre[j] = s_segpre[sg];
+          pre[j] = (uint32_t)__builtin_amdgcn_readlane((int)((sg & 1) ? preO : preE), (int)(sg >> 1));
           const uint32_t rel = sg * 64 + lane;
           b0[j] = s_len8[rel];
           b1[j] = s_len8[rel + 1];
@@ -511,7 +509,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
         }
       }
     }
-    total += s_misc[0];
+    total += qtotal;
     if (qb == 0) skip = fast_skip && n > kQuarter && total >= kQuarter - kSkipSlack;
     if constexpr (STAMPS) __syncthreads();
     stamp(5);
