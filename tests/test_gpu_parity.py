@@ -334,9 +334,11 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
         data = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
         assert data.size == total
         strategy = ["auto", "auto", "dynamic", "fixed"][it % 4]
-        got = np.frombuffer(compressor.compress(data, strategy=strategy), np.uint8)
-        want = O.compress(data, _params(strategy))
-        assert np.array_equal(got, want), (it, total, strategy, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
+        lazy = [3, 0, 1, 2, 3][it % 5]
+        fast = it % 7 != 0
+        got = np.frombuffer(compressor.compress(data, strategy=strategy, lazy=lazy, stored_fast_path=fast), np.uint8)
+        want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=int(fast)))
+        assert np.array_equal(got, want), (it, total, strategy, lazy, fast, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
         if it % 10 == 0:
             _roundtrip(got, data)
             idx, sub = compressor.last_index(), compressor.last_subindex()
