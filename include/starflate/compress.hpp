@@ -83,6 +83,7 @@ class compressor {
   compressor(compressor&& o) noexcept : ctx_{std::exchange(o.ctx_, nullptr)}, init_{o.init_} {}
   ~compressor() { sfh_destroy(ctx_); }
   [[nodiscard]] auto status() const -> CompressStatus { return init_; }
+  [[nodiscard]] auto native() const -> sfh_ctx* { return ctx_; }  // for the C-ABI entry points taking several contexts
 
   /// host spans: H2D, compress, D2H
   auto compress(std::span<const std::byte> src, std::span<std::byte> dst, const compress_options& opt = {})
@@ -132,6 +133,22 @@ class compressor {
     return out;
   }
 };
+
+/// One process, several GPUs: contiguous shards of `src` on the given compressors (one per device), one stream
+/// in `dst`, bit-identical to a single compress() call.
+inline auto compress(std::span<compressor* const> gpus, std::span<const std::byte> src, std::span<std::byte> dst,
+                     const compress_options& opt = {}) -> compat::expected<std::size_t, CompressStatus> {
+  std::vector<sfh_ctx*> h;
+  for (const auto* g : gpus) {
+    if (g == nullptr || g->native() == nullptr) return compat::unexpected{g != nullptr ? g->status() : CompressStatus::InvalidArgument};
+    h.push_back(g->native());
+  }
+  const auto c = detail::to_c(opt);
+  std::size_t n = 0;
+  const int rc = sfh_compress_multi(h.data(), static_cast<int>(h.size()), src.data(), src.size(), dst.data(), dst.size(), &n, &c);
+  if (rc != SFH_OK) return compat::unexpected{detail::to_status(rc)};
+  return n;
+}
 
 /// Compresses `src` into `dst` (dst.size() >= compress_bound(src.size())); returns the stream size.
 inline auto compress(std::span<const std::byte> src, std::span<std::byte> dst, const compress_options& opt = {})

@@ -97,6 +97,15 @@ size_t sfh_compress_bound(size_t n);
 int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap, size_t* out_n,
                  const sfh_options* opt);
 
+/* One process, several GPUs: `src` is cut into nctx contiguous shards on 32 KiB boundaries,
+ * shard i is compressed by ctxs[i] (normally one ctx per device; the contexts must be distinct) from its own host
+ * thread, every shard but the last as a non-final byte-aligned stream, and the streams are concatenated in `dst`
+ * -- one valid stream, bit-identical to what a single sfh_compress call writes.  cap >= sfh_compress_bound(n).
+ * opt->final_stream applies to the last shard; a container wraps the whole (shard checksums are computed on their
+ * devices and combined).  The block index of the whole stream is not assembled (use the per-ctx ones). */
+int sfh_compress_multi(sfh_ctx* const* ctxs, int nctx, const void* src, size_t n, void* dst, size_t cap,
+                       size_t* out_n, const sfh_options* opt);
+
 /* Device buffers (d_src 16-byte aligned), enqueued on `stream` (a hipStream_t,
  * NULL = the ctx's own stream); synchronises the stream and returns the size. */
 int sfh_compress_device(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap,

@@ -20,7 +20,7 @@ SUBINDEX_WORDS = 64
 # every symbol include/starflate_hip.h declares
 EXPORTS = [
     "sfh_default_options", "sfh_device_count", "sfh_get_device_props", "sfh_create", "sfh_destroy", "sfh_last_error",
-    "sfh_compress_bound", "sfh_compress", "sfh_compress_device", "sfh_compress_device_async",
+    "sfh_compress_bound", "sfh_compress", "sfh_compress_multi", "sfh_compress_device", "sfh_compress_device_async",
     "sfh_index_entries", "sfh_copy_index", "sfh_copy_subindex", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms",
     "sfh_inflate_stage_name", "sfh_checksum_device", "sfh_crc32_combine", "sfh_adler32_combine",
     "sfh_set_profiling", "sfh_last_stage_ms", "sfh_stage_name", "sfh_debug_read",
@@ -77,6 +77,8 @@ def lib():
     L.sfh_compress_bound.restype = sz
     L.sfh_compress.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Options)]
     L.sfh_compress.restype = C.c_int
+    L.sfh_compress_multi.argtypes = [C.POINTER(vp), C.c_int, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Options)]
+    L.sfh_compress_multi.restype = C.c_int
     L.sfh_compress_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Options), vp]
     L.sfh_compress_device.restype = C.c_int
     L.sfh_compress_device_async.argtypes = [vp, vp, sz, vp, sz, vp, C.POINTER(Options), vp]

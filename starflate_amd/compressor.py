@@ -224,6 +224,23 @@ class Compressor:
         return a
 
 
+def compress_multi(compressors, data, strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw"):
+    """One process, several contexts (normally one per GPU): contiguous shards compressed concurrently, one stream
+    out -- bit-identical to a single Compressor.compress call (sfh_compress_multi)."""
+    L = _capi.lib()
+    src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    cap = L.sfh_compress_bound(src.size)
+    dst = np.empty(cap, dtype=np.uint8)
+    out_n = C.c_size_t(0)
+    opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container)
+    handles = (C.c_void_p * len(compressors))(*[c._h for c in compressors])
+    rc = L.sfh_compress_multi(handles, len(compressors), src.ctypes.data if src.size else None, src.size, dst.ctypes.data, cap,
+                              C.byref(out_n), C.byref(opt))
+    if rc:
+        raise StarflateError(rc, "; ".join(L.sfh_last_error(c._h).decode() for c in compressors))
+    return dst[: out_n.value].tobytes()
+
+
 def checksum_combine(kind, a, b, len_b):
     """Checksum of A||B from checksum(A), checksum(B), len(B); kind "zlib" (Adler-32) or "gzip" (CRC-32)."""
     L = _capi.lib()

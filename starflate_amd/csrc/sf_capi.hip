@@ -6,7 +6,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
+#include <thread>
+#include <vector>
 
 struct sfh_ctx {
   int device = 0;
@@ -407,6 +410,93 @@ int sfh_checksum_device(sfh_ctx* ctx, const void* d_src, size_t n, uint32_t kind
 uint32_t sfh_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) { return sf::crc32_combine(crc_a, crc_b, len_b); }
 uint32_t sfh_adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b) {
   return sf::adler32_combine(adler_a, adler_b, len_b);
+}
+
+int sfh_compress_multi(sfh_ctx* const* ctxs, int nctx, const void* src, size_t n, void* dst, size_t cap, size_t* out_n,
+                       const sfh_options* opt) {
+  if (!ctxs || nctx <= 0 || (!src && n) || !dst || !out_n || check_opt(opt)) return SFH_E_INVALID_ARG;
+  for (int i = 0; i < nctx; ++i) {
+    if (!ctxs[i]) return SFH_E_INVALID_ARG;
+    for (int j = 0; j < i; ++j)
+      if (ctxs[j] == ctxs[i]) return fail(ctxs[i], SFH_E_INVALID_ARG, "sfh_compress_multi: the same ctx twice", hipSuccess);
+  }
+  if (cap < sfh_compress_bound(n)) return fail(ctxs[0], SFH_E_DST_TOO_SMALL, "cap < sfh_compress_bound(n)", hipSuccess);
+  sfh_options o;
+  if (opt) o = *opt; else sfh_default_options(&o);
+  // shards: equal numbers of chunks, the tail shards may be empty (they then contribute nothing)
+  const size_t nchunks = n ? (n + sf::kChunk - 1) / sf::kChunk : 1;
+  const size_t per = (nchunks + (size_t)nctx - 1) / (size_t)nctx;
+  struct Shard {
+    size_t lo = 0, len = 0, bound_off = 0, out = 0;
+    uint32_t sum = 0;
+    int rc = SFH_OK;
+    bool used = false;
+  };
+  std::vector<Shard> sh((size_t)nctx);
+  int last = 0;
+  const size_t hdr = sf::wrapper_header_bytes(o.container);
+  size_t off = hdr;  // the wrapper header goes in front of the first slice
+  for (int i = 0; i < nctx; ++i) {
+    Shard& s = sh[(size_t)i];
+    s.lo = std::min(n, (size_t)i * per * sf::kChunk);
+    const size_t hi = std::min(n, ((size_t)i + 1) * per * sf::kChunk);
+    s.len = hi - s.lo;
+    s.used = s.len > 0 || i == 0;  // an empty input is one empty stream on the first ctx
+    if (s.used) last = i;
+    s.bound_off = off;
+    if (s.used) off += sfh_compress_bound(s.len);
+  }
+  // every shard compresses into its own slice of dst (sized by the bound), then the slices are closed up
+  std::vector<std::thread> workers;
+  for (int i = 0; i < nctx; ++i) {
+    if (!sh[(size_t)i].used) continue;
+    workers.emplace_back([&, i] {
+      Shard& s = sh[(size_t)i];
+      sfh_options so = o;
+      so.container = SFH_RAW;
+      so.final_stream = (i == last) ? o.final_stream : 0u;
+      // a stream is shorter than its bound by more than the wrapper (>= 345 bytes of slack per chunk), so the
+      // slices, laid out bound after bound behind the header, stay inside cap = sfh_compress_bound(n)
+      s.rc = sfh_compress(ctxs[i], (const uint8_t*)src + s.lo, s.len, (uint8_t*)dst + s.bound_off,
+                          sfh_compress_bound(s.len), &s.out, &so);
+      if (s.rc == SFH_OK && o.container)  // the shard is still staged on the device: checksum it there
+        s.rc = sfh_checksum_device(ctxs[i], ctxs[i]->d_in, s.len, o.container, &s.sum, nullptr);
+    });
+  }
+  for (auto& w : workers) w.join();
+  for (int i = 0; i < nctx; ++i)
+    if (sh[(size_t)i].used && sh[(size_t)i].rc != SFH_OK) return sh[(size_t)i].rc;
+  uint8_t* d = (uint8_t*)dst;
+  size_t pos = hdr;
+  uint32_t sum = 0;
+  bool first = true;
+  for (int i = 0; i < nctx; ++i) {
+    const Shard& s = sh[(size_t)i];
+    if (!s.used) continue;
+    memmove(d + pos, d + s.bound_off, s.out);  // pos <= bound_off: slices only move down
+    pos += s.out;
+    if (o.container) {
+      sum = first ? s.sum : (o.container == SFH_ZLIB ? sf::adler32_combine(sum, s.sum, s.len) : sf::crc32_combine(sum, s.sum, s.len));
+      first = false;
+    }
+  }
+  if (o.container == SFH_ZLIB) {
+    d[0] = 0x78;
+    d[1] = 0x9C;
+    for (int k = 0; k < 4; ++k) d[pos + (size_t)k] = (uint8_t)(sum >> (24 - 8 * k));
+    pos += 4;
+  } else if (o.container == SFH_GZIP) {
+    static const uint8_t h[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, 0, 0xFF};
+    memcpy(d, h, 10);
+    const uint32_t isize = (uint32_t)n;
+    for (int k = 0; k < 4; ++k) {
+      d[pos + (size_t)k] = (uint8_t)(sum >> (8 * k));
+      d[pos + 4 + (size_t)k] = (uint8_t)(isize >> (8 * k));
+    }
+    pos += 8;
+  }
+  *out_n = pos;
+  return SFH_OK;
 }
 
 void sfh_set_profiling(sfh_ctx* ctx, int on) {

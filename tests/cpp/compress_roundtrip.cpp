@@ -4,6 +4,7 @@
 #include "starflate/compress.hpp"
 #include "starflate/decompress.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <fstream>
 #include <iterator>
@@ -104,6 +105,18 @@ auto main(int argc, char** argv) -> int {
         ++fail;
       }
     } else {
+      ++fail;
+    }
+  }
+  {
+    // two contexts, one stream: the bytes of a single call
+    compressor second{0};
+    compressor* const both[] = {&gpu, &second};
+    std::vector<std::byte> one(compress_bound(html.size())), two(compress_bound(html.size()));
+    const auto n1 = gpu.compress(html, one);
+    const auto n2 = compress(std::span<compressor* const>{both}, html, two);
+    if (!n1 || !n2 || *n1 != *n2 || !std::equal(one.begin(), one.begin() + static_cast<std::ptrdiff_t>(*n1), two.begin())) {
+      std::printf("multi-context compress differs from the single call\n");
       ++fail;
     }
   }

@@ -383,3 +383,26 @@ def test_repeated_calls_do_not_leak_or_drift():
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (64 << 20), (free0, free1)  # nothing accumulates (torch's own cache aside)
     c.close()
+
+
+def test_compress_multi_is_bit_identical_to_one_call(compressor, starfleet):
+    """sfh_compress_multi (one process, N contexts, one host thread each): contiguous shards, one stream, exactly the
+    bytes of a single call -- raw and wrapped, more contexts than chunks, empty input."""
+    from starflate_amd import Compressor, compress_multi
+
+    ctxs = [Compressor(0) for _ in range(3)]
+    text = synth.gen_text(11 * CHUNK + 4321, seed=61)
+    cases = {"text": text, "html": np.frombuffer(starfleet, np.uint8), "one_chunk": text[:1000], "empty": np.zeros(0, np.uint8),
+             "mixed": synth.gen_mixed(1 << 20, seed=62, stripe=1 << 15)}
+    for name, data in cases.items():
+        for container in ("raw", "zlib", "gzip"):
+            want = compressor.compress(data, container=container)
+            for k in (1, 2, 3):
+                got = compress_multi(ctxs[:k], data, container=container)
+                assert got == want, (name, container, k)
+        want = compressor.compress(data, strategy="fixed", final_stream=False)
+        assert compress_multi(ctxs, data, strategy="fixed", final_stream=False) == want, name
+    with pytest.raises(Exception):
+        compress_multi([ctxs[0], ctxs[0]], text)  # the same context twice
+    for c in ctxs:
+        c.close()
