@@ -323,7 +323,9 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
         t[rng.integers(0, max(n, 1), max(n // 97, 1)) % max(n, 1)] ^= 1
         return t
 
-    for it in range(300):
+    import os
+
+    for it in range(int(os.environ.get("SF_FUZZ_N", "300"))):  # SF_FUZZ_N=5000 for a soak run
         total = int(rng.choice([0, 1, 2, 3, 5, 100, 1023, 1024, 1025, 8191, 8192, 8193, CHUNK - 1, CHUNK, CHUNK + 1,
                                 int(rng.integers(0, 5 * CHUNK))]))
         parts, left = [], total
