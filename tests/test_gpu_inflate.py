@@ -245,3 +245,55 @@ def test_corrupted_streams_never_succeed_wrongly(compressor, starfleet):
                 assert st_ref == 0 and w_ref == data.size and got == out_ref[: data.size].tobytes(), (it, s is not None)
                 agree += 1
     assert agree >= 0
+
+
+def test_fuzz_decoder_on_zlib_and_own_streams(compressor):
+    """Seeded fuzz of the decoder: stitched inputs (runs, periods, text, noise, counters) compressed (a) by zlib at a
+    random level / strategy with Z_FULL_FLUSH every 32 KiB and (b) by this library; both decoder paths must return
+    the input.  SF_FUZZ_N scales it (default 120)."""
+    import os
+
+    rng = np.random.default_rng(4242)
+    text = synth.gen_text(300_000, seed=91)
+
+    def piece(n):
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            return np.full(n, int(rng.integers(0, 256)), np.uint8)
+        if kind == 1:
+            p = int(rng.integers(1, 3000))
+            return np.tile(rng.integers(0, 256, p, dtype=np.uint8), n // p + 1)[:n]
+        if kind == 2:
+            o = int(rng.integers(0, text.size - n)) if n < text.size else 0
+            return text[o:o + n]
+        if kind == 3:
+            return rng.integers(0, 256, n, dtype=np.uint8)
+        if kind == 4:
+            return rng.integers(0, int(rng.integers(2, 17)), n, dtype=np.uint8)
+        return (np.arange(n, dtype=np.uint32) * int(rng.integers(1, 9))).view(np.uint8)[:n]
+
+    levels = [(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED),
+              (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (6, zlib.Z_FILTERED), (0, zlib.Z_DEFAULT_STRATEGY)]
+    for it in range(int(os.environ.get("SF_FUZZ_N", "120"))):
+        total = int(rng.choice([0, 1, 7, 1024, CHUNK - 1, CHUNK, CHUNK + 1, int(rng.integers(0, 6 * CHUNK))]))
+        parts, left = [], total
+        while left > 0:
+            n = int(min(left, rng.integers(1, 30000)))
+            parts.append(np.ascontiguousarray(piece(n)[:n]))
+            left -= n
+        data = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        level, strat = levels[it % len(levels)]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strat)
+        nch = max(1, (data.size + CHUNK - 1) // CHUNK)
+        zs = []
+        for c in range(nch):
+            b = co.compress(data[c * CHUNK:(c + 1) * CHUNK].tobytes())
+            zs.append(b + co.flush(zlib.Z_FINISH if c == nch - 1 else zlib.Z_FULL_FLUSH))
+        index = np.concatenate([[0], np.cumsum([len(p) for p in zs])]).astype(np.uint64)
+        got, st = compressor.decompress(b"".join(zs), index, data.size)
+        assert st == 0 and got == data.tobytes(), (it, total, level, strat)
+        own = compressor.compress(data, strategy=["auto", "dynamic", "fixed"][it % 3])
+        idx, sub = compressor.last_index(), compressor.last_subindex()
+        for s in (None, sub):
+            got, st = compressor.decompress(own, idx, data.size, subindex=s)
+            assert st == 0 and got == data.tobytes(), (it, total, s is not None)
