@@ -956,28 +956,39 @@ constexpr uint32_t K3_THREADS = 1024;
 __global__ __launch_bounds__(K3_THREADS) void k_scan(uint32_t nchunks, const ChunkPlan* __restrict__ plan,
                                                      uint64_t base, uint64_t* __restrict__ offsets,
                                                      uint64_t* __restrict__ total) {
-  __shared__ uint64_t s_part[K3_THREADS];
-  const uint32_t t = threadIdx.x;
+  __shared__ uint64_t s_wave[K3_THREADS / 64];
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t per = (nchunks + K3_THREADS - 1) / K3_THREADS;
   const uint32_t b = t * per, e = (b + per < nchunks) ? b + per : nchunks;
   uint64_t sum = 0;
-  for (uint32_t c = b; c < e; ++c) sum += plan[c].out_bytes;
-  s_part[t] = sum;
-  __syncthreads();
-  for (uint32_t o = 1; o < K3_THREADS; o <<= 1) {
-    const uint64_t u = t >= o ? s_part[t - o] : 0;
-    __syncthreads();
-    s_part[t] += u;
-    __syncthreads();
+#pragma unroll 8
+  for (uint32_t c = b; c < e; ++c) sum += plan[c].out_bytes;  // unrolled: eight loads in flight, not one
+  // inclusive scan of the per-thread sums: inside each wave by shuffles, across the 16 waves through LDS
+  uint64_t incl = sum;
+#pragma unroll
+  for (uint32_t o = 1; o < 64; o <<= 1) {
+    const uint64_t u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
   }
-  uint64_t run = base + s_part[t] - sum;
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint64_t before = 0, all = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < K3_THREADS / 64; ++w) {
+    const uint64_t v = s_wave[w];
+    if (w < wave) before += v;
+    all += v;
+  }
+  incl += before;
+  uint64_t run = base + incl - sum;
+#pragma unroll 8
   for (uint32_t c = b; c < e; ++c) {
     offsets[c] = run;
     run += plan[c].out_bytes;
   }
-  if (t == K3_THREADS - 1) {
-    *total = base + s_part[t];
-    offsets[nchunks] = base + s_part[t];  // closes the index: chunk c occupies [offsets[c], offsets[c + 1])
+  if (t == 0) {
+    *total = base + all;
+    offsets[nchunks] = base + all;  // closes the index: chunk c occupies [offsets[c], offsets[c + 1])
   }
 }
 
