@@ -65,10 +65,18 @@ typedef struct sfh_options {
                             quarter of the match work); 1: always search the whole chunk */
   uint32_t container;    /* enum sfh_container; SFH_ZLIB / SFH_GZIP need final_stream = 1.  The checksum is
                             computed on the GPU from the same device buffer (two more launches) */
-  uint32_t reserved[3];  /* must be 0 */
+  uint32_t block_bytes;  /* bytes of input coded independently of what precedes them (a "strip"): a multiple of
+                            32768 up to 16 MiB; 0 (default) = SFH_DEFAULT_BLOCK_BYTES, less for inputs too small to
+                            fill the device with strips of that size (a function of n alone).  A strip is written
+                            as one byte-aligned DEFLATE block per 32 KiB; inside it the 32 KiB window slides across
+                            those blocks (src/decompress.cpp:178 only requires distance <= bytes written), so
+                            larger strips compress better; 32768 makes every DEFLATE block independent */
+  uint32_t reserved[2];  /* must be 0 */
 } sfh_options;
 
-/* fills *o with defaults: AUTO, final_stream=1, lazy=3 */
+#define SFH_DEFAULT_BLOCK_BYTES 262144u
+
+/* fills *o with defaults: AUTO, final_stream=1, lazy=3, block_bytes=0 */
 void sfh_default_options(sfh_options* o);
 
 int sfh_device_count(void);
@@ -90,8 +98,9 @@ int sfh_create(sfh_ctx** out, int device);
 void sfh_destroy(sfh_ctx* ctx);
 const char* sfh_last_error(const sfh_ctx* ctx);
 
-/* worst-case output bytes for n input bytes (any strategy, any container) */
-size_t sfh_compress_bound(size_t n);
+/* worst-case output bytes for n input bytes (any strategy, any container); block_bytes as in sfh_options
+ * (SURVEY.md 8(b) signature; the bound is per 32 KiB DEFLATE block, so today it does not depend on it) */
+size_t sfh_compress_bound(size_t n, uint32_t block_bytes);
 
 /* Host buffers: H2D copy, compress, D2H copy, synchronous.  *out_n = stream bytes. */
 int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap, size_t* out_n,
@@ -126,6 +135,9 @@ int sfh_compress_device_async(sfh_ctx* ctx, const void* d_src, size_t n, void* d
  * segments at once; without it DEFLATE decoding is serial (README.md:5-6).  Any stream with such an index
  * qualifies, e.g. zlib output flushed with Z_FULL_FLUSH every 32 KiB. */
 #define SFH_SEGMENT_BYTES 32768u
+
+/* strip size (sfh_options.block_bytes after defaulting) of the last sfh_compress* call on this ctx; 0 before any */
+uint32_t sfh_last_block_bytes(const sfh_ctx* ctx);
 
 /* entries of the index of the last sfh_compress* call on this ctx (segments + 1); 0 before any call */
 size_t sfh_index_entries(const sfh_ctx* ctx);
@@ -181,7 +193,10 @@ const char* sfh_stage_name(int stage);
 /* ---- stage inspection for parity tests: copies device scratch of the last call ---- */
 enum sfh_debug_what {
   SFH_DBG_NTOK = 0,   /* uint32 per chunk */
-  SFH_DBG_TOKENS = 1, /* uint32[32768] per chunk, first ntok valid */
+  SFH_DBG_TOKENS = 1, /* decoder: uint32[32768] per segment, first ntok valid */
+  SFH_DBG_ITEMS = 8,  /* compressor: uint16[32768] per chunk, first nitems valid (literal: byte; match: 0x8000 | len-3,
+                         then dist-1; 0x4000 + region index in bits 8..12 on a parse region's first item) */
+  SFH_DBG_NITEMS = 9, /* uint32 per chunk */
   SFH_DBG_HIST = 2,   /* uint32[320] per chunk: ll[0..285], d at [288..317] */
   SFH_DBG_PLAN = 3,   /* uint32[4] per chunk: btype, out_bytes, header_bits, body_bits */
   SFH_DBG_LENS = 4,   /* uint8[320] per chunk: ll lens [0..287], d lens [288..319] */

@@ -331,13 +331,14 @@ void sfo_default_params(sfo_params* p) {
   p->lazy = 3;
   p->final_stream = 1;
   p->strategy = 0;
-  p->depth = 1;
+  p->depth = 2;
   p->use_near = 1;
   p->long_hash_bytes = 0;
   p->chain_depth = 0;
   p->cap = 16;
   p->fast_skip = 1;
   p->far4_dist = 4096;
+  p->strip_bytes = 0;
 }
 
 static inline uint32_t load32(const uint8_t* p) {
@@ -367,7 +368,12 @@ static inline uint32_t hash_long(const uint8_t* q, const sfo_params* p) {
 static inline uint32_t ent_pos(uint32_t v, uint32_t W) { return ((v >> 12) - 1) * W + (4095 - (v & 4095)); }
 
 /*
- * Stage n1.  Positions are hashed in steps of p->step consecutive positions.
+ * Stage n1 over one STRIP: `strip_bytes` of input coded independently of everything before it
+ * (the unit a workgroup owns; the decoder only requires distance <= bytes already written,
+ * /root/reference/src/decompress.cpp:178, so matches may reach back across the strip's DEFLATE
+ * blocks).  A match reaches back at most SFO_WINDOW bytes and never before the strip's start.
+ *
+ * Positions are hashed in steps of p->step consecutive positions, numbered from the strip's start.
  * Every position of a step first reads its candidates, then the whole step is
  * inserted -- exactly what a workgroup does between two barriers, and
  * independent of the order in which threads run.
@@ -382,30 +388,66 @@ static inline uint32_t ent_pos(uint32_t v, uint32_t W) { return ((v >> 12) - 1) 
  * Candidates of position i: per table, the levels as read before this step's
  * insertions ("far", all < step start) and, with use_near, level 0 after the
  * insertions if it names a position < i ("near": first same-hash position of
- * this step).  Best = longest; ties -> smallest distance.
+ * this step).  Candidates farther back than SFO_WINDOW are ignored.
+ * Best = longest; ties -> smallest distance.
  * chain_depth > 0 (analysis only, not on the GPU): exact serial hash chains.
  */
-void sfo_match_chunk(const uint8_t* src, uint32_t n, const sfo_params* p, uint16_t* len16,
-                     uint16_t* dist16) {
+typedef struct {
+  const sfo_params* p;
+  uint8_t* d;        /* strip bytes + 16 bytes of zero padding */
+  uint32_t n;        /* strip length */
+  uint32_t* T;       /* [table][level][hash] */
+  uint32_t* far;     /* [step position][table][level] */
+  uint32_t* H;       /* chain_depth analysis mode: heads / links */
+  uint32_t* prev;
+  uint16_t* len16;   /* [n] best match per position (0: none) */
+  uint16_t* dist16;
+} matcher;
+
+static int matcher_init(matcher* m, const uint8_t* src, uint32_t n, const sfo_params* p) {
+  const uint32_t HS = 1u << p->hash_bits, D = p->depth ? p->depth : 1, NT = p->long_hash_bytes ? 2 : 1;
+  memset(m, 0, sizeof *m);
+  m->p = p;
+  m->n = n;
+  m->d = (uint8_t*)calloc((size_t)n + 16, 1);
+  m->len16 = (uint16_t*)calloc((size_t)n + 1, 2);
+  m->dist16 = (uint16_t*)calloc((size_t)n + 1, 2);
+  if (p->chain_depth) {
+    m->H = (uint32_t*)malloc((size_t)HS * 4);
+    m->prev = (uint32_t*)malloc((size_t)(n + 1) * 4);
+    if (m->H) for (uint32_t k = 0; k < HS; k++) m->H[k] = 0xFFFFFFFFu;
+  } else {
+    m->T = (uint32_t*)calloc((size_t)NT * D * HS, 4);
+    m->far = (uint32_t*)malloc((size_t)p->step * NT * D * 4);
+  }
+  if (!m->d || !m->len16 || !m->dist16 || (p->chain_depth ? (!m->H || !m->prev) : (!m->T || !m->far))) return -1;
+  if (n) memcpy(m->d, src, n);
+  return 0;
+}
+static void matcher_free(matcher* m) {
+  free(m->d); free(m->len16); free(m->dist16); free(m->T); free(m->far); free(m->H); free(m->prev);
+}
+
+/* steps [s0, s1) of the strip: candidates, insertion, best match per position */
+static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
+  const sfo_params* p = m->p;
+  const uint8_t* d = m->d;
+  const uint32_t n = m->n;
   const uint32_t W = p->step, HS = 1u << p->hash_bits, R = p->region_bytes, MM = p->min_match;
   const uint32_t D = p->depth ? p->depth : 1, LB = p->long_hash_bytes;
   const uint32_t NT = LB ? 2 : 1;
-  uint8_t* d = (uint8_t*)calloc((size_t)n + 16, 1);
-  memcpy(d, src, n);
-  memset(len16, 0, (size_t)n * 2);
-  memset(dist16, 0, (size_t)n * 2);
+  uint16_t *len16 = m->len16, *dist16 = m->dist16;
 
   if (p->chain_depth) {
-    uint32_t* H = (uint32_t*)malloc(HS * 4);
-    uint32_t* prev = (uint32_t*)malloc((size_t)(n + 1) * 4);
-    for (uint32_t k = 0; k < HS; k++) H[k] = NONE;
-    for (uint32_t i = 0; i + MM <= n; i++) {
+    uint32_t *H = m->H, *prev = m->prev;
+    uint32_t b = s0 * W, e = (uint64_t)s1 * W < n ? s1 * W : n;
+    for (uint32_t i = b; i < e && i + MM <= n; i++) {
       uint32_t h = hash_of(load32(d + i), p);
       uint32_t rend = (i / R + 1) * R;
       uint32_t maxlen = n - i < 258 ? n - i : 258;
       if (rend - i < maxlen) maxlen = rend - i;
       uint32_t best = 0, bc = 0, c = H[h];
-      for (uint32_t k = 0; k < p->chain_depth && c != NONE; k++, c = prev[c]) {
+      for (uint32_t k = 0; k < p->chain_depth && c != NONE && i - c <= SFO_WINDOW; k++, c = prev[c]) {
         uint32_t l = match_len(d, i, c, maxlen);
         if (l > best) { best = l; bc = c; }
       }
@@ -413,16 +455,13 @@ void sfo_match_chunk(const uint8_t* src, uint32_t n, const sfo_params* p, uint16
       prev[i] = H[h];
       H[h] = i;
     }
-    free(prev);
-    free(H);
-    free(d);
     return;
   }
 
-  /* T[table][level][hash] */
-  uint32_t* T = (uint32_t*)calloc((size_t)NT * D * HS, 4);
-  uint32_t* far = (uint32_t*)malloc((size_t)W * NT * D * 4);
-  for (uint32_t s = 0, b = 0; b < n; s++, b += W) {
+  uint32_t *T = m->T, *far = m->far;
+  for (uint32_t s = s0; s < s1; s++) {
+    uint32_t b = s * W;
+    if (b >= n) break;
     uint32_t e = b + W < n ? b + W : n;
     /* read phase */
     for (uint32_t i = b; i < e; i++)
@@ -456,50 +495,45 @@ void sfo_match_chunk(const uint8_t* src, uint32_t n, const sfo_params* p, uint16
         if (i + need > n) continue;
         uint32_t h = t ? hash_long(d + i, p) : hash_of(load32(d + i), p);
         uint32_t cand[8], nc = 0;
-        if (p->use_near) {
+        if (t ? p->x_long_near : p->use_near) {
           uint32_t c = ent_pos(T[(t * D) * HS + h], W);
           if (c < i) cand[nc++] = c;
         }
-        for (uint32_t k = 0; k < D; k++) {
+        for (uint32_t k = 0; k < (t && p->x_long_levels ? p->x_long_levels : D); k++) {
           uint32_t v = far[((i - b) * NT + t) * D + k];
           if (v) cand[nc++] = ent_pos(v, W);
         }
         for (uint32_t k = 0; k < nc; k++) {
-          uint32_t l = match_len(d, i, cand[k], cmplen), dist = i - cand[k];
+          uint32_t dist = i - cand[k];
+          if (dist > SFO_WINDOW) continue;
+          uint32_t l = match_len(d, i, cand[k], cmplen);
+          if (p->x_rank_cap && l > p->x_rank_cap) l = p->x_rank_cap;
           if (l > best || (l == best && l && dist < bdist)) { best = l; bdist = dist; }
         }
       }
+      if (p->x_rank_cap && best == p->x_rank_cap) best = match_len(d, i, i - bdist, cmplen);
       /* a 4-byte match far away costs more bits than four literals (length code + 5-bit
        * distance code + up to 13 extra bits): drop it */
       if (p->far4_dist && best == 4 && bdist > p->far4_dist) best = 0;
       if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)bdist; }
     }
   }
-  free(far);
-  free(T);
-  free(d);
 }
 
-/* Stage parse: greedy with one-step lazy deferral, independent per region. */
-void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
-                     const uint16_t* len16, const uint16_t* dist16, uint32_t* tokens,
-                     uint32_t* ntok) {
+/* Stage parse for the regions [r0, r1) of a strip: greedy with lazy deferral, independent per region.
+ * literal_only: emit every position as a literal (stored fast path).  Returns the tokens written. */
+static uint32_t parse_regions(const uint8_t* data, uint32_t n, const sfo_params* p, const uint16_t* len16,
+                              const uint16_t* dist16, uint32_t r0, uint32_t r1, int literal_only,
+                              uint32_t* tokens, uint32_t* ntok) {
   const uint32_t R = p->region_bytes, MM = p->min_match;
-  uint32_t nreg = (n + R - 1) / R;
-  /* Stored fast path: when the first SFO_SKIP_SPAN positions of a chunk parse to (almost)
-   * nothing but literals -- at least SFO_SKIP_SPAN - SFO_SKIP_SLACK tokens -- the rest of the
-   * chunk is not searched at all: every later position is emitted as a literal.  (High-entropy
-   * data then costs a quarter of the match work and ends up in a stored block.) */
-  uint32_t head_tokens = 0;
-  int skip = 0;
-  for (uint32_t r = 0; r < nreg; r++) {
+  uint32_t total = 0;
+  for (uint32_t r = r0; r < r1; r++) {
     uint32_t pos = r * R, end = pos + R < n ? pos + R : n, k = 0;
     uint32_t* out = tokens + (size_t)r * R;
-    if (p->fast_skip && pos == SFO_SKIP_SPAN && n > SFO_SKIP_SPAN && SFO_SKIP_SPAN % R == 0)
-      skip = head_tokens >= SFO_SKIP_SPAN - SFO_SKIP_SLACK;
-    if (skip) {
+    if (literal_only) {
       while (pos < end) out[k++] = data[pos++];
       ntok[r] = k;
+      total += k;
       continue;
     }
     while (pos < end) {
@@ -507,8 +541,8 @@ void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
       int take = l >= MM;
       /* lazy deferral, up to p->lazy positions ahead: a match is not taken when a position k
        * ahead (inside the region) offers one longer than l + (k-1) */
-      for (uint32_t k = 1; take && k <= p->lazy; k++)
-        if (pos + k < end && len16[pos + k] > l + (k - 1)) take = 0;
+      for (uint32_t k2 = 1; take && k2 <= p->lazy; k2++)
+        if (pos + k2 < end && len16[pos + k2] > l + (k2 - 1)) take = 0;
       if (take) {
         if (p->cap && l >= p->cap) { /* capped at match time: extend at the chain position */
           uint32_t maxlen = end - pos < 258 ? end - pos : 258;
@@ -523,8 +557,73 @@ void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
       }
     }
     ntok[r] = k;
-    if (pos <= SFO_SKIP_SPAN) head_tokens += k;
+    total += k;
   }
+  return total;
+}
+
+/*
+ * Stages n1 + parse for one strip, DEFLATE block by block (chunk_bytes each): the hash tables and the
+ * window carry over from block to block.
+ * Stored fast path: when the first SFO_SKIP_SPAN positions of a block parse to (almost) nothing but
+ * literals -- at least SFO_SKIP_SPAN - SFO_SKIP_SLACK tokens -- the rest of the block is neither
+ * searched nor inserted into the tables: every later position is emitted as a literal.  (High-entropy
+ * data then costs a quarter of the match work and ends up in a stored block.)
+ * tokens: region r's tokens at tokens[r * region_bytes + k], k < ntok[r] (regions counted from the
+ * strip's start); a block's regions are those it covers.
+ */
+int sfo_strip_tokens(const uint8_t* src, uint32_t n, const sfo_params* p, uint32_t* tokens, uint32_t* ntok) {
+  const uint32_t cb = p->chunk_bytes, R = p->region_bytes, W = p->step;
+  matcher m;
+  if (matcher_init(&m, src, n, p)) { matcher_free(&m); return -3; }
+  for (uint32_t c0 = 0; c0 < n; c0 += cb) {
+    const uint32_t cn = n - c0 < cb ? n - c0 : cb;
+    const uint32_t r0 = c0 / R, r1 = (c0 + cn + R - 1) / R;
+    const uint32_t s0 = c0 / W, s1 = (c0 + cn + W - 1) / W;
+    const int can_skip = p->fast_skip && cn > SFO_SKIP_SPAN && SFO_SKIP_SPAN % R == 0 && SFO_SKIP_SPAN % W == 0;
+    if (!can_skip) {
+      match_steps(&m, s0, s1);
+      parse_regions(m.d, n, p, m.len16, m.dist16, r0, r1, 0, tokens, ntok);
+      continue;
+    }
+    const uint32_t sh = s0 + SFO_SKIP_SPAN / W, rh = r0 + SFO_SKIP_SPAN / R;
+    match_steps(&m, s0, sh);
+    const uint32_t head = parse_regions(m.d, n, p, m.len16, m.dist16, r0, rh, 0, tokens, ntok);
+    const int skip = head >= SFO_SKIP_SPAN - SFO_SKIP_SLACK;
+    if (!skip) match_steps(&m, sh, s1);
+    parse_regions(m.d, n, p, m.len16, m.dist16, rh, r1, skip, tokens, ntok);
+  }
+  matcher_free(&m);
+  return 0;
+}
+
+/* one independent chunk (a strip of its own): stage n1 alone, then the parse alone */
+void sfo_match_chunk(const uint8_t* src, uint32_t n, const sfo_params* p, uint16_t* len16,
+                     uint16_t* dist16) {
+  matcher m;
+  memset(len16, 0, (size_t)n * 2);
+  memset(dist16, 0, (size_t)n * 2);
+  if (matcher_init(&m, src, n, p) == 0) {
+    match_steps(&m, 0, (n + p->step - 1) / p->step);
+    memcpy(len16, m.len16, (size_t)n * 2);
+    memcpy(dist16, m.dist16, (size_t)n * 2);
+  }
+  matcher_free(&m);
+}
+
+void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
+                     const uint16_t* len16, const uint16_t* dist16, uint32_t* tokens,
+                     uint32_t* ntok) {
+  const uint32_t R = p->region_bytes;
+  const uint32_t nreg = (n + R - 1) / R;
+  const int can_skip = p->fast_skip && n > SFO_SKIP_SPAN && SFO_SKIP_SPAN % R == 0;
+  if (!can_skip) {
+    parse_regions(data, n, p, len16, dist16, 0, nreg, 0, tokens, ntok);
+    return;
+  }
+  const uint32_t rh = SFO_SKIP_SPAN / R;
+  const uint32_t head = parse_regions(data, n, p, len16, dist16, 0, rh, 0, tokens, ntok);
+  parse_regions(data, n, p, len16, dist16, rh, nreg, head >= SFO_SKIP_SPAN - SFO_SKIP_SLACK, tokens, ntok);
 }
 
 static inline uint32_t len_symbol(uint32_t len) { /* 3..258 -> 257..285 */
@@ -788,6 +887,15 @@ static void emit_chunk(const uint8_t* data, uint32_t n, const uint32_t* tokens,
   }
 }
 
+/* strip_bytes = 0: the largest power-of-two multiple of chunk_bytes up to SFO_DEFAULT_STRIP chunks' worth that still
+ * gives SFO_MIN_STRIPS strips (a function of n alone; the GPU library uses the same rule for block_bytes = 0) */
+size_t sfo_resolve_strip_bytes(const sfo_params* p, size_t n) {
+  if (p->strip_bytes) return p->strip_bytes;
+  size_t b = (size_t)p->chunk_bytes * SFO_DEFAULT_STRIP_CHUNKS;
+  while (b > p->chunk_bytes && n / b < SFO_MIN_STRIPS) b >>= 1;
+  return b;
+}
+
 size_t sfo_compress_bound(size_t n, const sfo_params* p) {
   size_t cb = p->chunk_bytes;
   size_t nchunks = n ? (n + cb - 1) / cb : 1;
@@ -883,40 +991,45 @@ int sfo_compress_indexed(const uint8_t* src, size_t n, uint8_t* dst, size_t cap,
       (p->min_match != 3 && p->min_match != 4))
     return -1;
   const size_t cb = p->chunk_bytes;
+  const size_t sb = sfo_resolve_strip_bytes(p, n);
+  /* a strip is a whole number of DEFLATE blocks; blocks, regions and steps nest */
+  if (sb % cb || sb > (1u << 28) || (sb > cb && (cb % p->region_bytes || cb % p->step))) return -1;
   const size_t nchunks = n ? (n + cb - 1) / cb : 1;
-  uint16_t* len16 = (uint16_t*)malloc(cb * 2 + 2);
-  uint16_t* dist16 = (uint16_t*)malloc(cb * 2 + 2);
-  uint32_t* tokens = (uint32_t*)malloc((cb + p->region_bytes) * 4);
-  uint32_t ntok[4096];
+  uint32_t* tokens = (uint32_t*)malloc((sb + p->region_bytes) * 4);
+  uint32_t* ntok = (uint32_t*)calloc(sb / p->region_bytes + 2, 4);
   uint8_t* tmp = (uint8_t*)malloc(cb + cb / 8 + 1024);
   size_t off = 0;
   int rc = 0;
+  if (!tokens || !ntok || !tmp) { rc = -3; goto out; }
   if ((cb + p->region_bytes - 1) / p->region_bytes > 4096) { rc = -1; goto out; }
-  for (size_t c = 0; c < nchunks; c++) {
-    const uint8_t* data = src + c * cb;
-    uint32_t cn = (uint32_t)(n - c * cb < cb ? n - c * cb : cb);
-    int is_last = c + 1 == nchunks;
-    uint32_t ll[286], d[30];
-    sfo_plan plan;
-    sfo_match_chunk(data, cn, p, len16, dist16);
-    sfo_parse_chunk(data, cn, p, len16, dist16, tokens, ntok);
-    uint32_t nreg = (cn + p->region_bytes - 1) / p->region_bytes;
-    sfo_histogram(tokens, ntok, nreg, p->region_bytes, ll, d);
-    sfo_plan_chunk(ll, d, cn, is_last, p, &plan);
-    if (off + plan.out_bytes > cap) { rc = -2; goto out; }
-    memset(tmp, 0, plan.out_bytes + 8);
-    if (index) index[c] = off;
-    emit_chunk(data, cn, tokens, ntok, p, &plan, is_last, tmp,
-               subindex ? subindex + c * 2 * SFO_SUB_REGIONS : NULL);
-    memcpy(dst + off, tmp, plan.out_bytes);
-    off += plan.out_bytes;
+  for (size_t s0 = 0, c = 0; c < nchunks; s0 += sb) {
+    const uint32_t sn = (uint32_t)(n - s0 < sb ? n - s0 : sb);
+    if ((rc = sfo_strip_tokens(src + s0, sn, p, tokens, ntok)) != 0) goto out;
+    for (size_t c0 = 0; c0 < (sn ? sn : 1); c0 += cb, c++) {
+      const uint8_t* data = src + s0 + c0;
+      uint32_t cn = (uint32_t)(sn - c0 < cb ? sn - c0 : cb);
+      int is_last = c + 1 == nchunks;
+      uint32_t ll[286], d[30];
+      sfo_plan plan;
+      uint32_t r0 = (uint32_t)(c0 / p->region_bytes);
+      uint32_t nreg = (cn + p->region_bytes - 1) / p->region_bytes;
+      const uint32_t* ctok = tokens + (size_t)r0 * p->region_bytes;
+      sfo_histogram(ctok, ntok + r0, nreg, p->region_bytes, ll, d);
+      sfo_plan_chunk(ll, d, cn, is_last, p, &plan);
+      if (off + plan.out_bytes > cap) { rc = -2; goto out; }
+      memset(tmp, 0, plan.out_bytes + 8);
+      if (index) index[c] = off;
+      emit_chunk(data, cn, ctok, ntok + r0, p, &plan, is_last, tmp,
+                 subindex ? subindex + c * 2 * SFO_SUB_REGIONS : NULL);
+      memcpy(dst + off, tmp, plan.out_bytes);
+      off += plan.out_bytes;
+    }
   }
   *out_len = off;
   if (index) index[nchunks] = off;
 out:
   free(tmp);
+  free(ntok);
   free(tokens);
-  free(dist16);
-  free(len16);
   return rc;
 }

@@ -98,7 +98,19 @@ typedef struct sfo_params {
   uint32_t far4_dist;    /* >0: a match of exactly 4 bytes at a distance beyond this is not used */
   uint32_t container;    /* 0 raw RFC 1951; 1 zlib (RFC 1950: 78 9C .. Adler-32 BE); 2 gzip (RFC 1952:
                             1F 8B 08 00, MTIME 0, XFL 0, OS 255 .. CRC-32 LE, ISIZE LE); needs final_stream */
+  uint32_t strip_bytes;  /* 0 = sfo_resolve_strip_bytes(n).  Multiple of chunk_bytes: the unit coded independently of what
+                            precedes it.  Inside a strip the hash tables and a SFO_WINDOW-byte window slide
+                            across the DEFLATE blocks (one per chunk_bytes), so matches reach into earlier
+                            blocks of the same strip (legal: /root/reference/src/decompress.cpp:178) */
+  /* analysis knobs (tools/exp): levels of the long table that are tried (0 = depth), its near
+   * candidate, and a cap on the length that ranks candidates (the winner is then compared to `cap`) */
+  uint32_t x_long_levels, x_long_near, x_rank_cap;
 } sfo_params;
+
+#define SFO_WINDOW 32768u
+#define SFO_DEFAULT_STRIP_CHUNKS 8u /* 256 KiB strips of 32 KiB chunks */
+#define SFO_MIN_STRIPS 256u
+size_t sfo_resolve_strip_bytes(const sfo_params* p, size_t n);
 
 #define SFO_SKIP_SPAN 8192u
 #define SFO_SKIP_SLACK 128u
@@ -131,7 +143,11 @@ int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t*
 int sfo_compress_indexed(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,
                          const sfo_params* p, uint64_t* index, uint32_t* subindex);
 
-/* stage n1: per-position best match for one chunk; len16[i] in {0, min_match..258} */
+/* stages n1 + parse for one strip of n <= strip_bytes bytes: tokens of region r (regions of
+ * region_bytes counted from the strip's start) at tokens[r * region_bytes + k], k < ntok[r] */
+int sfo_strip_tokens(const uint8_t* strip, uint32_t n, const sfo_params* p, uint32_t* tokens, uint32_t* ntok);
+
+/* stage n1: per-position best match for one chunk that is a strip of its own; len16[i] in {0, min_match..258} */
 void sfo_match_chunk(const uint8_t* data, uint32_t n, const sfo_params* p, uint16_t* len16,
                      uint16_t* dist16);
 

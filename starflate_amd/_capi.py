@@ -15,13 +15,15 @@ STRATEGY = {"auto": 0, "stored": 1, "fixed": 2, "dynamic": 3}
 CONTAINER = {"raw": 0, "zlib": 1, "gzip": 2}
 DBG_NTOK, DBG_TOKENS, DBG_HIST, DBG_PLAN, DBG_LENS, DBG_OFFSETS, DBG_STAMPS = range(7)
 DBG_SUBINDEX = 7
+DBG_ITEMS, DBG_NITEMS = 8, 9
+DEFAULT_BLOCK_BYTES = 262144
 SUBINDEX_WORDS = 64
 
 # every symbol include/starflate_hip.h declares
 EXPORTS = [
     "sfh_default_options", "sfh_device_count", "sfh_get_device_props", "sfh_create", "sfh_destroy", "sfh_last_error",
     "sfh_compress_bound", "sfh_compress", "sfh_compress_multi", "sfh_compress_device", "sfh_compress_device_async",
-    "sfh_index_entries", "sfh_copy_index", "sfh_copy_subindex", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms",
+    "sfh_last_block_bytes", "sfh_index_entries", "sfh_copy_index", "sfh_copy_subindex", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms",
     "sfh_inflate_stage_name", "sfh_checksum_device", "sfh_crc32_combine", "sfh_adler32_combine",
     "sfh_set_profiling", "sfh_last_stage_ms", "sfh_stage_name", "sfh_debug_read",
 ]
@@ -29,7 +31,8 @@ EXPORTS = [
 
 class Options(C.Structure):
     _fields_ = [("strategy", C.c_uint32), ("final_stream", C.c_uint32), ("lazy", C.c_uint32),
-                ("no_stored_fast_path", C.c_uint32), ("container", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("no_stored_fast_path", C.c_uint32), ("container", C.c_uint32), ("block_bytes", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
 
 
 class DeviceProps(C.Structure):
@@ -73,7 +76,7 @@ def lib():
     L.sfh_destroy.restype = None
     L.sfh_last_error.argtypes = [vp]
     L.sfh_last_error.restype = C.c_char_p
-    L.sfh_compress_bound.argtypes = [sz]
+    L.sfh_compress_bound.argtypes = [sz, C.c_uint32]
     L.sfh_compress_bound.restype = sz
     L.sfh_compress.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Options)]
     L.sfh_compress.restype = C.c_int
@@ -83,6 +86,8 @@ def lib():
     L.sfh_compress_device.restype = C.c_int
     L.sfh_compress_device_async.argtypes = [vp, vp, sz, vp, sz, vp, C.POINTER(Options), vp]
     L.sfh_compress_device_async.restype = C.c_int
+    L.sfh_last_block_bytes.argtypes = [vp]
+    L.sfh_last_block_bytes.restype = C.c_uint32
     L.sfh_index_entries.argtypes = [vp]
     L.sfh_index_entries.restype = sz
     L.sfh_copy_index.argtypes = [vp, vp, sz, C.c_int, vp]
@@ -123,7 +128,7 @@ def device_props(device=0):
     return {k: (getattr(p, k).decode() if isinstance(getattr(p, k), bytes) else getattr(p, k)) for k, _ in p._fields_ if k != "reserved"}
 
 
-def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw"):
+def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw", block_bytes=0):
     o = Options()
     lib().sfh_default_options(C.byref(o))
     o.strategy = STRATEGY[strategy] if isinstance(strategy, str) else int(strategy)
@@ -131,4 +136,15 @@ def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path
     o.lazy = 3 if lazy is True else int(lazy)
     o.no_stored_fast_path = int(not stored_fast_path)
     o.container = CONTAINER[container] if isinstance(container, str) else int(container)
+    o.block_bytes = int(block_bytes)
     return o
+
+
+def resolve_block_bytes(block_bytes, n):
+    """What sfh_options.block_bytes = 0 stands for on an input of n bytes (mirrors sf_capi.hip)."""
+    if block_bytes:
+        return int(block_bytes)
+    b = DEFAULT_BLOCK_BYTES
+    while b > SEGMENT_BYTES and n // b < 256:
+        b >>= 1
+    return b

@@ -50,22 +50,23 @@ class Compressor:
 
     @staticmethod
     def compress_bound(n):
-        return _capi.lib().sfh_compress_bound(int(n))
+        return _capi.lib().sfh_compress_bound(int(n), 0)
 
     # ---- host buffers (PCIe inclusive) ----
-    def compress(self, data, strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw"):
+    def compress(self, data, strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw",
+                 block_bytes=0):
         src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         cap = self.compress_bound(src.size)
         dst = np.empty(cap, dtype=np.uint8)
         out_n = C.c_size_t(0)
-        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container)
+        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container, block_bytes)
         self._check(self._lib.sfh_compress(self._h, src.ctypes.data if src.size else None, src.size,
                                            dst.ctypes.data, cap, C.byref(out_n), C.byref(opt)))
         return dst[: out_n.value].tobytes()
 
     # ---- device buffers (torch uint8 CUDA tensors) ----
     def compress_tensor(self, src, out=None, strategy="auto", final_stream=True, lazy=True, stream=None,
-                        stored_fast_path=True, container="raw"):
+                        stored_fast_path=True, container="raw", block_bytes=0):
         """src: 1-D uint8 tensor on this device. Returns (out tensor, stream byte count)."""
         import torch
 
@@ -76,14 +77,14 @@ class Compressor:
             out = torch.empty(cap, dtype=torch.uint8, device=src.device)
         self._check_tensor(out)
         out_n = C.c_size_t(0)
-        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container)
+        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container, block_bytes)
         s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
         self._check(self._lib.sfh_compress_device(self._h, src.data_ptr() if n else None, n, out.data_ptr(),
                                                   out.numel(), C.byref(out_n), C.byref(opt), C.c_void_p(s)))
         return out, out_n.value
 
     def compress_tensor_async(self, src, out, size_out, strategy="auto", final_stream=True, lazy=True, stream=None,
-                              container="raw"):
+                              container="raw", block_bytes=0):
         """Enqueue only. size_out: 1-element int64 CUDA tensor receiving the stream size."""
         import torch
 
@@ -91,7 +92,7 @@ class Compressor:
         self._check_tensor(out)
         if size_out.dtype not in (torch.int64, torch.uint64) or not size_out.is_cuda:
             raise ValueError("size_out must be a 1-element int64 CUDA tensor")
-        opt = _capi.make_options(strategy, final_stream, lazy, container=container)
+        opt = _capi.make_options(strategy, final_stream, lazy, container=container, block_bytes=block_bytes)
         s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
         n = src.numel()
         self._check(self._lib.sfh_compress_device_async(self._h, src.data_ptr() if n else None, n, out.data_ptr(),
@@ -99,6 +100,10 @@ class Compressor:
 
     # ---- block index + GPU decompress (the reference's decompress(), /root/reference/src/decompress.hpp:63-71,
     #      for streams whose independently decodable 32 KiB segments are known) ----
+    def last_block_bytes(self):
+        """Strip size the last compress call used (block_bytes after defaulting)."""
+        return int(self._lib.sfh_last_block_bytes(self._h))
+
     def last_index(self, device=None):
         """Index of the last compress call: segments + 1 stream offsets.  numpy uint64 array, or (device given)
         an int64 tensor on that CUDA device."""
@@ -217,22 +222,48 @@ class Compressor:
             _capi.DBG_OFFSETS: ((nchunks,), np.uint64),
             _capi.DBG_STAMPS: ((2, nchunks, 8), np.uint64),  # [0] k_lz77 phases, [1] k_plan phases
             _capi.DBG_SUBINDEX: ((nchunks, 32, 2), np.uint32),
+            _capi.DBG_ITEMS: ((nchunks, CHUNK_BYTES), np.uint16),
+            _capi.DBG_NITEMS: ((nchunks,), np.uint32),
         }
         shape, dt = shapes[what]
         a = np.empty(shape, dtype=dt)
         self._check(self._lib.sfh_debug_read(self._h, what, a.ctypes.data, a.nbytes))
         return a
 
+    def debug_tokens(self, nchunks):
+        """The compressor's 16-bit items of the last call as per-chunk uint32 token arrays in the oracle's format
+        (bit 31 match, 16..23 len-3, 0..14 dist-1; literal = byte) -> (list of token arrays, list of (token
+        index, region) pairs naming the flagged first tokens of parse regions)."""
+        items = self.debug(_capi.DBG_ITEMS, nchunks)
+        nit = self.debug(_capi.DBG_NITEMS, nchunks)
+        toks, flags = [], []
+        for c in range(nchunks):
+            it = items[c, : nit[c]].astype(np.uint32)
+            head = (it & 0x8000) != 0
+            cont = np.zeros(it.size, dtype=bool)
+            cont[1:] = head[:-1]
+            head &= ~cont
+            start = ~cont
+            nxt = np.zeros(it.size, dtype=np.uint32)
+            nxt[:-1] = it[1:]
+            tok = np.where(head, np.uint32(0x80000000) | ((it & 0xFF) << 16) | (nxt & 0x7FFF), it & 0xFF)[start]
+            fl = ((it & 0x4000) != 0)[start]
+            reg = ((it >> 8) & 31)[start]
+            toks.append(tok.astype(np.uint32))
+            flags.append([(int(k), int(reg[k])) for k in np.flatnonzero(fl)])
+        return toks, flags
 
-def compress_multi(compressors, data, strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw"):
+
+def compress_multi(compressors, data, strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw",
+                   block_bytes=0):
     """One process, several contexts (normally one per GPU): contiguous shards compressed concurrently, one stream
     out -- bit-identical to a single Compressor.compress call (sfh_compress_multi)."""
     L = _capi.lib()
     src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
-    cap = L.sfh_compress_bound(src.size)
+    cap = L.sfh_compress_bound(src.size, 0)
     dst = np.empty(cap, dtype=np.uint8)
     out_n = C.c_size_t(0)
-    opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container)
+    opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container, block_bytes)
     handles = (C.c_void_p * len(compressors))(*[c._h for c in compressors])
     rc = L.sfh_compress_multi(handles, len(compressors), src.ctypes.data if src.size else None, src.size, dst.ctypes.data, cap,
                               C.byref(out_n), C.byref(opt))

@@ -16,8 +16,10 @@ struct sfh_ctx {
   hipStream_t stream = nullptr;  // used when the caller passes no stream
   sf::Workspace ws{};
   uint32_t cap_chunks = 0;       // chunks the workspace can hold
+  uint32_t cap_dtok = 0;         // segments the decoder's token buffer can hold
   size_t sums_cap = 0;           // bytes of ws.sums
   uint32_t last_chunks = 0;
+  uint32_t last_block_bytes = 0; // strip size the last compress call used
   bool index_valid = false;      // ws.offsets holds the index of the last compress call
   uint64_t* d_total = nullptr;   // own result slot for the synchronous entry points
   uint32_t* d_value = nullptr;   // result slot of sfh_checksum_device; [2] for the decoder's status
@@ -64,6 +66,8 @@ int grow(sfh_ctx* ctx, T** p, size_t* cap_bytes, size_t bytes, const char* what)
 }
 
 void free_ws(sfh_ctx* c) {
+  (void)hipFree(c->ws.items);
+  (void)hipFree(c->ws.nitems);
   (void)hipFree(c->ws.tokens);
   (void)hipFree(c->ws.ntok);
   (void)hipFree(c->ws.hist);
@@ -78,6 +82,7 @@ void free_ws(sfh_ctx* c) {
   c->ws = sf::Workspace{};
   c->ws.sums = keep;
   c->cap_chunks = 0;
+  c->cap_dtok = 0;
 }
 
 // checksum partials: 4 bytes per chunk, needed without the rest of the workspace by sfh_checksum_device
@@ -90,7 +95,8 @@ int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
   free_ws(ctx);
   const size_t nc = nchunks;
   hipError_t e;
-  if ((e = hipMalloc(&ctx->ws.tokens, nc * sf::kChunk * sizeof(uint32_t))) != hipSuccess ||
+  if ((e = hipMalloc(&ctx->ws.items, nc * sf::kChunk * sizeof(uint16_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.nitems, nc * sizeof(uint32_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.ntok, nc * sizeof(uint32_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.hist, nc * sf::kHistStride * sizeof(uint32_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.plan, nc * sizeof(sf::ChunkPlan))) != hipSuccess ||
@@ -110,13 +116,35 @@ int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
   return SFH_OK;
 }
 
+// the decoder's token buffer (4 bytes per output byte) is only allocated once a decode call needs it
+int ensure_dtok(sfh_ctx* ctx, uint32_t nseg) {
+  if (nseg <= ctx->cap_dtok) return SFH_OK;
+  (void)hipFree(ctx->ws.tokens);
+  ctx->ws.tokens = nullptr;
+  ctx->cap_dtok = 0;
+  const hipError_t e = hipMalloc(&ctx->ws.tokens, (size_t)nseg * sf::kChunk * sizeof(uint32_t));
+  if (e != hipSuccess) return fail(ctx, SFH_E_NOMEM, "decoder token buffer hipMalloc", e);
+  ctx->cap_dtok = nseg;
+  return SFH_OK;
+}
+
 uint32_t chunks_of(size_t n) { return n ? (uint32_t)((n + sf::kChunk - 1) / sf::kChunk) : 1u; }
+
+// block_bytes = 0: the largest power-of-two strip up to SFH_DEFAULT_BLOCK_BYTES that still leaves a
+// workgroup per CU of a 256-CU device (a function of n alone, so the stream is too)
+uint32_t resolve_block_bytes(uint32_t block_bytes, size_t n) {
+  if (block_bytes) return block_bytes;
+  uint32_t b = SFH_DEFAULT_BLOCK_BYTES;
+  while (b > sf::kChunk && n / b < 256) b >>= 1;
+  return b;
+}
 
 int check_opt(const sfh_options* o) {
   if (!o) return 0;
   if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 3 || o->no_stored_fast_path > 1) return -1;
   if (o->container > SFH_GZIP || (o->container && !o->final_stream)) return -1;  // a non-final shard has no trailer
-  for (int k = 0; k < 3; ++k)
+  if (o->block_bytes % sf::kChunk || o->block_bytes > sf::kMaxStrip) return -1;
+  for (int k = 0; k < 2; ++k)
     if (o->reserved[k]) return -1;
   return 0;
 }
@@ -125,7 +153,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
             const sfh_options* opt, hipStream_t s) {
   if (!ctx || (!d_src && n) || !d_dst || !d_out_n || check_opt(opt)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
   if (((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 3)) return fail(ctx, SFH_E_INVALID_ARG, "device pointer alignment (src 16, dst 4)", hipSuccess);
-  if (cap < sfh_compress_bound(n)) return fail(ctx, SFH_E_DST_TOO_SMALL, "cap < sfh_compress_bound(n)", hipSuccess);
+  if (cap < sfh_compress_bound(n, 0)) return fail(ctx, SFH_E_DST_TOO_SMALL, "cap < sfh_compress_bound(n)", hipSuccess);
   if (n > ((size_t)1 << 44)) return fail(ctx, SFH_E_INVALID_ARG, "input too large", hipSuccess);
   sfh_options o;
   if (opt) o = *opt; else sfh_default_options(&o);
@@ -136,7 +164,9 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   if (!rc && o.container) rc = ensure_sums(ctx, nchunks);
   if (rc) return rc;
   ctx->last_chunks = nchunks;
-  const sf::Options ko{o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path ? 0u : 1u};
+  const sf::Options ko{o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path ? 0u : 1u,
+                       resolve_block_bytes(o.block_bytes, n)};
+  ctx->last_block_bytes = ko.strip_bytes;
   const bool prof = ctx->profiling != 0;
   if (prof) SF_HIP(hipEventRecord(ctx->ev[0], s), "event");
   SF_HIP(sf::launch_lz77((const uint8_t*)d_src, n, nchunks, ctx->ws, ko, s), "launch k_lz77");
@@ -248,8 +278,9 @@ void sfh_destroy(sfh_ctx* ctx) {
 
 const char* sfh_last_error(const sfh_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
 
-size_t sfh_compress_bound(size_t n) {
-  // per chunk: fixed-Huffman worst case (9 bits per literal) + headers + alignment block
+size_t sfh_compress_bound(size_t n, uint32_t /*block_bytes*/) {
+  // per 32 KiB DEFLATE block: fixed-Huffman worst case (9 bits per literal) + headers + alignment block;
+  // the strip size does not enter (a strip is a whole number of such blocks)
   const size_t nchunks = n ? (n + sf::kChunk - 1) / sf::kChunk : 1;
   return nchunks * (size_t)(sf::kChunk + sf::kChunk / 8 + 640);
 }
@@ -276,7 +307,7 @@ int sfh_compress_device(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, 
 int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap, size_t* out_n,
                  const sfh_options* opt) {
   if (!ctx || (!src && n) || !dst || !out_n) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
-  const size_t bound = sfh_compress_bound(n);
+  const size_t bound = sfh_compress_bound(n, 0);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   int rc = grow(ctx, &ctx->d_in, &ctx->d_in_cap, n ? n : 16, "input staging");
   if (!rc) rc = grow(ctx, &ctx->d_out, &ctx->d_out_cap, bound, "output staging");
@@ -292,6 +323,8 @@ int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap,
   *out_n = total;
   return SFH_OK;
 }
+
+uint32_t sfh_last_block_bytes(const sfh_ctx* ctx) { return (ctx && ctx->index_valid) ? ctx->last_block_bytes : 0u; }
 
 size_t sfh_index_entries(const sfh_ctx* ctx) { return (ctx && ctx->index_valid) ? (size_t)ctx->last_chunks + 1 : 0; }
 
@@ -329,6 +362,7 @@ int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const u
   (void)hipGetLastError();  // see enqueue()
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int rc = ensure_ws(ctx, (uint32_t)nseg);
+  if (!rc) rc = ensure_dtok(ctx, (uint32_t)nseg);
   if (rc) return rc;
   ctx->index_valid = false;  // the decoder reuses the scratch: what sfh_debug_read returns now belongs to this call
   ctx->last_chunks = (uint32_t)nseg;
@@ -420,12 +454,16 @@ int sfh_compress_multi(sfh_ctx* const* ctxs, int nctx, const void* src, size_t n
     for (int j = 0; j < i; ++j)
       if (ctxs[j] == ctxs[i]) return fail(ctxs[i], SFH_E_INVALID_ARG, "sfh_compress_multi: the same ctx twice", hipSuccess);
   }
-  if (cap < sfh_compress_bound(n)) return fail(ctxs[0], SFH_E_DST_TOO_SMALL, "cap < sfh_compress_bound(n)", hipSuccess);
+  if (cap < sfh_compress_bound(n, 0)) return fail(ctxs[0], SFH_E_DST_TOO_SMALL, "cap < sfh_compress_bound(n)", hipSuccess);
   sfh_options o;
   if (opt) o = *opt; else sfh_default_options(&o);
-  // shards: equal numbers of chunks, the tail shards may be empty (they then contribute nothing)
-  const size_t nchunks = n ? (n + sf::kChunk - 1) / sf::kChunk : 1;
-  const size_t per = (nchunks + (size_t)nctx - 1) / (size_t)nctx;
+  // the strip size is fixed once, from the whole input: every shard is a whole number of strips, so the
+  // shards' streams are exactly the pieces of the single-call stream
+  o.block_bytes = resolve_block_bytes(o.block_bytes, n);
+  // shards: equal numbers of strips, the tail shards may be empty (they then contribute nothing)
+  const size_t cps = o.block_bytes / sf::kChunk;  // chunks per strip
+  const size_t nstrips = n ? (n + o.block_bytes - 1) / o.block_bytes : 1;
+  const size_t per = ((nstrips + (size_t)nctx - 1) / (size_t)nctx) * cps;
   struct Shard {
     size_t lo = 0, len = 0, bound_off = 0, out = 0;
     uint32_t sum = 0;
@@ -444,7 +482,7 @@ int sfh_compress_multi(sfh_ctx* const* ctxs, int nctx, const void* src, size_t n
     s.used = s.len > 0 || i == 0;  // an empty input is one empty stream on the first ctx
     if (s.used) last = i;
     s.bound_off = off;
-    if (s.used) off += sfh_compress_bound(s.len);
+    if (s.used) off += sfh_compress_bound(s.len, 0);
   }
   // every shard compresses into its own slice of dst (sized by the bound), then the slices are closed up
   std::vector<std::thread> workers;
@@ -458,7 +496,7 @@ int sfh_compress_multi(sfh_ctx* const* ctxs, int nctx, const void* src, size_t n
       // a stream is shorter than its bound by more than the wrapper (>= 345 bytes of slack per chunk), so the
       // slices, laid out bound after bound behind the header, stay inside cap = sfh_compress_bound(n)
       s.rc = sfh_compress(ctxs[i], (const uint8_t*)src + s.lo, s.len, (uint8_t*)dst + s.bound_off,
-                          sfh_compress_bound(s.len), &s.out, &so);
+                          sfh_compress_bound(s.len, 0), &s.out, &so);
       if (s.rc == SFH_OK && o.container)  // the shard is still staged on the device: checksum it there
         s.rc = sfh_checksum_device(ctxs[i], ctxs[i]->d_in, s.len, o.container, &s.sum, nullptr);
     });
@@ -521,7 +559,9 @@ int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes) {
   size_t avail = 0;
   switch (what) {
     case SFH_DBG_NTOK: p = ctx->ws.ntok; avail = nc * 4; break;
-    case SFH_DBG_TOKENS: p = ctx->ws.tokens; avail = nc * sf::kChunk * 4; break;
+    case SFH_DBG_TOKENS: p = ctx->ws.tokens; avail = ctx->cap_dtok >= nc ? nc * sf::kChunk * 4 : 0; break;
+    case SFH_DBG_ITEMS: p = ctx->ws.items; avail = nc * sf::kChunk * 2; break;
+    case SFH_DBG_NITEMS: p = ctx->ws.nitems; avail = nc * 4; break;
     case SFH_DBG_HIST: p = ctx->ws.hist; avail = nc * sf::kHistStride * 4; break;
     case SFH_DBG_PLAN: p = ctx->ws.plan; avail = nc * sizeof(sf::ChunkPlan); break;
     case SFH_DBG_OFFSETS: p = ctx->ws.offsets; avail = nc * 8; break;

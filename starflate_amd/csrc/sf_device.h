@@ -1,9 +1,11 @@
 // sf_device.h -- device-side data layout shared by the kernels and the C-ABI host.
 //
 // Pipeline (one HIP stream, four launches per call):
-//   K1 k_lz77   one 1024-thread workgroup per 32 KiB chunk: chunk + hash table +
-//               per-position (len,dist) in LDS; step-synchronous hash insertion,
-//               candidate compare, speculative lane-parallel greedy/lazy parse, token + histogram out
+//   K1 k_lz77   one 1024-thread workgroup per STRIP (block_bytes of input, a whole number of 32 KiB
+//               chunks, coded independently of what precedes it): a 32 KiB window + the 4 KiB round in
+//               flight + the hash table + per-position (len,dist) of the round in LDS; step-synchronous
+//               hash insertion, candidate compare, speculative lane-parallel greedy/lazy parse;
+//               16-bit token items + histogram out, one DEFLATE block per chunk
 //   K2 k_plan   one wave per chunk: length-limited Huffman lengths (ll, d, cl),
 //               canonical codes, dynamic header bits, block type, exact byte size
 //   K3 k_scan   exclusive scan of chunk byte sizes -> output offsets, total
@@ -20,17 +22,24 @@
 
 namespace sf {
 
-constexpr uint32_t kChunk = 32768;      // bytes per independently coded DEFLATE block
+constexpr uint32_t kChunk = 32768;      // bytes per DEFLATE block (byte-aligned in the stream)
+constexpr uint32_t kWindow = 32768;     // a match reaches back at most this far, and never before its strip
 constexpr uint32_t kStep = 1024;        // positions per hash-insertion step (= K1 threads)
-constexpr uint32_t kHashBits = 12;
+constexpr uint32_t kHashBits = 12;      // buckets of two 16-bit history levels each
+constexpr uint32_t kMaxStrip = 1u << 24;  // largest block_bytes
 constexpr uint32_t kRegion = 1024;      // parse region: matches never cross it
 constexpr uint32_t kCap = 16;           // match-time compare width; longer matches are extended by the parse
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kFar4 = 4096;        // a match of exactly 4 bytes beyond this distance is not used
 constexpr uint32_t kSkipSlack = 128;    // stored fast path: first 8 KiB with >= 8192-128 tokens => no further search
 constexpr uint32_t kSubRegions = kChunk / kRegion;  // 32 sub-index entries per chunk
-constexpr uint32_t kTokMatch = 0x80000000u;  // token: bit31 match, 16..23 len-3, 0..14 dist-1
-constexpr uint32_t kTokRegion = 0x40000000u; // k_lz77 -> k_emit only: first token of a parse region, region index in 24..28
+constexpr uint32_t kTokMatch = 0x80000000u;  // decoder token (k_inflate_*): bit31 match, 16..23 len-3, 0..14 dist-1
+constexpr uint32_t kTokRegion = 0x40000000u; // decoder token: first token of a parse region, region index in 24..28
+// k_lz77 -> k_emit: 16-bit ITEMS, at most kChunk per chunk.  A literal is one item (the byte); a match is two:
+// head = kItemMatch | len-3, then dist-1 (bit 15 clear, so "the item before me has bit 15 set" identifies it).
+// The first item of a parse region's first token also carries kItemRegion and the region's index in bits 8..12.
+constexpr uint32_t kItemMatch = 0x8000u;
+constexpr uint32_t kItemRegion = 0x4000u;
 
 constexpr uint32_t kChecksumAdler32 = 1;  // = SFH_ZLIB
 constexpr uint32_t kChecksumCrc32 = 2;    // = SFH_GZIP
@@ -64,8 +73,10 @@ struct SegInfo {
 };
 
 struct Workspace {
-  uint32_t* tokens;   // [nchunks][kChunk]
-  uint32_t* ntok;     // [nchunks]
+  uint16_t* items;    // [nchunks][kChunk] token items (K1 -> K4)
+  uint32_t* nitems;   // [nchunks]
+  uint32_t* tokens;   // [nseg][kChunk] decoder only (k_inflate_tokens* -> k_inflate_bytes)
+  uint32_t* ntok;     // [nchunks] tokens (a match counts once)
   uint32_t* hist;     // [nchunks][kHistStride]
   ChunkPlan* plan;    // [nchunks]
   ChunkCodes* codes;  // [nchunks]
@@ -82,6 +93,7 @@ struct Options {
   uint32_t final_stream;
   uint32_t lazy;
   uint32_t fast_skip;
+  uint32_t strip_bytes;  // multiple of kChunk
 };
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,

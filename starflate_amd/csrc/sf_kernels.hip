@@ -53,50 +53,58 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 }
 
 // ---------------------------------------------------------------------------
-// K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per chunk, two
-// workgroups per CU (LDS <= 80 KiB, 64 VGPRs): the chunk stays in LDS, per-position results only
-// for the 8 KiB quarter in flight.  The CU has ONE scalar unit for all its waves, so the
-// hot loops are straight-line vector code.  Per quarter:
-//   match : 8 steps of step-synchronous hash insertion (kStep positions, one per thread, between
-//           two barriers); branch-free compare of kCap bytes against the far candidate (read
-//           before the insertion) and the near candidate (after)
+// K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per STRIP (block_bytes of
+// input), two workgroups per CU (LDS <= 80 KiB, 64 VGPRs).  The strip is processed in ROUNDS of
+// kRound positions; LDS holds the kWindow bytes before the round, the round itself and a short
+// look-ahead, shifted down by one round at every round start, so a position's LDS address is
+// kWindow + (position - round start) and a candidate's is that minus the distance.  The hash table
+// and the window persist over the strip's DEFLATE blocks (one per kChunk = 8 rounds): matches reach
+// into earlier blocks of the strip (legal: /root/reference/src/decompress.cpp:178 only requires
+// distance <= bytes written).  The CU has ONE scalar unit for all its waves, so the hot loops are
+// straight-line vector code.  Per round:
+//   stage : shift the window, store the prefetched 4 KiB, age the table's step codes if due
+//   match : 4 steps of step-synchronous hash insertion (kStep positions, one per thread, between
+//           two barriers).  A bucket is one dword = two 16-bit history levels {newest, the one
+//           before}; ONE ds_max_u32 of (code << 16 | old newest) inserts: every thread of a step
+//           carries the same low half, so the result is independent of thread order.  Branch-free
+//           compare of kCap bytes against both far levels (read before the insertion) and the near
+//           candidate (the step's first same-hash position, read after it)
 //   take  : one ballot per 64-position segment flags the positions whose match the greedy /
 //           lazy rule would take
 //   walk  : 32 LANES per kRegion-byte region follow the chain speculatively from 32 sub-region
 //           starts and reconcile with their predecessors' exits (regions are independent:
 //           matches never cross them); sets chain / match bit masks, extends capped matches
-//   segpre: tokens before every 64-position segment and before every region (sub-index)
-//   emit  : position-parallel: chain positions -> compact tokens + LDS histogram
+//   emit  : position-parallel: chain positions -> compact 16-bit items + LDS histogram
 // ---------------------------------------------------------------------------
-#ifndef SF_K1_PPT
-#define SF_K1_PPT 1
-#endif
-constexpr uint32_t kPPT = SF_K1_PPT;                         // adjacent positions per thread per step
-static_assert(kPPT == 1 || kPPT == 2 || kPPT == 4, "positions per thread");
-constexpr uint32_t K1_THREADS = kStep / kPPT;
+constexpr uint32_t K1_THREADS = kStep;
 constexpr uint32_t K1_WAVES = K1_THREADS / 64;
-constexpr uint32_t kQuarter = 8192;                          // positions per match->parse round
-constexpr uint32_t kQSegs = kQuarter / 64;                   // 128 mask words per quarter
-constexpr uint32_t kQRegions = kQuarter / kRegion;
-static_assert(kQRegions <= 64, "one walker wave per quarter");
+constexpr uint32_t kRound = 4096;                            // positions per match->parse round
+constexpr uint32_t kRSegs = kRound / 64;                     // 64 mask words per round: one per lane
+constexpr uint32_t kRRegions = kRound / kRegion;
+constexpr uint32_t kRoundsPerChunk = kChunk / kRound;
+constexpr uint32_t kLook = 32;                               // bytes staged beyond the round (compare + alignment)
+constexpr uint32_t kSkipSpan = 8192;                         // stored fast path: decided after this many positions of a chunk
+static_assert(kRSegs == 64, "segment prefixes: one segment per lane");
+static_assert(kSkipSpan % kRound == 0 && kChunk % kRound == 0, "round geometry");
+// step codes in a 16-bit table half: ((step - epoch) + 1) << 10 | (1023 - t); the epoch advances by
+// kEpochSteps whenever a round would reach kEpochMax steps past it, entries older than that vanish
+constexpr uint32_t kEpochSteps = 16, kEpochMax = 48;
+static_assert(kEpochMax - kEpochSteps >= kWindow / kStep && ((kEpochMax + 1) << 10) <= 65536, "step codes");
+static_assert(kEpochMax % (kRound / kStep) == 0 && kEpochSteps % (kRound / kStep) == 0, "ageing happens between rounds");
 // LDS carve (bytes); every offset is a multiple of 16
-constexpr uint32_t L_DATA = 0;                               // u32[8192+4]
-constexpr uint32_t L_LEN8 = L_DATA + kChunk + 16;            // u8[kQuarter+16] bit7 take, low bits len-3
-constexpr uint32_t L_DIST = L_LEN8 + kQuarter + 16;          // u16[kQuarter]
-constexpr uint32_t L_TABLE = L_DIST + 2 * kQuarter;          // u32[1<<kHashBits]
+constexpr uint32_t L_DATA = 0;                               // window | round | look-ahead
+constexpr uint32_t L_LEN8 = L_DATA + kWindow + kRound + kLook;  // u8[kRound+16] low bits len-3 (capped)
+constexpr uint32_t L_DIST = L_LEN8 + kRound + 16;            // u16[kRound]
+constexpr uint32_t L_TABLE = L_DIST + 2 * kRound;            // u32[1<<kHashBits]
 constexpr uint32_t L_HIST = L_TABLE + (4u << kHashBits);     // u32[320]
-constexpr uint32_t L_MARKS = L_HIST + 4 * kHistStride;       // u64[128] chain positions per 64-segment
-constexpr uint32_t L_MM = L_MARKS + 8 * kQSegs;              // u64[128] chain positions that are matches
-constexpr uint32_t K1_LDS = L_MM + 8 * kQSegs;
+constexpr uint32_t L_MARKS = L_HIST + 4 * kHistStride;       // u64[64] chain positions per 64-segment
+constexpr uint32_t L_MM = L_MARKS + 8 * kRSegs;              // u64[64] positions whose match would be taken
+constexpr uint32_t K1_LDS = L_MM + 8 * kRSegs;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
-static_assert(L_MARKS % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0 && L_LEN8 % 16 == 0, "LDS alignment");
+static_assert(L_MARKS % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0 && L_LEN8 % 16 == 0 && L_HIST % 16 == 0, "LDS alignment");
+static_assert((kWindow + kLook) % 16 == 0 && kRound % 16 == 0, "window shift in 16-byte units");
 
-__device__ __forceinline__ uint32_t lds_load4(const uint32_t* d32, uint32_t a) {
-  const uint32_t w = a >> 2;
-  return __builtin_amdgcn_alignbyte(d32[w + 1], d32[w], a & 3);
-}
-
-// first mismatching byte (0..16) between the 16 bytes in a0..a3 and those at data[c..]
+// first mismatching byte (0..16) between the 16 bytes in a0..a3 and those at LDS byte address c
 __device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t a2,
                                           uint32_t a3, uint32_t c) {
   const uint32_t cw = c >> 2, csh = c & 3;
@@ -116,21 +124,19 @@ __device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, uint32_t a0, uint
   return min(base + (f >> 3), 16u);
 }
 
-// Table entry = ((step+1) << 10) | (1023 - t), t = position - step*1024.  Ordered exactly like
-// the specification's ((step+1) << 12) | (4095 - t), so MAX keeps the same winner (the first
-// position of the latest step); it decodes in three operations: pos = v - 1 - 2*(v & 1023).
+// 16-bit step code -> position relative to the epoch's first step: (sc-1)*1024 + t with
+// v = sc << 10 | (1023 - t); ordered like the specification's ((step+1) << 12) | (4095 - t), so MAX
+// keeps the same winner (the first position of the latest step)
 static_assert(kStep == 1024, "entry encoding");
 __device__ __forceinline__ uint32_t entry_pos(uint32_t v) { return v - 1u - 2u * (v & 1023u); }
 
 // STAMPS: diagnostic build only (SFH_K1_STAMPS=1), s_memtime at phase boundaries into `stamps`
-// [chunk][8] = cycles in {stage, match, take, walk, segpre, emit, tail}; never used for timing claims.
+// [strip][8] = cycles in {stage, match, take, walk, segpre, emit, flush}; never used for timing claims.
 template <bool STAMPS>
-__global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const uint8_t* __restrict__ src, uint64_t n_total,
-                                                     uint32_t* __restrict__ tokens,
-                                                     uint32_t* __restrict__ ntok_out,
-                                                     uint32_t* __restrict__ hist_out,
-                                                     uint32_t* __restrict__ rtok_out, uint32_t lazy,
-                                                     uint32_t fast_skip, uint64_t* __restrict__ stamps) {
+__global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
+    const uint8_t* __restrict__ src, uint64_t n_total, uint32_t strip_bytes, uint16_t* __restrict__ items,
+    uint32_t* __restrict__ nitems_out, uint32_t* __restrict__ ntok_out, uint32_t* __restrict__ hist_out,
+    uint32_t* __restrict__ rtok_out, uint32_t lazy, uint32_t fast_skip, uint64_t* __restrict__ stamps) {
   uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t st_t = 0;
   auto stamp = [&](int slot) {
@@ -158,374 +164,389 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(const
   // t >> 6 is wave-uniform, but only readfirstlane tells the compiler so
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), lane = t & 63;
   const uint64_t lt_mask = (1ull << lane) - 1;
-  const uint32_t chunk = blockIdx.x;
-  const uint64_t base = (uint64_t)chunk * kChunk;
-  const uint32_t n = (uint32_t)((n_total - base) < (uint64_t)kChunk ? (n_total - base) : kChunk);
-  uint32_t* const tk = tokens + (uint64_t)chunk * kChunk;
+  const uint32_t strip = blockIdx.x;
+  const uint64_t sbase = (uint64_t)strip * strip_bytes;
+  const uint32_t n = (uint32_t)((n_total - sbase) < (uint64_t)strip_bytes ? (n_total - sbase) : strip_bytes);
+  const uint32_t chunk0 = strip * (strip_bytes / kChunk);
+  const uint8_t* const sp = src + sbase;
 
-  // ---- stage the chunk: coalesced 16 B per lane, zero beyond n ----
+  // four bytes of the strip at `pos` (multiple of 4), zero beyond n
+  auto load4 = [&](uint32_t pos) -> uint32_t {
+    if (pos + 4 <= n) return *reinterpret_cast<const uint32_t*>(sp + pos);
+    uint32_t w = 0;
+    for (uint32_t b = 0; pos + b < n; ++b) w |= (uint32_t)sp[pos + b] << (8 * b);
+    return w;
+  };
+
+  // ---- prologue: empty table and histogram; the strip's first kLook bytes where the first shift finds them ----
   {
-    const uint4* g = reinterpret_cast<const uint4*>(src + base);
-    uint4* s4 = reinterpret_cast<uint4*>(smem + L_DATA);
-#pragma unroll
-    for (uint32_t k = 0; k < kChunk / 16 / K1_THREADS; ++k) {
-      const uint32_t idx = t + k * K1_THREADS;
-      const uint32_t off = idx * 16;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (off + 16 <= n) {
-        v = g[idx];
-      } else if (off < n) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        for (uint32_t b = 0; off + b < n; ++b) w[b >> 2] |= (uint32_t)src[base + off + b] << (8 * (b & 3));
-        v = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-      s4[idx] = v;
-    }
-    if (t < 4) s_data[kChunk / 4 + t] = 0;
-    if (t < 4) s_len32[kQuarter / 4 + t] = 0;  // pad read by the take pass
     uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
     for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) t4[idx] = make_uint4(0, 0, 0, 0);
     for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) s_hist[idx] = (idx == 256) ? 1u : 0u;
+    if (t < kLook / 4) s_data[(kWindow + kRound) / 4 + t] = load4(4 * t);
+    if (t < 4) s_len32[kRound / 4 + t] = 0;  // pad read by the take pass
   }
+  uint32_t pre_next = load4(kLook + 4 * t);  // this thread's dword of round 0 (positions kLook + 4t ..)
   __syncthreads();
   stamp(0);
 
-  const uint32_t nsteps = (n + kStep - 1) / kStep;
-  uint32_t total = 0;  // tokens of the quarters done so far (uniform)
+  const uint32_t nrounds = (n + kRound - 1) / kRound;
+  uint32_t ebase = 0;                    // first step of the table's epoch (uniform)
+  uint32_t tot_tok = 0, tot_items = 0;   // of the chunk in flight (uniform)
+  bool skip = false;                     // stored fast path (uniform): set after kSkipSpan positions of a chunk
 
-  bool skip = false;  // stored fast path (uniform): set after the first quarter
-  for (uint32_t qb = 0; qb < n; qb += kQuarter) {
+  for (uint32_t r = 0; r < nrounds; ++r) {
+    const uint32_t rb = r * kRound;                         // strip position of the round's first byte
+    const uint32_t rc = r % kRoundsPerChunk;                // round within its chunk
+    const uint32_t chunk = chunk0 + r / kRoundsPerChunk;
+    const uint32_t cstart = rb - rc * kRound;               // strip position of the chunk's first byte
+    const uint32_t qn = (n - rb) < kRound ? (n - rb) : kRound;  // valid positions in this round
+    uint16_t* const gi = items + (uint64_t)chunk * kChunk;
+    if (rc == 0) { tot_tok = 0; tot_items = 0; skip = false; }
+    if (rc == kSkipSpan / kRound) skip = fast_skip && (n - cstart) > kSkipSpan && tot_tok >= kSkipSpan - kSkipSlack;
+
+    // ---- stage: shift the window down by one round, append the prefetched 4 KiB ----
+    {
+      uint4* s4 = reinterpret_cast<uint4*>(smem + L_DATA);
+      constexpr uint32_t kUnits = (kWindow + kLook) / 16, kOff = kRound / 16;  // 2050 units move down by 256
+      static_assert(kUnits > 2 * K1_THREADS && kUnits <= 3 * K1_THREADS, "shift: three units per thread");
+      const uint4 c0 = s4[kOff + t], c1 = s4[kOff + K1_THREADS + t];
+      uint4 c2 = make_uint4(0, 0, 0, 0);
+      if (t < kUnits - 2 * K1_THREADS) c2 = s4[kOff + 2 * K1_THREADS + t];
+      __syncthreads();  // every read of the old window (this shift, the previous round's emit) precedes the writes
+      s4[t] = c0;
+      s4[K1_THREADS + t] = c1;
+      if (t < kUnits - 2 * K1_THREADS) s4[2 * K1_THREADS + t] = c2;
+      s_data[(kWindow + kLook) / 4 + t] = pre_next;
+      pre_next = (r + 1 < nrounds) ? load4(rb + kRound + kLook + 4 * t) : 0u;
+      // age the step codes: entries older than the window drop out, the rest move down by kEpochSteps
+      if (rb / kStep - ebase >= kEpochMax) {
+        constexpr uint32_t kDrop = (kEpochSteps + 1) << 10, kSub = kEpochSteps << 10;
+        for (uint32_t idx = t; idx < (1u << kHashBits); idx += K1_THREADS) {
+          const uint32_t e = s_table[idx];
+          const uint32_t hi = e >> 16, lo = e & 0xFFFFu;
+          s_table[idx] = ((hi >= kDrop ? hi - kSub : 0u) << 16) | (lo >= kDrop ? lo - kSub : 0u);
+        }
+        ebase += kEpochSteps;
+      }
+      __syncthreads();
+    }
+    stamp(0);
+
     if (skip) {
-      // the first quarter was (almost) all literals: no search, every position is a literal
-      const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;
+      // the chunk's first kSkipSpan positions were (almost) all literals: no search, no insertion,
+      // every position is a literal
       for (uint32_t rel = t; rel < qn; rel += K1_THREADS) {
-        const uint32_t b = s_bytes[qb + rel];
-        tk[total + rel] = (rel & (kRegion - 1)) == 0 ? (b | kTokRegion | (((qb + rel) / kRegion) << 24)) : b;
+        const uint32_t b = s_bytes[kWindow + rel];
+        gi[tot_items + rel] = (uint16_t)((rel & (kRegion - 1)) == 0 ? (b | kItemRegion | ((rc * kRRegions + rel / kRegion) << 8)) : b);
         atomicAdd(&s_hist[b], 1u);
       }
-      if (t < kQRegions) rtok_out[chunk * kSubRegions + qb / kRegion + t] = total + (t * kRegion < qn ? t * kRegion : qn);
-      total += qn;
-      continue;
-    }
-    // ---- match finding over this quarter ----
-    const uint32_t s_end = (qb / kStep + kQuarter / kStep) < nsteps ? (qb / kStep + kQuarter / kStep) : nsteps;
-    for (uint32_t s = qb / kStep; s < s_end; ++s) {
-      const uint32_t p0 = s * kStep + kPPT * t;  // first of this thread's kPPT adjacent positions
-      const uint32_t dw = p0 >> 2, sh0 = p0 & 3;  // sh0 + kPPT - 1 <= 3
-      const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2], d3 = s_data[dw + 3],
-                     d4 = s_data[dw + 4];
-      uint32_t a[kPPT][4], h[kPPT], farv[kPPT], lfar[kPPT], farpos[kPPT];
-#pragma unroll
-      for (uint32_t k = 0; k < kPPT; ++k) {
-        a[k][0] = __builtin_amdgcn_alignbyte(d1, d0, sh0 + k);
-        a[k][1] = __builtin_amdgcn_alignbyte(d2, d1, sh0 + k);
-        a[k][2] = __builtin_amdgcn_alignbyte(d3, d2, sh0 + k);
-        a[k][3] = __builtin_amdgcn_alignbyte(d4, d3, sh0 + k);
-      }
-#pragma unroll
-      for (uint32_t k = 0; k < kPPT; ++k) {
-        h[k] = (a[k][0] * 2654435761u) >> (32 - kHashBits);
-        farv[k] = s_table[h[k]];
-      }
-      // the far candidate only needs the (immutable) chunk: compare it ahead of the barriers
-#pragma unroll
-      for (uint32_t k = 0; k < kPPT; ++k) {
-        const uint32_t p = p0 + k;
-        const uint32_t farp = farv[k] ? entry_pos(farv[k]) : p;
-        const uint32_t l = cmp16(s_data, a[k][0], a[k][1], a[k][2], a[k][3], farp);
-        lfar[k] = farv[k] ? l : 0u;
-        farpos[k] = farp;
-      }
-      __syncthreads();  // every far read of this step precedes every insertion of this step
-#pragma unroll
-      for (uint32_t k = 0; k < kPPT; ++k) {
-        const uint32_t p = p0 + k;
-        // positions without kMinMatch bytes left insert 0, which MAX ignores
-        const uint32_t v = (p + kMinMatch <= n) ? (((s + 1) << 10) | (1023u - (kPPT * t + k))) : 0u;
-        atomicMax(&s_table[h[k]], v);
-      }
-      __syncthreads();  // insertions complete before the near reads
-      uint32_t len4 = 0;
-      uint32_t dist[kPPT];
-#pragma unroll
-      for (uint32_t k = 0; k < kPPT; ++k) {
-        const uint32_t p = p0 + k;
-        const uint32_t nearv = s_table[h[k]];
-        const uint32_t nearp = nearv ? entry_pos(nearv) : p;
-        const uint32_t np = nearp < p ? nearp : p;
-        const uint32_t ln = cmp16(s_data, a[k][0], a[k][1], a[k][2], a[k][3], np);
-        const uint32_t rend = (p & ~(kRegion - 1)) + kRegion;
-        uint32_t maxlen = (p < n) ? (n - p < kCap ? n - p : kCap) : 0u;
-        maxlen = rend - p < maxlen ? rend - p : maxlen;
-        uint32_t best = nearp < p ? (ln < maxlen ? ln : maxlen) : 0u;
-        uint32_t bd = p - np;
-        const uint32_t lf = lfar[k] < maxlen ? lfar[k] : maxlen;
-        if (lf > best) {
-          best = lf;
-          bd = p - farpos[k];
+      if (t < kRRegions) rtok_out[chunk * kSubRegions + rc * kRRegions + t] = tot_tok + (t * kRegion < qn ? t * kRegion : qn);
+      tot_tok += qn;
+      tot_items += qn;
+    } else {
+      // ---- match finding over this round ----
+      const uint32_t nsteps = (qn + kStep - 1) / kStep;
+      const uint32_t K = kWindow + ebase * kStep - rb;  // LDS byte address of a coded position = entry_pos(code) + K (mod 2^32)
+      for (uint32_t s = 0; s < nsteps; ++s) {
+        const uint32_t rel = s * kStep + t;
+        const uint32_t p = rb + rel;                       // strip position
+        const uint32_t ad = kWindow + rel;                 // its LDS byte address
+        const uint32_t dw = ad >> 2, sh0 = ad & 3;
+        const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2], d3 = s_data[dw + 3], d4 = s_data[dw + 4];
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0),
+                       a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0), a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
+        const uint32_t h = (a0 * 2654435761u) >> (32 - kHashBits);
+        const uint32_t farv = s_table[h];
+        // the far candidates only need the (immutable) window: compare them ahead of the barriers
+        const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
+        const uint32_t c0 = entry_pos(f0) + K, c1 = entry_pos(f1) + K;
+        const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = f1 != 0 && ad - c1 <= kWindow;
+        const uint32_t q0 = ok0 ? c0 : ad, q1 = ok1 ? c1 : ad;
+        const uint32_t l0 = cmp16(s_data, a0, a1, a2, a3, q0);
+        const uint32_t l1 = cmp16(s_data, a0, a1, a2, a3, q1);
+        const uint32_t lf0 = ok0 ? l0 : 0u, lf1 = ok1 ? l1 : 0u;
+        __syncthreads();  // every far read of this step precedes every insertion of this step
+        {
+          // positions without kMinMatch bytes left insert 0, which MAX ignores
+          const uint32_t code = ((rb / kStep + s - ebase + 1) << 10) | (1023u - t);
+          const uint32_t v = (p + kMinMatch <= n) ? ((code << 16) | f0) : 0u;
+          atomicMax(&s_table[h], v);
         }
+        __syncthreads();  // insertions complete before the near reads
+        const uint32_t nv = s_table[h] >> 16;
+        const uint32_t nc = entry_pos(nv) + K;
+        const bool okn = nv != 0 && nc < ad;
+        const uint32_t qnr = okn ? nc : ad;
+        const uint32_t ln = cmp16(s_data, a0, a1, a2, a3, qnr);
+        const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
+        uint32_t maxlen = (rel < qn) ? (qn - rel < kCap ? qn - rel : kCap) : 0u;
+        maxlen = rend - rel < maxlen ? rend - rel : maxlen;
+        // longest wins; ties go to the smaller distance: near, then the newer far level
+        uint32_t best = okn ? (ln < maxlen ? ln : maxlen) : 0u;
+        uint32_t bd = ad - qnr;
+        const uint32_t m0 = lf0 < maxlen ? lf0 : maxlen, m1 = lf1 < maxlen ? lf1 : maxlen;
+        if (m0 > best) { best = m0; bd = ad - q0; }
+        if (m1 > best) { best = m1; bd = ad - q1; }
         // a 4-byte match farther than kFar4 costs more bits than four literals: drop it
         const bool ok = best >= kMinMatch && (p + kMinMatch <= n) && !(best == 4 && bd > kFar4);
-        len4 |= (ok ? best - 3 : 0u) << (8 * k);
-        dist[k] = ok ? bd : 0u;
+        s_len8[rel] = (uint8_t)(ok ? best - 3 : 0u);
+        s_dist[rel] = (uint16_t)(ok ? bd : 0u);
       }
-      const uint32_t rel = p0 - qb;  // multiple of kPPT
-      if constexpr (kPPT == 4) {
-        s_len32[rel >> 2] = len4;
-        *reinterpret_cast<uint2*>(&s_dist[rel]) = make_uint2(dist[0] | (dist[1] << 16), dist[2] | (dist[3] << 16));
-      } else if constexpr (kPPT == 2) {
-        *reinterpret_cast<uint16_t*>(&s_len8[rel]) = (uint16_t)len4;
-        *reinterpret_cast<uint32_t*>(&s_dist[rel]) = dist[0] | (dist[1] << 16);
-      } else {
-        s_len8[rel] = (uint8_t)len4;
-        s_dist[rel] = (uint16_t)dist[0];
-      }
-    }
-    __syncthreads();
-    stamp(1);
+      __syncthreads();
+      stamp(1);
 
-    // ---- take pass (position-parallel): 64-bit masks of the positions whose match the
-    // greedy/lazy rule would take.  Each wave owns kIter consecutive segments: batched loads,
-    // one ballot per segment, no barrier inside.
-    {
-      const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;  // valid positions in this quarter
-      constexpr uint32_t kIter = kQSegs / K1_WAVES;  // 64-position segments per wave
-      const uint32_t sg0 = wave * kIter;
-      uint32_t l3[kIter], n1[kIter], n2[kIter], n3[kIter];
+      // ---- take pass (position-parallel): 64-bit masks of the positions whose match the
+      // greedy/lazy rule would take.  Each wave owns kIter consecutive segments: batched loads,
+      // one ballot per segment, no barrier inside.
+      {
+        constexpr uint32_t kIter = kRSegs / K1_WAVES;  // 64-position segments per wave
+        const uint32_t sg0 = wave * kIter;
+        uint32_t l3[kIter], n1[kIter], n2[kIter], n3[kIter];
 #pragma unroll
-      for (uint32_t j = 0; j < kIter; ++j) {
-        const uint32_t rel = (sg0 + j) * 64 + lane;
-        l3[j] = s_len8[rel];
-        n1[j] = s_len8[rel + 1];
-        n2[j] = s_len8[rel + 2];
-        n3[j] = s_len8[rel + 3];
-      }
+        for (uint32_t j = 0; j < kIter; ++j) {
+          const uint32_t rel = (sg0 + j) * 64 + lane;
+          l3[j] = s_len8[rel];
+          n1[j] = s_len8[rel + 1];
+          n2[j] = s_len8[rel + 2];
+          n3[j] = s_len8[rel + 3];
+        }
 #pragma unroll
-      for (uint32_t j = 0; j < kIter; ++j) {
-        const uint32_t rel = (sg0 + j) * 64 + lane;
-        const uint32_t cur = rel < qn ? l3[j] : 0u;  // beyond n: stale results of an earlier quarter
-        // lazy deferral looks up to `lazy` positions ahead, inside the region and the input
-        const uint32_t room = kRegion - (rel & (kRegion - 1));  // positions left in the region, this one included
-        const uint32_t a1 = (lazy >= 1 && rel + 1 < qn && room > 1) ? n1[j] : 0u;
-        const uint32_t a2 = (lazy >= 2 && rel + 2 < qn && room > 2) ? n2[j] : 0u;
-        const uint32_t a3 = (lazy >= 3 && rel + 3 < qn && room > 3) ? n3[j] : 0u;
-        const bool defer = a1 > cur || a2 > cur + 1 || a3 > cur + 2;
-        const uint64_t T = __ballot(cur != 0 && !defer);
-        if (lane == 0) s_mm[sg0 + j] = T;
+        for (uint32_t j = 0; j < kIter; ++j) {
+          const uint32_t rel = (sg0 + j) * 64 + lane;
+          const uint32_t cur = rel < qn ? l3[j] : 0u;  // beyond n: stale results of an earlier round
+          // lazy deferral looks up to `lazy` positions ahead, inside the region and the input
+          const uint32_t room = kRegion - (rel & (kRegion - 1));  // positions left in the region, this one included
+          const uint32_t a1 = (lazy >= 1 && rel + 1 < qn && room > 1) ? n1[j] : 0u;
+          const uint32_t a2 = (lazy >= 2 && rel + 2 < qn && room > 2) ? n2[j] : 0u;
+          const uint32_t a3 = (lazy >= 3 && rel + 3 < qn && room > 3) ? n3[j] : 0u;
+          const bool defer = a1 > cur || a2 > cur + 1 || a3 > cur + 2;
+          const uint64_t T = __ballot(cur != 0 && !defer);
+          if (lane == 0) s_mm[sg0 + j] = T;
+        }
       }
-    }
-    __syncthreads();
-    stamp(2);
+      __syncthreads();
+      stamp(2);
 
-    // ---- walk: the chain of every 128-byte region, four lanes per region ----
-    // Lane (r, s) walks the 32-position sub-region s of region r: first speculatively from
-    // the sub-region's start (exact for s = 0), chain bits kept in a register (one dword per
-    // lane).  Then each lane re-walks from its predecessor's exit until it meets its own
-    // speculative chain (greedy chains that meet stay together) or leaves the sub-region;
-    // at most three rounds make every entry equal the predecessor's final exit, i.e. the
-    // exact serial chain.  One loop iteration is a chain step (one dependent LDS byte read)
-    // or one 8-byte step of extending a capped match (lane-local state machine).
+      // ---- walk: the chain of every 1024-byte region, 32 lanes per region ----
+      // Lane (r, s) walks the 32-position sub-region s of region r: first speculatively from
+      // the sub-region's start (exact for s = 0), chain bits kept in a register (one dword per
+      // lane).  Then each lane re-walks from its predecessor's exit until it meets its own
+      // speculative chain (greedy chains that meet stay together) or leaves the sub-region;
+      // the rounds stop when no entry changes and leave the exact serial chain.  One loop
+      // iteration is a chain step (one dependent LDS byte read) or one 8-byte step of
+      // extending a capped match (lane-local state machine).
 #ifndef SF_K1_SUB
 #define SF_K1_SUB 32
 #endif
-    constexpr uint32_t kSub = SF_K1_SUB, kSubPerRegion = kRegion / kSub, kWalkWaves = kQuarter / kSub / 64;
-    static_assert((kSub == 16 || kSub == 32) && kWalkWaves >= 1 && K1_WAVES % kWalkWaves == 0, "walker geometry");
-    const uint32_t w0 = ((qb / kQuarter) * kWalkWaves) % K1_WAVES;  // walking waves rotate over the SIMDs
-    if (wave >= w0 && wave < w0 + kWalkWaves) {
-      const uint32_t L = (wave - w0) * 64 + lane;                  // sub-region index in the quarter
-      const uint32_t qn = (n - qb) < kQuarter ? (n - qb) : kQuarter;
-      const uint32_t sb = L * kSub;
-      const uint32_t rb = sb & ~(kRegion - 1);
-      const uint32_t re = rb + kRegion < qn ? rb + kRegion : qn;   // region end (quarter-relative)
-      const uint32_t se = sb + kSub < re ? sb + kSub : re;         // sub-region end (may be <= sb)
-      const uint32_t sub = L & (kSubPerRegion - 1);
-      constexpr uint32_t kNone = 0xFFFFFFFFu;
-      // walk from `pos` while inside [sb, se); stops early on a position of `conv`
-      using mask_t = uint64_t;
-      static_assert(kSub <= 32, "the take-mask slice of a sub-region is one 32-bit register");
-      const uint32_t t32 = (uint32_t)(s_mm[sb >> 6] >> (sb & 63)) & (kSub == 32 ? 0xFFFFFFFFu : ((1u << (kSub & 31)) - 1u));
-      auto sub_walk = [&](uint32_t pos, mask_t conv, mask_t& marks, uint32_t& exitp, uint32_t& e0, uint32_t& e1,
-                          uint32_t& cpos) {
-        marks = 0; e0 = 0; e1 = 0; cpos = kNone;
-        uint32_t xl = 0, xmp = 0, xpa = 0, xca = 0, xmax = 0;      // extension state (xl = 0: none)
-        while (pos < se) {
-          if (xl == 0) {
-            const uint32_t m = t32 >> (pos - sb);      // take positions from pos to the sub-region's end
-            const bool hit = m != 0;
-            const uint32_t k = hit ? (uint32_t)__builtin_ctz(m) : 0u;
-            const uint32_t nb = hit ? k + 1 : se - pos;  // chain run: literals (+ the match position)
-            const uint64_t run = ((1ull << nb) - 1ull) << (pos - sb);
-            const uint64_t c = conv & run;
-            if (c) {                                   // met the speculative chain: from here on it is ours
-              const uint32_t q = (uint32_t)__builtin_ctzll(c);
-              marks |= run & ((1ull << q) - 1ull);
-              cpos = sb + q;
-              break;
-            }
-            marks |= run;
-            const uint32_t mp = pos + k;               // match position on a hit (inside the sub-region)
-            if (hit) {
-              const uint32_t len = (uint32_t)s_len8[mp] + 3;  // the one dependent LDS read per match
-              if (len == kCap) {                       // capped at match time: extend from here
-                xmp = mp;
-                xpa = qb + mp;
-                xca = xpa - s_dist[mp];
-                xmax = re - mp < 258u ? re - mp : 258u;
-                xl = kCap;
+      constexpr uint32_t kSub = SF_K1_SUB, kSubPerRegion = kRegion / kSub, kWalkWaves = kRound / kSub / 64;
+      static_assert((kSub == 16 || kSub == 32) && kWalkWaves >= 1 && K1_WAVES % kWalkWaves == 0, "walker geometry");
+      const uint32_t w0 = (r * kWalkWaves) % K1_WAVES;  // walking waves rotate over the SIMDs
+      if (wave >= w0 && wave < w0 + kWalkWaves) {
+        const uint32_t L = (wave - w0) * 64 + lane;                  // sub-region index in the round
+        const uint32_t sb = L * kSub;
+        const uint32_t rgb = sb & ~(kRegion - 1);
+        const uint32_t re = rgb + kRegion < qn ? rgb + kRegion : qn; // region end (round-relative)
+        const uint32_t se = sb + kSub < re ? sb + kSub : re;         // sub-region end (may be <= sb)
+        const uint32_t sub = L & (kSubPerRegion - 1);
+        constexpr uint32_t kNone = 0xFFFFFFFFu;
+        using mask_t = uint64_t;
+        static_assert(kSub <= 32, "the take-mask slice of a sub-region is one 32-bit register");
+        const uint32_t t32 = (uint32_t)(s_mm[sb >> 6] >> (sb & 63)) & (kSub == 32 ? 0xFFFFFFFFu : ((1u << (kSub & 31)) - 1u));
+        // walk from `pos` while inside [sb, se); stops early on a position of `conv`
+        auto sub_walk = [&](uint32_t pos, mask_t conv, mask_t& marks, uint32_t& exitp, uint32_t& e0, uint32_t& e1,
+                            uint32_t& cpos) {
+          marks = 0; e0 = 0; e1 = 0; cpos = kNone;
+          uint32_t xl = 0, xmp = 0, xpa = 0, xca = 0, xmax = 0;      // extension state (xl = 0: none)
+          while (pos < se) {
+            if (xl == 0) {
+              const uint32_t m = t32 >> (pos - sb);      // take positions from pos to the sub-region's end
+              const bool hit = m != 0;
+              const uint32_t k = hit ? (uint32_t)__builtin_ctz(m) : 0u;
+              const uint32_t nb = hit ? k + 1 : se - pos;  // chain run: literals (+ the match position)
+              const uint64_t run = ((1ull << nb) - 1ull) << (pos - sb);
+              const uint64_t c = conv & run;
+              if (c) {                                   // met the speculative chain: from here on it is ours
+                const uint32_t q = (uint32_t)__builtin_ctzll(c);
+                marks |= run & ((1ull << q) - 1ull);
+                cpos = sb + q;
+                break;
+              }
+              marks |= run;
+              const uint32_t mp = pos + k;               // match position on a hit (inside the sub-region)
+              if (hit) {
+                const uint32_t len = (uint32_t)s_len8[mp] + 3;  // the one dependent LDS read per match
+                if (len == kCap) {                       // capped at match time: extend from here
+                  xmp = mp;
+                  xpa = kWindow + mp;
+                  xca = xpa - s_dist[mp];
+                  xmax = re - mp < 258u ? re - mp : 258u;
+                  xl = kCap;
+                } else {
+                  pos = mp + len;
+                }
               } else {
-                pos = mp + len;
+                pos = pos + nb;                          // literals up to the run's (clipped) end
               }
             } else {
-              pos = pos + nb;                          // literals up to the run's (clipped) end
+              uint32_t l = xl;
+              bool done = l >= xmax;
+              if (!done) {
+                const uint32_t ia = xpa + l, ja = xca + l;
+                const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
+                const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
+                const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, ia & 3) ^ __builtin_amdgcn_alignbyte(j1, j0, ja & 3);
+                const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, ia & 3) ^ __builtin_amdgcn_alignbyte(j2, j1, ja & 3);
+                if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; done = true; }
+                else if (x1) { l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3); done = true; }
+                else l += 8;
+              }
+              if (done) {
+                l = l < xmax ? l : xmax;
+                const uint32_t e = 0x10000u | ((xmp - sb) << 9) | l;  // full length of a capped chain match (pos: 6 bits)
+                if (e0 == 0) e0 = e; else e1 = e;
+                pos = xmp + l;
+                xl = 0;
+              } else {
+                xl = l;
+              }
             }
-          } else {
-            uint32_t l = xl;
-            bool done = l >= xmax;
-            if (!done) {
-              const uint32_t ia = xpa + l, ja = xca + l;
-              const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
-              const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
-              const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, ia & 3) ^ __builtin_amdgcn_alignbyte(j1, j0, ja & 3);
-              const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, ia & 3) ^ __builtin_amdgcn_alignbyte(j2, j1, ja & 3);
-              if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; done = true; }
-              else if (x1) { l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3); done = true; }
-              else l += 8;
-            }
-            if (done) {
-              l = l < xmax ? l : xmax;
-              const uint32_t e = 0x10000u | ((xmp - sb) << 9) | l;  // full length of a capped chain match (pos: 6 bits)
-              if (e0 == 0) e0 = e; else e1 = e;
-              pos = xmp + l;
-              xl = 0;
+          }
+          exitp = pos;
+        };
+        mask_t mS;
+        uint32_t xS, eS0, eS1, cdummy;
+        sub_walk(sb, 0u, mS, xS, eS0, eS1, cdummy);
+        if (se <= sb) xS = sb;
+        mask_t marks = mS;
+        uint32_t exitc = xS, f0 = eS0, f1 = eS1, entry_used = sb;
+        for (uint32_t round = 0; round < kSubPerRegion - 1; ++round) {
+          const uint32_t pe = (uint32_t)__shfl_up((int)exitc, 1, 64);
+          const bool redo = sub != 0 && pe != entry_used;
+          if (!__any(redo)) break;
+          if (redo) {
+            entry_used = pe;
+            if (pe >= se) {                              // a long match of the predecessor jumps over us
+              marks = 0; exitc = pe; f0 = 0; f1 = 0;
             } else {
-              xl = l;
+              mask_t mF;
+              uint32_t xF, eF0, eF1, cpos;
+              sub_walk(pe, mS, mF, xF, eF0, eF1, cpos);
+              if (cpos != kNone) {
+                const mask_t keep = ~((1ull << (cpos - sb)) - 1ull);  // speculative chain from cpos on
+                marks = mF | (mS & keep);
+                exitc = xS;
+                // capped matches: the re-walked ones, then the speculative ones at or after cpos
+                f0 = eF0; f1 = eF1;
+                const uint32_t q = cpos - sb;
+                if (eS0 && ((eS0 >> 9) & 63u) >= q) { if (f0 == 0) f0 = eS0; else f1 = eS0; }
+                if (eS1 && ((eS1 >> 9) & 63u) >= q) { if (f0 == 0) f0 = eS1; else f1 = eS1; }
+              } else {
+                marks = mF; exitc = xF; f0 = eF0; f1 = eF1;
+              }
             }
           }
         }
-        exitp = pos;
-      };
-      mask_t mS;
-      uint32_t xS, eS0, eS1, cdummy;
-      sub_walk(sb, 0u, mS, xS, eS0, eS1, cdummy);
-      if (se <= sb) xS = sb;
-      mask_t marks = mS;
-      uint32_t exitc = xS, f0 = eS0, f1 = eS1, entry_used = sb;
-      for (uint32_t round = 0; round < kSubPerRegion - 1; ++round) {
-        const uint32_t pe = (uint32_t)__shfl_up((int)exitc, 1, 64);
-        const bool redo = sub != 0 && pe != entry_used;
-        if (!__any(redo)) break;
-        if (redo) {
-          entry_used = pe;
-          if (pe >= se) {                              // a long match of the predecessor jumps over us
-            marks = 0; exitc = pe; f0 = 0; f1 = 0;
-          } else {
-            mask_t mF;
-            uint32_t xF, eF0, eF1, cpos;
-            sub_walk(pe, mS, mF, xF, eF0, eF1, cpos);
-            if (cpos != kNone) {
-              const mask_t keep = ~((1ull << (cpos - sb)) - 1ull);  // speculative chain from cpos on
-              marks = mF | (mS & keep);
-              exitc = xS;
-              // capped matches: the re-walked ones, then the speculative ones at or after cpos
-              f0 = eF0; f1 = eF1;
-              const uint32_t q = cpos - sb;
-              if (eS0 && ((eS0 >> 9) & 63u) >= q) { if (f0 == 0) f0 = eS0; else f1 = eS0; }
-              if (eS1 && ((eS1 >> 9) & 63u) >= q) { if (f0 == 0) f0 = eS1; else f1 = eS1; }
-            } else {
-              marks = mF; exitc = xF; f0 = eF0; f1 = eF1;
-            }
-          }
-        }
+        if constexpr (kSub == 32) s_marks32[L] = (uint32_t)marks;
+        else reinterpret_cast<uint16_t*>(s_marks32)[L] = (uint16_t)marks;
+        // the position after a capped chain match is covered by it: park the full length there
+        if (f0) s_len8[sb + ((f0 >> 9) & 63u) + 1] = (uint8_t)((f0 & 511u) - 3);
+        if (f1) s_len8[sb + ((f1 >> 9) & 63u) + 1] = (uint8_t)((f1 & 511u) - 3);
       }
-      if constexpr (kSub == 64) s_marks[L] = marks;
-      else if constexpr (kSub == 32) s_marks32[L] = (uint32_t)marks;
-      else reinterpret_cast<uint16_t*>(s_marks32)[L] = (uint16_t)marks;
-      // the position after a capped chain match is covered by it: park the full length there
-      if (f0) s_len8[sb + ((f0 >> 9) & 63u) + 1] = (uint8_t)((f0 & 511u) - 3);
-      if (f1) s_len8[sb + ((f1 >> 9) & 63u) + 1] = (uint8_t)((f1 & 511u) - 3);
-    }
-    __syncthreads();
-    stamp(3);
-    // ---- tokens before each 64-position segment: every wave scans the 128 popcounts itself (two segments
-    //      per lane, results stay in registers) -- no single-wave phase, no barrier before the emit pass ----
-    uint32_t preE, preO, qtotal;
-    {
-      const uint32_t c0 = (uint32_t)__popcll(s_marks[2 * lane]), c1 = (uint32_t)__popcll(s_marks[2 * lane + 1]);
-      const uint32_t incl = wave_incl_scan(c0 + c1, lane);
-      preE = incl - c0 - c1;
-      preO = incl - c1;
-      qtotal = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      // tokens before each 1024-byte parse region: where the decoder's region lanes start (sub-index)
-      if (wave == 0 && (lane & (kRegion / 128 - 1)) == 0)
-        rtok_out[chunk * kSubRegions + qb / kRegion + lane / (kRegion / 128)] = total + preE;
-    }
-    stamp(4);
+      __syncthreads();
+      stamp(3);
+      // ---- tokens and matches before each 64-position segment: every wave scans the 64 popcounts itself (one
+      //      segment per lane, results stay in registers) -- no single-wave phase, no barrier before the emit pass.
+      //      low half: tokens, high half: matches (a match takes two items) ----
+      uint32_t pre, rtotal;
+      {
+        const uint64_t mk = s_marks[lane];
+        const uint32_t v = (uint32_t)__popcll(mk) | ((uint32_t)__popcll(mk & s_mm[lane]) << 16);
+        const uint32_t incl = wave_incl_scan(v, lane);
+        pre = incl - v;
+        rtotal = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        // tokens before each 1024-byte parse region: where the decoder's region lanes start (sub-index)
+        if (wave == 0 && (lane & (kRegion / 64 - 1)) == 0)
+          rtok_out[chunk * kSubRegions + rc * kRRegions + lane / (kRegion / 64)] = tot_tok + (pre & 0xFFFFu);
+      }
+      stamp(4);
 
-    // ---- emit: chain positions -> tokens (compact, chunk order) + histogram ----
-    // kIter consecutive segments per wave, loads batched four segments at a time
-    {
-      constexpr uint32_t kIter = kQSegs / K1_WAVES;
-      constexpr uint32_t kB = 4;
-      static_assert(kIter % kB == 0, "emit batch");
+      // ---- emit: chain positions -> items (compact, chunk order) + histogram ----
+      // kIter consecutive segments per wave, loads batched
+      {
+        constexpr uint32_t kIter = kRSegs / K1_WAVES;
 #pragma unroll
-      for (uint32_t j0 = 0; j0 < kIter; j0 += kB) {
-        uint64_t marks[kB], mm[kB];
-        uint32_t pre[kB], b0[kB], b1[kB], dd[kB], lit[kB];
+        for (uint32_t j0 = 0; j0 < kIter; j0 += kIter) {
+          uint64_t marks[kIter], mm[kIter];
+          uint32_t pr[kIter], b0[kIter], b1[kIter], dd[kIter], lit[kIter];
 #pragma unroll
-        for (uint32_t j = 0; j < kB; ++j) {
-          const uint32_t sg = wave * kIter + j0 + j;
-          marks[j] = s_marks[sg];
-          mm[j] = s_mm[sg];
-          pre[j] = (uint32_t)__builtin_amdgcn_readlane((int)((sg & 1) ? preO : preE), (int)(sg >> 1));
-          const uint32_t rel = sg * 64 + lane;
-          b0[j] = s_len8[rel];
-          b1[j] = s_len8[rel + 1];
-          dd[j] = s_dist[rel];
-          lit[j] = s_bytes[qb + rel];
-        }
+          for (uint32_t j = 0; j < kIter; ++j) {
+            const uint32_t sg = wave * kIter + j0 + j;
+            marks[j] = s_marks[sg];
+            mm[j] = s_mm[sg];
+            pr[j] = (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)sg);
+            const uint32_t rel = sg * 64 + lane;
+            b0[j] = s_len8[rel];
+            b1[j] = s_len8[rel + 1];
+            dd[j] = s_dist[rel];
+            lit[j] = s_bytes[kWindow + rel];
+          }
 #pragma unroll
-        for (uint32_t j = 0; j < kB; ++j) {
-          if ((marks[j] >> lane) & 1) {
-            const uint32_t idx = total + pre[j] + (uint32_t)__popcll(marks[j] & lt_mask);
-            uint32_t tok;
-            if ((mm[j] >> lane) & 1) {
-              uint32_t l3 = b0[j];                 // capped len-3 from the match phase
-              if (l3 == kCap - 3) l3 = b1[j];      // capped match: the walker left the full length next door
-              const uint32_t d1 = dd[j] - 1;
-              tok = kTokMatch | (l3 << 16) | d1;
-              uint32_t eb, ev;
-              atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
-              atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
-            } else {
-              tok = lit[j];
-              atomicAdd(&s_hist[tok], 1u);
+          for (uint32_t j = 0; j < kIter; ++j) {
+            if ((marks[j] >> lane) & 1) {
+              const uint64_t cm = marks[j] & mm[j];  // chain positions that are matches
+              const uint32_t idx = tot_items + (pr[j] & 0xFFFFu) + (pr[j] >> 16) +
+                                   (uint32_t)__popcll(marks[j] & lt_mask) + (uint32_t)__popcll(cm & lt_mask);
+              // first token of a parse region (its position is always a token start): only lane 0 of every 16th
+              // segment can be one -- the segment test is uniform, so 15 of 16 segments skip this entirely
+              const uint32_t sgq = wave * kIter + j0 + j;
+              uint32_t flag = 0;
+              if ((sgq & (kRegion / 64 - 1)) == 0 && lane == 0) flag = kItemRegion | ((rc * kRRegions + sgq / (kRegion / 64)) << 8);
+              if ((cm >> lane) & 1) {
+                uint32_t l3 = b0[j];                 // capped len-3 from the match phase
+                if (l3 == kCap - 3) l3 = b1[j];      // capped match: the walker left the full length next door
+                const uint32_t d1 = dd[j] - 1;
+                gi[idx] = (uint16_t)(kItemMatch | flag | l3);
+                gi[idx + 1] = (uint16_t)d1;
+                uint32_t eb, ev;
+                atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
+                atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
+              } else {
+                gi[idx] = (uint16_t)(lit[j] | flag);
+                atomicAdd(&s_hist[lit[j]], 1u);
+              }
             }
-            // first token of a parse region (its position is always a token start): only lane 0 of every 16th
-            // segment can be one -- the segment test is uniform, so 15 of 16 segments skip this entirely
-            const uint32_t sgq = wave * kIter + j0 + j;
-            if ((sgq & (kRegion / 64 - 1)) == 0 && lane == 0) tok |= kTokRegion | (((qb + sgq * 64) / kRegion) << 24);
-            tk[idx] = tok;
           }
         }
       }
+      tot_tok += rtotal & 0xFFFFu;
+      tot_items += (rtotal & 0xFFFFu) + (rtotal >> 16);
+      if constexpr (STAMPS) __syncthreads();
+      stamp(5);
     }
-    total += qtotal;
-    if (qb == 0) skip = fast_skip && n > kQuarter && total >= kQuarter - kSkipSlack;
-    if constexpr (STAMPS) __syncthreads();
-    stamp(5);
-    // the next quarter's first barrier orders these reads before its result writes
+
+    // ---- end of a chunk: its counts and histogram go out, the histogram starts over ----
+    if (rc == kRoundsPerChunk - 1 || r + 1 == nrounds) {
+      __syncthreads();  // this round's histogram updates are complete
+      for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) {
+        hist_out[(uint64_t)chunk * kHistStride + idx] = s_hist[idx];
+        s_hist[idx] = (idx == 256) ? 1u : 0u;
+      }
+      if (t == 0) { ntok_out[chunk] = tot_tok; nitems_out[chunk] = tot_items; }
+      const uint32_t covered = (rc + 1) * kRRegions;  // regions of the rounds that ran
+      if (t < kSubRegions && t >= covered) rtok_out[chunk * kSubRegions + t] = tot_tok;
+      stamp(6);
+    }
+    // the next round's first barrier orders this round's LDS reads before its writes
   }
-  __syncthreads();
-  for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) hist_out[(uint64_t)chunk * kHistStride + idx] = s_hist[idx];
-  if (t == 0) ntok_out[chunk] = total;
-  {
-    const uint32_t covered = ((n + kQuarter - 1) / kQuarter) * kQRegions;  // regions of the quarters that ran
-    if (t < kSubRegions && t >= covered) rtok_out[chunk * kSubRegions + t] = total;
+  if (nrounds == 0) {  // empty input: one empty chunk
+    for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) hist_out[(uint64_t)chunk0 * kHistStride + idx] = (idx == 256) ? 1u : 0u;
+    if (t == 0) { ntok_out[chunk0] = 0; nitems_out[chunk0] = 0; }
+    if (t < kSubRegions) rtok_out[chunk0 * kSubRegions + t] = 0;
   }
-  stamp(6);
   if constexpr (STAMPS) {
     if (t == 0)
-      for (int k = 0; k < 8; ++k) stamps[(uint64_t)chunk * 8 + k] = st_acc[k];
+      for (int k = 0; k < 8; ++k) stamps[(uint64_t)strip * 8 + k] = st_acc[k];
   }
 }
 
@@ -998,35 +1019,36 @@ __global__ __launch_bounds__(K3_THREADS) void k_scan(uint32_t nchunks, const Chu
 // ---------------------------------------------------------------------------
 constexpr uint32_t K4_THREADS = 512;
 constexpr uint32_t K4_WAVES = K4_THREADS / 64;
-constexpr uint32_t K4_TPT = 4;  // tokens per thread per batch
+constexpr uint32_t K4_IPT = 8;  // items per thread per batch (one 16-byte load)
 constexpr uint32_t K4_STAGE_WORDS = 10240;  // 40 KiB: fixed-Huffman worst case of a 32 KiB chunk + align
 
-__device__ __forceinline__ void token_bits(uint32_t tok, const uint32_t* lcode, const uint32_t* dcode,
+// code bits of one token: literal byte, or match (l3 = len-3, d1 = dist-1)
+__device__ __forceinline__ void literal_bits(uint32_t byte, const uint32_t* lcode, uint64_t& value, uint32_t& nb) {
+  const uint32_t lc = lcode[byte];
+  value = lc & 0xFFFF;
+  nb = lc >> 16;
+}
+__device__ __forceinline__ void match_bits(uint32_t l3, uint32_t d1, const uint32_t* lcode, const uint32_t* dcode,
                                            uint64_t& value, uint32_t& nb) {
-  if (tok & kTokMatch) {
-    uint32_t le, lv, de, dv;
-    const uint32_t ls = len_symbol((tok >> 16) & 0xFF, le, lv);
-    const uint32_t ds = dist_symbol(tok & 0x7FFF, de, dv);
-    const uint32_t lc = lcode[ls], dc = dcode[ds];
-    uint32_t p = lc >> 16;
-    uint64_t v = lc & 0xFFFF;
-    v |= (uint64_t)lv << p;
-    p += le;
-    v |= (uint64_t)(dc & 0xFFFF) << p;
-    p += dc >> 16;
-    v |= (uint64_t)dv << p;
-    p += de;
-    value = v;
-    nb = p;
-  } else {
-    const uint32_t lc = lcode[tok & 0xFF];
-    value = lc & 0xFFFF;
-    nb = lc >> 16;
-  }
+  uint32_t le, lv, de, dv;
+  const uint32_t ls = len_symbol(l3, le, lv);
+  const uint32_t ds = dist_symbol(d1, de, dv);
+  const uint32_t lc = lcode[ls], dc = dcode[ds];
+  uint32_t p = lc >> 16;
+  uint64_t v = lc & 0xFFFF;
+  v |= (uint64_t)lv << p;
+  p += le;
+  v |= (uint64_t)(dc & 0xFFFF) << p;
+  p += dc >> 16;
+  v |= (uint64_t)dv << p;
+  p += de;
+  value = v;
+  nb = p;
 }
 
 __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__ src, uint64_t n_total,
-                                                     uint32_t /*nchunks*/, const uint32_t* __restrict__ tokens,
+                                                     uint32_t /*nchunks*/, const uint16_t* __restrict__ items,
+                                                     const uint32_t* __restrict__ nitems_in,
                                                      const uint32_t* __restrict__ ntok_in,
                                                      const ChunkPlan* __restrict__ plan,
                                                      const ChunkCodes* __restrict__ codes,
@@ -1109,23 +1131,44 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
   __syncthreads();
 
   const uint32_t ntok = ntok_in[chunk];
-  const uint32_t* tk = tokens + (uint64_t)chunk * kChunk;
+  const uint32_t nit = nitems_in[chunk];
+  const uint16_t* it = items + (uint64_t)chunk * kChunk;
   uint32_t running = 8 * sh + P.header_bits;
   uint32_t buf = 0;
-  // tokens in batches of K4_THREADS*4; the next batch is in flight while this one is packed.
-  // (reads past ntok stay inside the chunk's 32768-slot token area; they are masked below)
-  uint4 q_next = ntok ? *reinterpret_cast<const uint4*>(tk + t * K4_TPT) : make_uint4(0, 0, 0, 0);
-  for (uint32_t b0 = 0; b0 < ntok; b0 += K4_THREADS * K4_TPT, buf ^= 1) {
-    const uint32_t i0 = b0 + t * K4_TPT;
+  // items in batches of K4_THREADS*8 (one 16-byte load per thread); the next batch is in flight while this
+  // one is packed.  A thread also needs the item before its eight (is my first one a match's distance?) and
+  // the one after them (the distance of a match head in my last slot): its neighbours' -- same cache lines.
+  // (reads past nit stay inside the chunk's kChunk-slot item area; they are masked below)
+  auto load_batch = [&](uint32_t i0, uint4& q, uint32_t& before, uint32_t& after) {
+    q = *reinterpret_cast<const uint4*>(it + i0);
+    before = i0 ? it[i0 - 1] : 0u;
+    after = (i0 + K4_IPT < nit) ? it[i0 + K4_IPT] : 0u;
+  };
+  uint4 q_next = make_uint4(0, 0, 0, 0);
+  uint32_t before_next = 0, after_next = 0;
+  if (nit) load_batch(t * K4_IPT, q_next, before_next, after_next);
+  for (uint32_t b0 = 0; b0 < nit; b0 += K4_THREADS * K4_IPT, buf ^= 1) {
+    const uint32_t i0 = b0 + t * K4_IPT;
     const uint4 q = q_next;
-    if (b0 + K4_THREADS * K4_TPT < ntok) q_next = *reinterpret_cast<const uint4*>(tk + i0 + K4_THREADS * K4_TPT);
-    const uint32_t tok[K4_TPT] = {q.x, q.y, q.z, q.w};
-    uint64_t val[K4_TPT];
-    uint32_t nb[K4_TPT], mine = 0;
+    const uint32_t before = before_next, after = after_next;
+    if (b0 + K4_THREADS * K4_IPT < nit) load_batch(i0 + K4_THREADS * K4_IPT, q_next, before_next, after_next);
+    // e[0] = the item before mine, e[1..8] = mine, e[9] = the one after
+    const uint32_t e[K4_IPT + 2] = {before,        q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16,
+                                    q.z & 0xFFFFu, q.z >> 16,     q.w & 0xFFFFu, q.w >> 16, after};
+    uint64_t val[K4_IPT];
+    uint32_t nb[K4_IPT], mine = 0;
+    uint32_t starts = 0;  // bit k: item k starts a token and carries the region flag
 #pragma unroll
-    for (uint32_t k = 0; k < K4_TPT; ++k) {
-      token_bits(tok[k], s_lcode, s_dcode, val[k], nb[k]);
-      if (i0 + k >= ntok) { val[k] = 0; nb[k] = 0; }
+    for (uint32_t k = 0; k < K4_IPT; ++k) {
+      const uint32_t cur = e[k + 1];
+      const bool cont = (e[k] & kItemMatch) != 0;      // the distance half of the match before
+      val[k] = 0;
+      nb[k] = 0;
+      if (!cont && i0 + k < nit) {
+        if (cur & kItemMatch) match_bits(cur & 0xFFu, e[k + 2] & 0x7FFFu, s_lcode, s_dcode, val[k], nb[k]);
+        else literal_bits(cur & 0xFFu, s_lcode, val[k], nb[k]);
+        if (cur & kItemRegion) starts |= 1u << k;
+      }
       mine += nb[k];
     }
     const uint32_t incl = wave_incl_scan(mine, lane);
@@ -1138,16 +1181,16 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
       if (w < wave) pre += v;
       all += v;
     }
-    // the thread's four codes are contiguous in the stream: gather them in a 64-bit window
+    // the thread's codes are contiguous in the stream: gather them in a 64-bit window
     // and OR whole words, instead of one to three atomics per token
     const uint32_t pos = running + pre + incl - mine;
-    if ((tok[0] | tok[1] | tok[2] | tok[3]) & kTokRegion) {
+    if (starts) {
       // k_lz77 flags the first token of every 1024-byte parse region (32 per chunk): its bit offset is the
       // sub-index entry
       uint32_t pk = pos;
 #pragma unroll
-      for (uint32_t k = 0; k < K4_TPT; ++k) {
-        if ((tok[k] & kTokRegion) && i0 + k < ntok) sub[2 * ((tok[k] >> 24) & 31u)] = pk - 8 * sh;
+      for (uint32_t k = 0; k < K4_IPT; ++k) {
+        if ((starts >> k) & 1) sub[2 * ((e[k + 1] >> 8) & 31u)] = pk - 8 * sh;
         pk += nb[k];
       }
     }
@@ -1163,7 +1206,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
       }
     };
 #pragma unroll
-    for (uint32_t k = 0; k < K4_TPT; ++k) {
+    for (uint32_t k = 0; k < K4_IPT; ++k) {
       if (nb[k] <= 32) {
         put((uint32_t)val[k], nb[k]);
       } else {
@@ -1221,18 +1264,21 @@ hipError_t init_kernels() {
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
                        const Options& opt, hipStream_t s) {
-  // diagnostic: SFH_K1_EXTRA_LDS=<bytes> inflates the LDS request (e.g. 8192 -> one workgroup per CU)
+  // diagnostic: SFH_K1_EXTRA_LDS=<bytes> inflates the LDS request (e.g. 16384 -> one workgroup per CU)
   static const uint32_t extra = [] {
     const char* e = getenv("SFH_K1_EXTRA_LDS");
     return e ? (uint32_t)atoi(e) : 0u;
   }();
   const uint32_t K1_LDS = sf::K1_LDS + extra;
+  if (opt.strip_bytes == 0 || opt.strip_bytes % kChunk || opt.strip_bytes > kMaxStrip) return hipErrorInvalidValue;
+  const uint32_t per = opt.strip_bytes / kChunk;
+  const uint32_t nstrips = (nchunks + per - 1) / per;
   if (ws.stamps)
-    hipLaunchKernelGGL(k_lz77<true>, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
-                       ws.hist, ws.rtok, opt.lazy, opt.fast_skip, ws.stamps);
+    hipLaunchKernelGGL(k_lz77<true>, dim3(nstrips), dim3(K1_THREADS), K1_LDS, s, src, n, opt.strip_bytes, ws.items,
+                       ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, ws.stamps);
   else
-    hipLaunchKernelGGL(k_lz77<false>, dim3(nchunks), dim3(K1_THREADS), K1_LDS, s, src, n, ws.tokens, ws.ntok,
-                       ws.hist, ws.rtok, opt.lazy, opt.fast_skip, (uint64_t*)nullptr);
+    hipLaunchKernelGGL(k_lz77<false>, dim3(nstrips), dim3(K1_THREADS), K1_LDS, s, src, n, opt.strip_bytes, ws.items,
+                       ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, (uint64_t*)nullptr);
   return hipGetLastError();
 }
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,
@@ -1247,7 +1293,7 @@ hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, uin
 }
 hipError_t launch_emit(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
                        uint8_t* dst, hipStream_t s) {
-  hipLaunchKernelGGL(k_emit, dim3(nchunks), dim3(K4_THREADS), 0, s, src, n, nchunks, ws.tokens, ws.ntok,
+  hipLaunchKernelGGL(k_emit, dim3(nchunks), dim3(K4_THREADS), 0, s, src, n, nchunks, ws.items, ws.nitems, ws.ntok,
                      ws.plan, ws.codes, ws.offsets, ws.rtok, ws.subidx, dst);
   return hipGetLastError();
 }

@@ -32,6 +32,10 @@ class Params(C.Structure):
         ("fast_skip", C.c_uint32),
         ("far4_dist", C.c_uint32),
         ("container", C.c_uint32),
+        ("strip_bytes", C.c_uint32),
+        ("x_long_levels", C.c_uint32),
+        ("x_long_near", C.c_uint32),
+        ("x_rank_cap", C.c_uint32),
     ]
 
 
@@ -89,6 +93,10 @@ def lib():
         L.sfo_crc32_combine.restype = C.c_uint32
         L.sfo_adler32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
         L.sfo_adler32_combine.restype = C.c_uint32
+        L.sfo_strip_tokens.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Params), C.c_void_p, C.c_void_p]
+        L.sfo_strip_tokens.restype = C.c_int
+        L.sfo_resolve_strip_bytes.argtypes = [C.POINTER(Params), C.c_size_t]
+        L.sfo_resolve_strip_bytes.restype = C.c_size_t
         L.sfo_match_chunk.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Params), C.c_void_p, C.c_void_p]
         L.sfo_match_chunk.restype = None
         L.sfo_parse_chunk.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -169,6 +177,40 @@ def crc32(data):
 def adler32(data):
     s = _u8(data)
     return lib().sfo_adler32(_ptr(s) if s.size else None, s.size)
+
+
+def resolve_strip_bytes(params, n):
+    return lib().sfo_resolve_strip_bytes(C.byref(params), n)
+
+
+def strip_tokens(data, params):
+    """Stages n1 + parse over one strip -> (tokens uint32[nregions * R] with region r's tokens at [r * R, r * R +
+    ntok[r]), ntok uint32[nregions]); regions count from the strip's start, a chunk's regions are those it covers."""
+    s = _u8(data)
+    R = params.region_bytes
+    nreg = (s.size + R - 1) // R
+    tokens = np.zeros((nreg + 1) * R, dtype=np.uint32)
+    ntok = np.zeros(nreg + 1, dtype=np.uint32)
+    rc = lib().sfo_strip_tokens(_ptr(s) if s.size else None, s.size, C.byref(params), _ptr(tokens), _ptr(ntok))
+    if rc:
+        raise RuntimeError(f"sfo_strip_tokens rc={rc}")
+    return tokens[: nreg * R], ntok[:nreg]
+
+
+def chunk_tokens(data, params):
+    """Per chunk of the whole input (strips of sfo_resolve_strip_bytes): (flat token array, tokens per region)."""
+    s = _u8(data)
+    sb = resolve_strip_bytes(params, s.size)
+    cb, R = params.chunk_bytes, params.region_bytes
+    out = []
+    for s0 in range(0, max(s.size, 1), sb):
+        strip = s[s0:s0 + sb]
+        t, nt = strip_tokens(strip, params)
+        for c0 in range(0, max(strip.size, 1), cb):
+            r0, r1 = c0 // R, (min(c0 + cb, strip.size) + R - 1) // R
+            flat = [t[r * R: r * R + nt[r]] for r in range(r0, r1)]
+            out.append((np.concatenate(flat) if flat else np.zeros(0, np.uint32), nt[r0:r1].copy(), t[r0 * R: r1 * R].copy()))
+    return out
 
 
 def match_chunk(data, params):
