@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--container", default="raw", choices=["raw", "zlib", "gzip"],
                     help="wrap the stream (RFC 1950 / 1952); the checksum kernels are then inside the timed step")
     ap.add_argument("--no-decompress", action="store_true", help="skip the GPU decompress leg (N = 1 only)")
+    ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N > 1 code path (RCCL group, rounds, gather) even with one rank")
     args = ap.parse_args()
@@ -100,7 +101,7 @@ def main():
 
         def compress_fn(piece, final, k):
             out, nb = comp.compress_tensor(piece, out=scratch[k], final_stream=final,
-                                           container="raw" if multi else args.container)
+                                           container="raw" if multi else args.container, block_bytes=args.block_bytes)
             sizes[k] = nb
             for name, v in comp.stage_ms().items():
                 ms[name] = ms.get(name, 0.0) + v

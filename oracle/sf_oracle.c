@@ -326,7 +326,7 @@ void sfo_default_params(sfo_params* p) {
   p->chunk_bytes = 32768;
   p->step = 1024;
   p->hash_bits = 12;
-  p->region_bytes = 1024;
+  p->region_bytes = 512;
   p->min_match = 4;
   p->lazy = 3;
   p->final_stream = 1;
@@ -447,7 +447,7 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
       uint32_t maxlen = n - i < 258 ? n - i : 258;
       if (rend - i < maxlen) maxlen = rend - i;
       uint32_t best = 0, bc = 0, c = H[h];
-      for (uint32_t k = 0; k < p->chain_depth && c != NONE && i - c <= SFO_WINDOW; k++, c = prev[c]) {
+      for (uint32_t k = 0; k < p->chain_depth && c != NONE && i - c <= (p->x_window ? p->x_window : SFO_WINDOW); k++, c = prev[c]) {
         uint32_t l = match_len(d, i, c, maxlen);
         if (l > best) { best = l; bc = c; }
       }
@@ -505,7 +505,7 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
         }
         for (uint32_t k = 0; k < nc; k++) {
           uint32_t dist = i - cand[k];
-          if (dist > SFO_WINDOW) continue;
+          if (dist > (p->x_window ? p->x_window : SFO_WINDOW)) continue;
           uint32_t l = match_len(d, i, cand[k], cmplen);
           if (p->x_rank_cap && l > p->x_rank_cap) l = p->x_rank_cap;
           if (l > best || (l == best && l && dist < bdist)) { best = l; bdist = dist; }
@@ -858,9 +858,14 @@ static void emit_chunk(const uint8_t* data, uint32_t n, const uint32_t* tokens,
   uint32_t llc[288], dc[32];
   sfo_canonical_codes(ll_lens, 288, llc);
   sfo_canonical_codes(d_lens, 32, dc);
-  uint32_t nreg = (n + p->region_bytes - 1) / p->region_bytes, seen = 0;
+  uint32_t nreg = (n + p->region_bytes - 1) / p->region_bytes, seen = 0, nsub = 0;
   for (uint32_t r = 0; r < nreg; r++) {
-    if (sub && r < SFO_SUB_REGIONS) { sub[2 * r] = (uint32_t)w.bitpos; sub[2 * r + 1] = seen; }
+    /* sub-index entry per SFO_SUB_BYTES of input (a region boundary, hence a token start) */
+    if (sub && (r * p->region_bytes) % SFO_SUB_BYTES == 0 && nsub < SFO_SUB_REGIONS) {
+      sub[2 * nsub] = (uint32_t)w.bitpos;
+      sub[2 * nsub + 1] = seen;
+      nsub++;
+    }
     seen += ntok[r];
     for (uint32_t k = 0; k < ntok[r]; k++) {
       uint32_t t = tokens[(size_t)r * p->region_bytes + k];
@@ -876,7 +881,7 @@ static void emit_chunk(const uint8_t* data, uint32_t n, const uint32_t* tokens,
       }
     }
   }
-  for (uint32_t r = nreg; sub && r < SFO_SUB_REGIONS; r++) { sub[2 * r] = (uint32_t)w.bitpos; sub[2 * r + 1] = seen; }
+  for (uint32_t r = nsub; sub && r < SFO_SUB_REGIONS; r++) { sub[2 * r] = (uint32_t)w.bitpos; sub[2 * r + 1] = seen; }
   put_bits(&w, rev_bits(llc[256], ll_lens[256]), ll_lens[256]);
   if (!bfinal) {
     /* byte-align with an empty non-final stored block: 000, pad, 00 00 FF FF */

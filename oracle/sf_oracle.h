@@ -104,7 +104,7 @@ typedef struct sfo_params {
                             blocks of the same strip (legal: /root/reference/src/decompress.cpp:178) */
   /* analysis knobs (tools/exp): levels of the long table that are tried (0 = depth), its near
    * candidate, and a cap on the length that ranks candidates (the winner is then compared to `cap`) */
-  uint32_t x_long_levels, x_long_near, x_rank_cap;
+  uint32_t x_long_levels, x_long_near, x_rank_cap, x_window;
 } sfo_params;
 
 #define SFO_WINDOW 32768u
@@ -140,6 +140,7 @@ int sfo_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t*
  *           byte, tokens before it}; regions past the data name the end-of-block code / token total;
  *           all zero for a stored chunk. */
 #define SFO_SUB_REGIONS 32u
+#define SFO_SUB_BYTES 1024u /* one sub-index entry per this many input bytes; region_bytes must divide it */
 int sfo_compress_indexed(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len,
                          const sfo_params* p, uint64_t* index, uint32_t* subindex);
 

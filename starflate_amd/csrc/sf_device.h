@@ -27,12 +27,13 @@ constexpr uint32_t kWindow = 32768;     // a match reaches back at most this far
 constexpr uint32_t kStep = 1024;        // positions per hash-insertion step (= K1 threads)
 constexpr uint32_t kHashBits = 12;      // buckets of two 16-bit history levels each
 constexpr uint32_t kMaxStrip = 1u << 24;  // largest block_bytes
-constexpr uint32_t kRegion = 1024;      // parse region: matches never cross it
+constexpr uint32_t kRegion = 512;       // parse region: matches never cross it (one wave of k_lz77 parses one)
+constexpr uint32_t kSubBytes = 1024;    // sub-index granularity: every kSubBytes-th position starts a token
 constexpr uint32_t kCap = 16;           // match-time compare width; longer matches are extended by the parse
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kFar4 = 4096;        // a match of exactly 4 bytes beyond this distance is not used
 constexpr uint32_t kSkipSlack = 128;    // stored fast path: first 8 KiB with >= 8192-128 tokens => no further search
-constexpr uint32_t kSubRegions = kChunk / kRegion;  // 32 sub-index entries per chunk
+constexpr uint32_t kSubRegions = kChunk / kSubBytes;  // 32 sub-index entries per chunk
 constexpr uint32_t kTokMatch = 0x80000000u;  // decoder token (k_inflate_*): bit31 match, 16..23 len-3, 0..14 dist-1
 constexpr uint32_t kTokRegion = 0x40000000u; // decoder token: first token of a parse region, region index in 24..28
 // k_lz77 -> k_emit: 16-bit ITEMS, at most kChunk per chunk.  A literal is one item (the byte); a match is two:

@@ -52,6 +52,32 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
   return v;
 }
 
+// Wave-wide scans on the DPP network (no LDS round trips).  Identity 0; a lane whose source does not exist keeps
+// the identity (`old` operand, bound_ctrl off).  row_shr:n = 0x110+n, row_bcast:15 = 0x142 (rows 1 and 3),
+// row_bcast:31 = 0x143 (rows 2 and 3), wave_shr:1 = 0x138.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_from(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+  v += dpp_from<0x111, 0xF>(v);
+  v += dpp_from<0x112, 0xF>(v);
+  v += dpp_from<0x114, 0xF>(v);
+  v += dpp_from<0x118, 0xF>(v);
+  v += dpp_from<0x142, 0xA>(v);
+  v += dpp_from<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_excl_max(uint32_t v) {
+  v = max(v, dpp_from<0x111, 0xF>(v));
+  v = max(v, dpp_from<0x112, 0xF>(v));
+  v = max(v, dpp_from<0x114, 0xF>(v));
+  v = max(v, dpp_from<0x118, 0xF>(v));
+  v = max(v, dpp_from<0x142, 0xA>(v));
+  v = max(v, dpp_from<0x143, 0xC>(v));
+  return dpp_from<0x138, 0xF>(v);
+}
+
 // ---------------------------------------------------------------------------
 // K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per STRIP (block_bytes of
 // input), two workgroups per CU (LDS <= 80 KiB, 64 VGPRs).  The strip is processed in ROUNDS of
@@ -78,13 +104,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 // ---------------------------------------------------------------------------
 constexpr uint32_t K1_THREADS = kStep;
 constexpr uint32_t K1_WAVES = K1_THREADS / 64;
-constexpr uint32_t kRound = 4096;                            // positions per match->parse round
-constexpr uint32_t kRSegs = kRound / 64;                     // 64 mask words per round: one per lane
-constexpr uint32_t kRRegions = kRound / kRegion;
+constexpr uint32_t kRound = 8192;                            // positions per match->parse round
+constexpr uint32_t kRSubs = kRound / kSubBytes;              // sub-index regions per round
 constexpr uint32_t kRoundsPerChunk = kChunk / kRound;
 constexpr uint32_t kLook = 32;                               // bytes staged beyond the round (compare + alignment)
 constexpr uint32_t kSkipSpan = 8192;                         // stored fast path: decided after this many positions of a chunk
-static_assert(kRSegs == 64, "segment prefixes: one segment per lane");
+static_assert(kRound / 8 == K1_THREADS && kRegion == 8 * 64, "parse: eight positions per thread, one region per wave");
+static_assert(kSubBytes % kRegion == 0 && kRound % kSubBytes == 0, "sub-index regions are whole parse regions");
 static_assert(kSkipSpan % kRound == 0 && kChunk % kRound == 0, "round geometry");
 // step codes in a 16-bit table half: ((step - epoch) + 1) << 10 | (1023 - t); the epoch advances by
 // kEpochSteps whenever a round would reach kEpochMax steps past it, entries older than that vanish
@@ -93,15 +119,15 @@ static_assert(kEpochMax - kEpochSteps >= kWindow / kStep && ((kEpochMax + 1) << 
 static_assert(kEpochMax % (kRound / kStep) == 0 && kEpochSteps % (kRound / kStep) == 0, "ageing happens between rounds");
 // LDS carve (bytes); every offset is a multiple of 16
 constexpr uint32_t L_DATA = 0;                               // window | round | look-ahead
-constexpr uint32_t L_LEN8 = L_DATA + kWindow + kRound + kLook;  // u8[kRound+16] low bits len-3 (capped)
-constexpr uint32_t L_DIST = L_LEN8 + kRound + 16;            // u16[kRound]
+constexpr uint32_t L_LEN4 = L_DATA + kWindow + kRound + kLook;  // 4 bits per position: capped len-3 (0: no match), eight per dword
+constexpr uint32_t L_DIST = L_LEN4 + kRound / 2 + 16;        // u16[kRound]
 constexpr uint32_t L_TABLE = L_DIST + 2 * kRound;            // u32[1<<kHashBits]
 constexpr uint32_t L_HIST = L_TABLE + (4u << kHashBits);     // u32[320]
-constexpr uint32_t L_MARKS = L_HIST + 4 * kHistStride;       // u64[64] chain positions per 64-segment
-constexpr uint32_t L_MM = L_MARKS + 8 * kRSegs;              // u64[64] positions whose match would be taken
-constexpr uint32_t K1_LDS = L_MM + 8 * kRSegs;
+constexpr uint32_t L_WTOT = L_HIST + 4 * kHistStride;        // u32[16] tokens | matches << 16 of each wave's region
+constexpr uint32_t K1_LDS = L_WTOT + 4 * K1_WAVES;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
-static_assert(L_MARKS % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0 && L_LEN8 % 16 == 0 && L_HIST % 16 == 0, "LDS alignment");
+static_assert(L_WTOT % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0 && L_LEN4 % 16 == 0 && L_HIST % 16 == 0, "LDS alignment");
+static_assert(kCap - 3 <= 15, "capped len-3 fits four bits");
 static_assert((kWindow + kLook) % 16 == 0 && kRound % 16 == 0, "window shift in 16-byte units");
 
 // first mismatching byte (0..16) between the 16 bytes in a0..a3 and those at LDS byte address c
@@ -136,7 +162,7 @@ template <bool STAMPS>
 __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     const uint8_t* __restrict__ src, uint64_t n_total, uint32_t strip_bytes, uint16_t* __restrict__ items,
     uint32_t* __restrict__ nitems_out, uint32_t* __restrict__ ntok_out, uint32_t* __restrict__ hist_out,
-    uint32_t* __restrict__ rtok_out, uint32_t lazy, uint32_t fast_skip, uint64_t* __restrict__ stamps) {
+    uint32_t* __restrict__ rtok_out, uint32_t lazy, uint32_t fast_skip, uint64_t* __restrict__ stamps, uint32_t dbg) {
   uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t st_t = 0;
   auto stamp = [&](int slot) {
@@ -151,19 +177,15 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* s_data = reinterpret_cast<uint32_t*>(smem + L_DATA);
   uint8_t* s_bytes = smem + L_DATA;
-  uint8_t* s_len8 = smem + L_LEN8;
-  uint32_t* s_len32 = reinterpret_cast<uint32_t*>(smem + L_LEN8);
+  uint32_t* s_len4 = reinterpret_cast<uint32_t*>(smem + L_LEN4);
   uint16_t* s_dist = reinterpret_cast<uint16_t*>(smem + L_DIST);
   uint32_t* s_table = reinterpret_cast<uint32_t*>(smem + L_TABLE);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + L_HIST);
-  uint32_t* s_marks32 = reinterpret_cast<uint32_t*>(smem + L_MARKS);
-  uint64_t* s_marks = reinterpret_cast<uint64_t*>(smem + L_MARKS);
-  uint64_t* s_mm = reinterpret_cast<uint64_t*>(smem + L_MM);
+  uint32_t* s_wtot = reinterpret_cast<uint32_t*>(smem + L_WTOT);
 
   const uint32_t t = threadIdx.x;
   // t >> 6 is wave-uniform, but only readfirstlane tells the compiler so
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), lane = t & 63;
-  const uint64_t lt_mask = (1ull << lane) - 1;
   const uint32_t strip = blockIdx.x;
   const uint64_t sbase = (uint64_t)strip * strip_bytes;
   const uint32_t n = (uint32_t)((n_total - sbase) < (uint64_t)strip_bytes ? (n_total - sbase) : strip_bytes);
@@ -184,9 +206,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) t4[idx] = make_uint4(0, 0, 0, 0);
     for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) s_hist[idx] = (idx == 256) ? 1u : 0u;
     if (t < kLook / 4) s_data[(kWindow + kRound) / 4 + t] = load4(4 * t);
-    if (t < 4) s_len32[kRound / 4 + t] = 0;  // pad read by the take pass
+    if (t < 4) s_len4[kRound / 8 + t] = 0;  // pad read by the take pass
   }
-  uint32_t pre_next = load4(kLook + 4 * t);  // this thread's dword of round 0 (positions kLook + 4t ..)
+  // this thread's eight bytes of round 0 (positions kLook + 8t ..)
+  uint32_t pre_lo = load4(kLook + 8 * t), pre_hi = load4(kLook + 8 * t + 4);
   __syncthreads();
   stamp(0);
 
@@ -208,7 +231,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     // ---- stage: shift the window down by one round, append the prefetched 4 KiB ----
     {
       uint4* s4 = reinterpret_cast<uint4*>(smem + L_DATA);
-      constexpr uint32_t kUnits = (kWindow + kLook) / 16, kOff = kRound / 16;  // 2050 units move down by 256
+      constexpr uint32_t kUnits = (kWindow + kLook) / 16, kOff = kRound / 16;  // 2050 units move down by 512
       static_assert(kUnits > 2 * K1_THREADS && kUnits <= 3 * K1_THREADS, "shift: three units per thread");
       const uint4 c0 = s4[kOff + t], c1 = s4[kOff + K1_THREADS + t];
       uint4 c2 = make_uint4(0, 0, 0, 0);
@@ -217,8 +240,11 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       s4[t] = c0;
       s4[K1_THREADS + t] = c1;
       if (t < kUnits - 2 * K1_THREADS) s4[2 * K1_THREADS + t] = c2;
-      s_data[(kWindow + kLook) / 4 + t] = pre_next;
-      pre_next = (r + 1 < nrounds) ? load4(rb + kRound + kLook + 4 * t) : 0u;
+      *reinterpret_cast<uint2*>(&s_data[(kWindow + kLook) / 4 + 2 * t]) = make_uint2(pre_lo, pre_hi);
+      if (r + 1 < nrounds) {
+        pre_lo = load4(rb + kRound + kLook + 8 * t);
+        pre_hi = load4(rb + kRound + kLook + 8 * t + 4);
+      }
       // age the step codes: entries older than the window drop out, the rest move down by kEpochSteps
       if (rb / kStep - ebase >= kEpochMax) {
         constexpr uint32_t kDrop = (kEpochSteps + 1) << 10, kSub = kEpochSteps << 10;
@@ -238,10 +264,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // every position is a literal
       for (uint32_t rel = t; rel < qn; rel += K1_THREADS) {
         const uint32_t b = s_bytes[kWindow + rel];
-        gi[tot_items + rel] = (uint16_t)((rel & (kRegion - 1)) == 0 ? (b | kItemRegion | ((rc * kRRegions + rel / kRegion) << 8)) : b);
+        gi[tot_items + rel] = (uint16_t)((rel & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((rc * kRSubs + rel / kSubBytes) << 8)) : b);
         atomicAdd(&s_hist[b], 1u);
       }
-      if (t < kRRegions) rtok_out[chunk * kSubRegions + rc * kRRegions + t] = tot_tok + (t * kRegion < qn ? t * kRegion : qn);
+      if (t < kRSubs) rtok_out[chunk * kSubRegions + rc * kRSubs + t] = tot_tok + (t * kSubBytes < qn ? t * kSubBytes : qn);
       tot_tok += qn;
       tot_items += qn;
     } else {
@@ -290,232 +316,175 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         if (m1 > best) { best = m1; bd = ad - q1; }
         // a 4-byte match farther than kFar4 costs more bits than four literals: drop it
         const bool ok = best >= kMinMatch && (p + kMinMatch <= n) && !(best == 4 && bd > kFar4);
-        s_len8[rel] = (uint8_t)(ok ? best - 3 : 0u);
         s_dist[rel] = (uint16_t)(ok ? bd : 0u);
+        // eight lanes' 4-bit lengths -> one dword, gathered with DPP moves (no LDS round trip)
+        uint32_t v = ok ? best - 3 : 0u;
+        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
+        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA /* quad_perm:[2,2,2,2] */, 0xF, 0xF, true) << 8;
+        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104 /* row_shl:4 */, 0xF, 0xF, true) << 16;
+        if ((t & 7) == 0) s_len4[rel >> 3] = v;
       }
       __syncthreads();
       stamp(1);
 
-      // ---- take pass (position-parallel): 64-bit masks of the positions whose match the
-      // greedy/lazy rule would take.  Each wave owns kIter consecutive segments: batched loads,
-      // one ballot per segment, no barrier inside.
+      // ---- parse: wave-local.  Thread t owns the eight positions [8t, 8t+8) of the round, a wave one
+      // kRegion-byte parse region (matches never cross it), so the greedy/lazy chain of a region is
+      // resolved inside one wave, in registers, with no barrier:
+      //   take    : from the lane's dword of 4-bit lengths (+ the next lane's for the look-ahead) the
+      //             positions whose match the greedy/lazy rule would take
+      //   walk    : every lane follows the chain through its eight positions from an entry offset
+      //             (speculatively 0) and reports where the chain leaves it; a lane's true entry is
+      //             the largest exit of the lanes before it (exclusive prefix maximum over the wave;
+      //             lanes the chain jumps over report nothing).  Lanes whose entry changed walk again,
+      //             until nothing changes -- lane k is final after k rounds at the latest, usually
+      //             after two or three, since chains that meet stay together.
+      //   count   : tokens / matches per lane, wave scan, one total per wave to LDS
+      // then one barrier and
+      //   emit    : every lane writes its (at most eight) items at their compact place, + histogram
+      const uint32_t pb = 8 * t;                       // the lane's first position, round-relative
+      const uint32_t nv = qn > pb ? (qn - pb < 8 ? qn - pb : 8u) : 0u;  // its valid positions
+      uint32_t T;                                      // take bits of the eight positions
+      const uint32_t N = s_len4[t];
       {
-        constexpr uint32_t kIter = kRSegs / K1_WAVES;  // 64-position segments per wave
-        const uint32_t sg0 = wave * kIter;
-        uint32_t l3[kIter], n1[kIter], n2[kIter], n3[kIter];
+        // lazy deferral looks up to `lazy` positions ahead, inside the region and the input
+        const uint32_t wn = lane == 63 ? 0u : s_len4[t + 1];
+        // positions at or beyond qn carry stale lengths of an earlier round: clear them
+        const uint32_t left = qn > pb ? qn - pb : 0u;  // valid positions from this dword's first on
+        uint64_t W = (uint64_t)N | ((uint64_t)wn << 32);
+        if (left < 16) W &= left ? ((1ull << (4 * left)) - 1ull) : 0ull;
+        uint32_t bits = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < kIter; ++j) {
-          const uint32_t rel = (sg0 + j) * 64 + lane;
-          l3[j] = s_len8[rel];
-          n1[j] = s_len8[rel + 1];
-          n2[j] = s_len8[rel + 2];
-          n3[j] = s_len8[rel + 3];
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < kIter; ++j) {
-          const uint32_t rel = (sg0 + j) * 64 + lane;
-          const uint32_t cur = rel < qn ? l3[j] : 0u;  // beyond n: stale results of an earlier round
-          // lazy deferral looks up to `lazy` positions ahead, inside the region and the input
-          const uint32_t room = kRegion - (rel & (kRegion - 1));  // positions left in the region, this one included
-          const uint32_t a1 = (lazy >= 1 && rel + 1 < qn && room > 1) ? n1[j] : 0u;
-          const uint32_t a2 = (lazy >= 2 && rel + 2 < qn && room > 2) ? n2[j] : 0u;
-          const uint32_t a3 = (lazy >= 3 && rel + 3 < qn && room > 3) ? n3[j] : 0u;
+        for (uint32_t k = 0; k < 8; ++k) {
+          const uint32_t cur = (uint32_t)(W >> (4 * k)) & 15u;
+          const uint32_t a1 = lazy >= 1 ? (uint32_t)(W >> (4 * k + 4)) & 15u : 0u;
+          const uint32_t a2 = lazy >= 2 ? (uint32_t)(W >> (4 * k + 8)) & 15u : 0u;
+          const uint32_t a3 = lazy >= 3 ? (uint32_t)(W >> (4 * k + 12)) & 15u : 0u;
           const bool defer = a1 > cur || a2 > cur + 1 || a3 > cur + 2;
-          const uint64_t T = __ballot(cur != 0 && !defer);
-          if (lane == 0) s_mm[sg0 + j] = T;
+          bits |= (cur != 0 && !defer) ? (1u << k) : 0u;
         }
+        T = bits;
       }
-      __syncthreads();
       stamp(2);
-
-      // ---- walk: the chain of every 1024-byte region, 32 lanes per region ----
-      // Lane (r, s) walks the 32-position sub-region s of region r: first speculatively from
-      // the sub-region's start (exact for s = 0), chain bits kept in a register (one dword per
-      // lane).  Then each lane re-walks from its predecessor's exit until it meets its own
-      // speculative chain (greedy chains that meet stay together) or leaves the sub-region;
-      // the rounds stop when no entry changes and leave the exact serial chain.  One loop
-      // iteration is a chain step (one dependent LDS byte read) or one 8-byte step of
-      // extending a capped match (lane-local state machine).
-#ifndef SF_K1_SUB
-#define SF_K1_SUB 32
-#endif
-      constexpr uint32_t kSub = SF_K1_SUB, kSubPerRegion = kRegion / kSub, kWalkWaves = kRound / kSub / 64;
-      static_assert((kSub == 16 || kSub == 32) && kWalkWaves >= 1 && K1_WAVES % kWalkWaves == 0, "walker geometry");
-      const uint32_t w0 = (r * kWalkWaves) % K1_WAVES;  // walking waves rotate over the SIMDs
-      if (wave >= w0 && wave < w0 + kWalkWaves) {
-        const uint32_t L = (wave - w0) * 64 + lane;                  // sub-region index in the round
-        const uint32_t sb = L * kSub;
-        const uint32_t rgb = sb & ~(kRegion - 1);
-        const uint32_t re = rgb + kRegion < qn ? rgb + kRegion : qn; // region end (round-relative)
-        const uint32_t se = sb + kSub < re ? sb + kSub : re;         // sub-region end (may be <= sb)
-        const uint32_t sub = L & (kSubPerRegion - 1);
-        constexpr uint32_t kNone = 0xFFFFFFFFu;
-        using mask_t = uint64_t;
-        static_assert(kSub <= 32, "the take-mask slice of a sub-region is one 32-bit register");
-        const uint32_t t32 = (uint32_t)(s_mm[sb >> 6] >> (sb & 63)) & (kSub == 32 ? 0xFFFFFFFFu : ((1u << (kSub & 31)) - 1u));
-        // walk from `pos` while inside [sb, se); stops early on a position of `conv`
-        auto sub_walk = [&](uint32_t pos, mask_t conv, mask_t& marks, uint32_t& exitp, uint32_t& e0, uint32_t& e1,
-                            uint32_t& cpos) {
-          marks = 0; e0 = 0; e1 = 0; cpos = kNone;
-          uint32_t xl = 0, xmp = 0, xpa = 0, xca = 0, xmax = 0;      // extension state (xl = 0: none)
-          while (pos < se) {
-            if (xl == 0) {
-              const uint32_t m = t32 >> (pos - sb);      // take positions from pos to the sub-region's end
-              const bool hit = m != 0;
-              const uint32_t k = hit ? (uint32_t)__builtin_ctz(m) : 0u;
-              const uint32_t nb = hit ? k + 1 : se - pos;  // chain run: literals (+ the match position)
-              const uint64_t run = ((1ull << nb) - 1ull) << (pos - sb);
-              const uint64_t c = conv & run;
-              if (c) {                                   // met the speculative chain: from here on it is ours
-                const uint32_t q = (uint32_t)__builtin_ctzll(c);
-                marks |= run & ((1ull << q) - 1ull);
-                cpos = sb + q;
-                break;
-              }
-              marks |= run;
-              const uint32_t mp = pos + k;               // match position on a hit (inside the sub-region)
-              if (hit) {
-                const uint32_t len = (uint32_t)s_len8[mp] + 3;  // the one dependent LDS read per match
-                if (len == kCap) {                       // capped at match time: extend from here
-                  xmp = mp;
-                  xpa = kWindow + mp;
-                  xca = xpa - s_dist[mp];
-                  xmax = re - mp < 258u ? re - mp : 258u;
-                  xl = kCap;
-                } else {
-                  pos = mp + len;
+      uint32_t marks = 0;                              // chain positions among the eight
+      uint32_t cap_mp = 8, cap_len = 0;                // the capped chain match that was extended (at most one per lane)
+      uint32_t exit_abs = 0;                           // region-relative position where the chain leaves this lane (0: not on it)
+      {
+        const uint32_t lb = 8 * lane;                  // the lane's first position, region-relative
+        const uint32_t rend = (pb & ~(kRegion - 1)) + kRegion < qn ? (pb & ~(kRegion - 1)) + kRegion : qn;  // region end, round-relative
+        // follow the chain from local offset e (< nv)
+        auto walk = [&](uint32_t e) {
+          uint32_t pos = e, mk = 0;
+#pragma unroll 1
+          while (pos < nv) {
+            const uint32_t m = T >> pos;
+            if (m == 0) {                              // literals to the lane's end
+              mk |= ((1u << nv) - 1u) & ~((1u << pos) - 1u);
+              pos = 8;
+              break;
+            }
+            const uint32_t k = (uint32_t)__builtin_ctz(m);
+            mk |= ((2u << k) - 1u) << pos;             // literals, then the match position
+            const uint32_t mp = pos + k;
+            uint32_t len = ((N >> (4 * mp)) & 15u) + 3;
+            if (len == kCap) {                         // capped at match time: extend (once per position)
+              if (cap_mp != mp) {
+                const uint32_t xpa = kWindow + pb + mp, xca = xpa - s_dist[pb + mp];
+                const uint32_t xmax = rend - (pb + mp) < 258u ? rend - (pb + mp) : 258u;
+                uint32_t l = kCap;
+                while (l < xmax) {
+                  const uint32_t ia = xpa + l, ja = xca + l;
+                  const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
+                  const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
+                  const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, ia & 3) ^ __builtin_amdgcn_alignbyte(j1, j0, ja & 3);
+                  const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, ia & 3) ^ __builtin_amdgcn_alignbyte(j2, j1, ja & 3);
+                  if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; break; }
+                  if (x1) { l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3); break; }
+                  l += 8;
                 }
-              } else {
-                pos = pos + nb;                          // literals up to the run's (clipped) end
+                cap_mp = mp;
+                cap_len = l < xmax ? l : xmax;
               }
-            } else {
-              uint32_t l = xl;
-              bool done = l >= xmax;
-              if (!done) {
-                const uint32_t ia = xpa + l, ja = xca + l;
-                const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
-                const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
-                const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, ia & 3) ^ __builtin_amdgcn_alignbyte(j1, j0, ja & 3);
-                const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, ia & 3) ^ __builtin_amdgcn_alignbyte(j2, j1, ja & 3);
-                if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; done = true; }
-                else if (x1) { l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3); done = true; }
-                else l += 8;
-              }
-              if (done) {
-                l = l < xmax ? l : xmax;
-                const uint32_t e = 0x10000u | ((xmp - sb) << 9) | l;  // full length of a capped chain match (pos: 6 bits)
-                if (e0 == 0) e0 = e; else e1 = e;
-                pos = xmp + l;
-                xl = 0;
-              } else {
-                xl = l;
-              }
+              len = cap_len;
             }
+            pos = mp + len;
           }
-          exitp = pos;
+          marks = mk;
+          exit_abs = lb + (pos > 8 ? pos : 8u);
         };
-        mask_t mS;
-        uint32_t xS, eS0, eS1, cdummy;
-        sub_walk(sb, 0u, mS, xS, eS0, eS1, cdummy);
-        if (se <= sb) xS = sb;
-        mask_t marks = mS;
-        uint32_t exitc = xS, f0 = eS0, f1 = eS1, entry_used = sb;
-        for (uint32_t round = 0; round < kSubPerRegion - 1; ++round) {
-          const uint32_t pe = (uint32_t)__shfl_up((int)exitc, 1, 64);
-          const bool redo = sub != 0 && pe != entry_used;
-          if (!__any(redo)) break;
-          if (redo) {
-            entry_used = pe;
-            if (pe >= se) {                              // a long match of the predecessor jumps over us
-              marks = 0; exitc = pe; f0 = 0; f1 = 0;
-            } else {
-              mask_t mF;
-              uint32_t xF, eF0, eF1, cpos;
-              sub_walk(pe, mS, mF, xF, eF0, eF1, cpos);
-              if (cpos != kNone) {
-                const mask_t keep = ~((1ull << (cpos - sb)) - 1ull);  // speculative chain from cpos on
-                marks = mF | (mS & keep);
-                exitc = xS;
-                // capped matches: the re-walked ones, then the speculative ones at or after cpos
-                f0 = eF0; f1 = eF1;
-                const uint32_t q = cpos - sb;
-                if (eS0 && ((eS0 >> 9) & 63u) >= q) { if (f0 == 0) f0 = eS0; else f1 = eS0; }
-                if (eS1 && ((eS1 >> 9) & 63u) >= q) { if (f0 == 0) f0 = eS1; else f1 = eS1; }
-              } else {
-                marks = mF; exitc = xF; f0 = eF0; f1 = eF1;
-              }
-            }
+        uint32_t entry = 0;
+        if (nv) walk(0);
+#pragma unroll 1
+        for (uint32_t round = 0; round < 64; ++round) {
+          const uint32_t pm = wave_excl_max(exit_abs);
+          const uint32_t ne = pm > lb ? pm - lb : 0u;  // where the chain enters this lane (>= nv: it jumps over it)
+          const bool changed = ne != entry && nv != 0;
+          if (!__any(changed)) break;
+          if (changed) {
+            entry = ne;
+            if (ne >= nv) { marks = 0; exit_abs = 0; }
+            else walk(ne);
           }
         }
-        if constexpr (kSub == 32) s_marks32[L] = (uint32_t)marks;
-        else reinterpret_cast<uint16_t*>(s_marks32)[L] = (uint16_t)marks;
-        // the position after a capped chain match is covered by it: park the full length there
-        if (f0) s_len8[sb + ((f0 >> 9) & 63u) + 1] = (uint8_t)((f0 & 511u) - 3);
-        if (f1) s_len8[sb + ((f1 >> 9) & 63u) + 1] = (uint8_t)((f1 & 511u) - 3);
       }
-      __syncthreads();
       stamp(3);
-      // ---- tokens and matches before each 64-position segment: every wave scans the 64 popcounts itself (one
-      //      segment per lane, results stay in registers) -- no single-wave phase, no barrier before the emit pass.
-      //      low half: tokens, high half: matches (a match takes two items) ----
-      uint32_t pre, rtotal;
+      // tokens (low half) and matches (high half: a match takes two items) before this lane, per wave, per round
+      const uint32_t cm = marks & T;                   // chain positions that are matches
+      const uint32_t mine = (uint32_t)__popc(marks) | ((uint32_t)__popc(cm) << 16);
+      const uint32_t incl = wave_incl_add(mine);
+      if (lane == 63) s_wtot[wave] = incl;
+      __syncthreads();
+      uint32_t wbase = 0, rtotal = 0;
       {
-        const uint64_t mk = s_marks[lane];
-        const uint32_t v = (uint32_t)__popcll(mk) | ((uint32_t)__popcll(mk & s_mm[lane]) << 16);
-        const uint32_t incl = wave_incl_scan(v, lane);
-        pre = incl - v;
-        rtotal = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        // tokens before each 1024-byte parse region: where the decoder's region lanes start (sub-index)
-        if (wave == 0 && (lane & (kRegion / 64 - 1)) == 0)
-          rtok_out[chunk * kSubRegions + rc * kRRegions + lane / (kRegion / 64)] = tot_tok + (pre & 0xFFFFu);
+        const uint4* w4 = reinterpret_cast<const uint4*>(s_wtot);
+#pragma unroll
+        for (uint32_t q = 0; q < K1_WAVES / 4; ++q) {
+          const uint4 v = w4[q];
+          const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (uint32_t k = 0; k < 4; ++k) {
+            rtotal += e[k];
+            wbase += (4 * q + k < wave) ? e[k] : 0u;
+          }
+        }
       }
+      // tokens before each 1024-byte sub-index region (two waves): where the decoder's region lanes start
+      if ((wave & (kSubBytes / kRegion - 1)) == 0 && lane == 0)
+        rtok_out[chunk * kSubRegions + rc * kRSubs + wave / (kSubBytes / kRegion)] = tot_tok + (wbase & 0xFFFFu);
       stamp(4);
 
-      // ---- emit: chain positions -> items (compact, chunk order) + histogram ----
-      // kIter consecutive segments per wave, loads batched
-      {
-        constexpr uint32_t kIter = kRSegs / K1_WAVES;
+      // ---- emit: the lane's chain positions -> items (compact, chunk order) + histogram ----
+      if (marks) {
+        const uint32_t before = wbase + incl - mine;
+        uint32_t idx = tot_items + (before & 0xFFFFu) + (before >> 16);
+        const uint4 D = *reinterpret_cast<const uint4*>(&s_dist[pb]);
+        const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + pb]);
+        const uint32_t dd[4] = {D.x, D.y, D.z, D.w};
+        // first token of a sub-index region (its position is always a token start)
+        uint32_t flag = (t & (kSubBytes / 8 - 1)) == 0 ? (kItemRegion | ((rc * kRSubs + pb / kSubBytes) << 8)) : 0u;
 #pragma unroll
-        for (uint32_t j0 = 0; j0 < kIter; j0 += kIter) {
-          uint64_t marks[kIter], mm[kIter];
-          uint32_t pr[kIter], b0[kIter], b1[kIter], dd[kIter], lit[kIter];
-#pragma unroll
-          for (uint32_t j = 0; j < kIter; ++j) {
-            const uint32_t sg = wave * kIter + j0 + j;
-            marks[j] = s_marks[sg];
-            mm[j] = s_mm[sg];
-            pr[j] = (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)sg);
-            const uint32_t rel = sg * 64 + lane;
-            b0[j] = s_len8[rel];
-            b1[j] = s_len8[rel + 1];
-            dd[j] = s_dist[rel];
-            lit[j] = s_bytes[kWindow + rel];
-          }
-#pragma unroll
-          for (uint32_t j = 0; j < kIter; ++j) {
-            if ((marks[j] >> lane) & 1) {
-              const uint64_t cm = marks[j] & mm[j];  // chain positions that are matches
-              const uint32_t idx = tot_items + (pr[j] & 0xFFFFu) + (pr[j] >> 16) +
-                                   (uint32_t)__popcll(marks[j] & lt_mask) + (uint32_t)__popcll(cm & lt_mask);
-              // first token of a parse region (its position is always a token start): only lane 0 of every 16th
-              // segment can be one -- the segment test is uniform, so 15 of 16 segments skip this entirely
-              const uint32_t sgq = wave * kIter + j0 + j;
-              uint32_t flag = 0;
-              if ((sgq & (kRegion / 64 - 1)) == 0 && lane == 0) flag = kItemRegion | ((rc * kRRegions + sgq / (kRegion / 64)) << 8);
-              if ((cm >> lane) & 1) {
-                uint32_t l3 = b0[j];                 // capped len-3 from the match phase
-                if (l3 == kCap - 3) l3 = b1[j];      // capped match: the walker left the full length next door
-                const uint32_t d1 = dd[j] - 1;
+        for (uint32_t k = 0; k < 8; ++k) {
+          if ((marks >> k) & 1) {
+            if ((cm >> k) & 1) {
+              uint32_t l3 = (N >> (4 * k)) & 15u;    // capped len-3 from the match phase
+              if (l3 == kCap - 3) l3 = cap_len - 3;  // capped match: the walk extended it
+              const uint32_t d1 = ((dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) - 1;
+              if (!(dbg & 2)) {
                 gi[idx] = (uint16_t)(kItemMatch | flag | l3);
                 gi[idx + 1] = (uint16_t)d1;
+              }
+              idx += 2;
+              if (!(dbg & 1)) {
                 uint32_t eb, ev;
                 atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
                 atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
-              } else {
-                gi[idx] = (uint16_t)(lit[j] | flag);
-                atomicAdd(&s_hist[lit[j]], 1u);
               }
+            } else {
+              const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
+              if (!(dbg & 2)) gi[idx] = (uint16_t)(b | flag);
+              idx += 1;
+              if (!(dbg & 1)) atomicAdd(&s_hist[b], 1u);
             }
+            flag = 0;
           }
         }
       }
@@ -533,7 +502,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         s_hist[idx] = (idx == 256) ? 1u : 0u;
       }
       if (t == 0) { ntok_out[chunk] = tot_tok; nitems_out[chunk] = tot_items; }
-      const uint32_t covered = (rc + 1) * kRRegions;  // regions of the rounds that ran
+      const uint32_t covered = (rc + 1) * kRSubs;  // sub-index regions of the rounds that ran
       if (t < kSubRegions && t >= covered) rtok_out[chunk * kSubRegions + t] = tot_tok;
       stamp(6);
     }
@@ -1270,15 +1239,19 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
     return e ? (uint32_t)atoi(e) : 0u;
   }();
   const uint32_t K1_LDS = sf::K1_LDS + extra;
+  static const uint32_t dbg = [] {
+    const char* e = getenv("SFH_K1_DBG");
+    return e ? (uint32_t)atoi(e) : 0u;
+  }();
   if (opt.strip_bytes == 0 || opt.strip_bytes % kChunk || opt.strip_bytes > kMaxStrip) return hipErrorInvalidValue;
   const uint32_t per = opt.strip_bytes / kChunk;
   const uint32_t nstrips = (nchunks + per - 1) / per;
   if (ws.stamps)
     hipLaunchKernelGGL(k_lz77<true>, dim3(nstrips), dim3(K1_THREADS), K1_LDS, s, src, n, opt.strip_bytes, ws.items,
-                       ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, ws.stamps);
+                       ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, ws.stamps, dbg);
   else
     hipLaunchKernelGGL(k_lz77<false>, dim3(nstrips), dim3(K1_THREADS), K1_LDS, s, src, n, opt.strip_bytes, ws.items,
-                       ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, (uint64_t*)nullptr);
+                       ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, (uint64_t*)nullptr, dbg);
   return hipGetLastError();
 }
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,

@@ -36,6 +36,7 @@ class Params(C.Structure):
         ("x_long_levels", C.c_uint32),
         ("x_long_near", C.c_uint32),
         ("x_rank_cap", C.c_uint32),
+        ("x_window", C.c_uint32),
     ]
 
 

@@ -11,13 +11,15 @@ import torch
 from starflate_amd import Compressor, _capi, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256 << 20
+bb = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 data = synth.gen_text_torch(n, seed=3, device="cuda")
 c = Compressor(0)
 for _ in range(2):
-    c.compress_tensor(data)
+    c.compress_tensor(data, block_bytes=bb)
 both = c.debug(_capi.DBG_STAMPS, n // 32768).astype(np.float64)
-st = both[0]
-names = ["stage", "match", "take", "walk", "segpre", "emit", "tail"]
+per = c.last_block_bytes() // 32768  # k_lz77 stamps one row per strip: scale to a 32 KiB chunk
+st = both[0][: (n // 32768 + per - 1) // per] / per
+names = ["stage", "match", "take", "walk", "segpre", "emit", "flush"]
 med = np.median(st[:, :7], axis=0)
 print("median cycles per chunk:", {k: int(v) for k, v in zip(names, med)}, "sum", int(med.sum()))
 print("shares:", {k: round(v / med.sum(), 3) for k, v in zip(names, med)})
