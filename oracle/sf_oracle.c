@@ -339,6 +339,7 @@ void sfo_default_params(sfo_params* p) {
   p->fast_skip = 1;
   p->far4_dist = 4096;
   p->strip_bytes = 0;
+  p->rank_bytes = 8;
 }
 
 static inline uint32_t load32(const uint8_t* p) {
@@ -507,11 +508,11 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
           uint32_t dist = i - cand[k];
           if (dist > (p->x_window ? p->x_window : SFO_WINDOW)) continue;
           uint32_t l = match_len(d, i, cand[k], cmplen);
-          if (p->x_rank_cap && l > p->x_rank_cap) l = p->x_rank_cap;
+          if (p->rank_bytes && l > p->rank_bytes) l = p->rank_bytes;
           if (l > best || (l == best && l && dist < bdist)) { best = l; bdist = dist; }
         }
       }
-      if (p->x_rank_cap && best == p->x_rank_cap) best = match_len(d, i, i - bdist, cmplen);
+      if (p->rank_bytes && best == p->rank_bytes) best = match_len(d, i, i - bdist, cmplen);
       /* a 4-byte match far away costs more bits than four literals (length code + 5-bit
        * distance code + up to 13 extra bits): drop it */
       if (p->far4_dist && best == 4 && bdist > p->far4_dist) best = 0;

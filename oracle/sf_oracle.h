@@ -102,9 +102,11 @@ typedef struct sfo_params {
                             precedes it.  Inside a strip the hash tables and a SFO_WINDOW-byte window slide
                             across the DEFLATE blocks (one per chunk_bytes), so matches reach into earlier
                             blocks of the same strip (legal: /root/reference/src/decompress.cpp:178) */
-  /* analysis knobs (tools/exp): levels of the long table that are tried (0 = depth), its near
-   * candidate, and a cap on the length that ranks candidates (the winner is then compared to `cap`) */
-  uint32_t x_long_levels, x_long_near, x_rank_cap, x_window;
+  /* analysis knobs (tools/exp): levels of the long table that are tried (0 = depth), its near candidate */
+  uint32_t x_long_levels, x_long_near;
+  uint32_t rank_bytes;   /* >0: a position's candidates are ranked by min(match length, rank_bytes) (ties: smallest
+                            distance); only the winner is then compared up to `cap` bytes.  0: all compared to `cap` */
+  uint32_t x_window;     /* analysis knob: 0 = SFO_WINDOW */
 } sfo_params;
 
 #define SFO_WINDOW 32768u

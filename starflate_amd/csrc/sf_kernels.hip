@@ -38,20 +38,6 @@ __device__ __forceinline__ uint32_t fixed_ll_len(uint32_t s) {
   return s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t u = __shfl_up(v, o, 64);
-    if (lane >= (uint32_t)o) v += u;
-  }
-  return v;
-}
-
 // Wave-wide scans on the DPP network (no LDS round trips).  Identity 0; a lane whose source does not exist keeps
 // the identity (`old` operand, bound_ctrl off).  row_shr:n = 0x110+n, row_bcast:15 = 0x142 (rows 1 and 3),
 // row_bcast:31 = 0x143 (rows 2 and 3), wave_shr:1 = 0x138.
@@ -77,6 +63,11 @@ __device__ __forceinline__ uint32_t wave_excl_max(uint32_t v) {
   v = max(v, dpp_from<0x143, 0xC>(v));
   return dpp_from<0x138, 0xF>(v);
 }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_add(v), 63);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) { return wave_incl_add(v); }
 
 // ---------------------------------------------------------------------------
 // K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per STRIP (block_bytes of
@@ -108,6 +99,7 @@ constexpr uint32_t kRound = 8192;                            // positions per ma
 constexpr uint32_t kRSubs = kRound / kSubBytes;              // sub-index regions per round
 constexpr uint32_t kRoundsPerChunk = kChunk / kRound;
 constexpr uint32_t kLook = 32;                               // bytes staged beyond the round (compare + alignment)
+constexpr uint32_t kRank = 8;                                // bytes that rank a position's candidates
 constexpr uint32_t kSkipSpan = 8192;                         // stored fast path: decided after this many positions of a chunk
 static_assert(kRound / 8 == K1_THREADS && kRegion == 8 * 64, "parse: eight positions per thread, one region per wave");
 static_assert(kSubBytes % kRegion == 0 && kRound % kSubBytes == 0, "sub-index regions are whole parse regions");
@@ -148,6 +140,17 @@ __device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, uint32_t a0, uint
   base = x0 ? 0u : base;
   const uint32_t f = (uint32_t)(__builtin_ffs((int)x) - 1);
   return min(base + (f >> 3), 16u);
+}
+
+// first mismatching byte (0..8) between the 8 bytes in a0,a1 and those at LDS byte address c
+__device__ __forceinline__ uint32_t cmp8(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t c) {
+  const uint32_t cw = c >> 2, csh = c & 3;
+  const uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2];
+  const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
+  const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
+  const uint32_t x = x0 ? x0 : x1, base = x0 ? 0u : 4u;
+  const uint32_t f = (uint32_t)(__builtin_ffs((int)x) - 1);  // 0xFFFFFFFF when all eight bytes are equal
+  return min(base + (f >> 3), 8u);
 }
 
 // 16-bit step code -> position relative to the epoch's first step: (sc-1)*1024 + t with
@@ -289,8 +292,9 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t c0 = entry_pos(f0) + K, c1 = entry_pos(f1) + K;
         const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = f1 != 0 && ad - c1 <= kWindow;
         const uint32_t q0 = ok0 ? c0 : ad, q1 = ok1 ? c1 : ad;
-        const uint32_t l0 = cmp16(s_data, a0, a1, a2, a3, q0);
-        const uint32_t l1 = cmp16(s_data, a0, a1, a2, a3, q1);
+        // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
+        const uint32_t l0 = cmp8(s_data, a0, a1, q0);
+        const uint32_t l1 = cmp8(s_data, a0, a1, q1);
         const uint32_t lf0 = ok0 ? l0 : 0u, lf1 = ok1 ? l1 : 0u;
         __syncthreads();  // every far read of this step precedes every insertion of this step
         {
@@ -304,16 +308,22 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t nc = entry_pos(nv) + K;
         const bool okn = nv != 0 && nc < ad;
         const uint32_t qnr = okn ? nc : ad;
-        const uint32_t ln = cmp16(s_data, a0, a1, a2, a3, qnr);
+        const uint32_t ln = cmp8(s_data, a0, a1, qnr);
         const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
         uint32_t maxlen = (rel < qn) ? (qn - rel < kCap ? qn - rel : kCap) : 0u;
         maxlen = rend - rel < maxlen ? rend - rel : maxlen;
         // longest wins; ties go to the smaller distance: near, then the newer far level
         uint32_t best = okn ? (ln < maxlen ? ln : maxlen) : 0u;
-        uint32_t bd = ad - qnr;
+        uint32_t bq = qnr;
         const uint32_t m0 = lf0 < maxlen ? lf0 : maxlen, m1 = lf1 < maxlen ? lf1 : maxlen;
-        if (m0 > best) { best = m0; bd = ad - q0; }
-        if (m1 > best) { best = m1; bd = ad - q1; }
+        if (m0 > best) { best = m0; bq = q0; }
+        if (m1 > best) { best = m1; bq = q1; }
+        const uint32_t bd = ad - bq;
+        {
+          // the winner's next eight bytes (they only count when its first kRank all matched)
+          const uint32_t lx = kRank + cmp8(s_data, a2, a3, bq + kRank);
+          best = best == kRank ? (lx < maxlen ? lx : maxlen) : best;
+        }
         // a 4-byte match farther than kFar4 costs more bits than four literals: drop it
         const bool ok = best >= kMinMatch && (p + kMinMatch <= n) && !(best == 4 && bd > kFar4);
         s_dist[rel] = (uint16_t)(ok ? bd : 0u);

@@ -35,7 +35,7 @@ class Params(C.Structure):
         ("strip_bytes", C.c_uint32),
         ("x_long_levels", C.c_uint32),
         ("x_long_near", C.c_uint32),
-        ("x_rank_cap", C.c_uint32),
+        ("rank_bytes", C.c_uint32),
         ("x_window", C.c_uint32),
     ]
 
