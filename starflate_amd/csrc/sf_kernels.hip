@@ -381,22 +381,22 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       {
         const uint32_t lb = 8 * lane;                  // the lane's first position, region-relative
         const uint32_t rend = (pb & ~(kRegion - 1)) + kRegion < qn ? (pb & ~(kRegion - 1)) + kRegion : qn;  // region end, round-relative
-        // follow the chain from local offset e (< nv)
+        // follow the chain from local offset e (< nv): at most two matches fit into eight positions, so two
+        // predicated passes (literals up to a taken match, the match) cover the lane; straight-line code but for
+        // the rare extension of a capped match
         auto walk = [&](uint32_t e) {
           uint32_t pos = e, mk = 0;
-#pragma unroll 1
-          while (pos < nv) {
-            const uint32_t m = T >> pos;
-            if (m == 0) {                              // literals to the lane's end
-              mk |= ((1u << nv) - 1u) & ~((1u << pos) - 1u);
-              pos = 8;
-              break;
-            }
-            const uint32_t k = (uint32_t)__builtin_ctz(m);
-            mk |= ((2u << k) - 1u) << pos;             // literals, then the match position
-            const uint32_t mp = pos + k;
+#pragma unroll
+          for (uint32_t it = 0; it < 2; ++it) {
+            const bool act = pos < nv;
+            const uint32_t m = act ? (T >> (pos & 7)) : 0u;
+            const bool hit = m != 0;
+            const uint32_t k = hit ? (uint32_t)__builtin_ctz(m) : 0u;
+            const uint32_t tail = ((1u << nv) - 1u) & ~((1u << (pos & 7)) - 1u);  // literals to the lane's end
+            mk |= hit ? (((2u << k) - 1u) << (pos & 7)) : (act ? tail : 0u);   // literals, then the match position
+            const uint32_t mp = (pos + k) & 7;
             uint32_t len = ((N >> (4 * mp)) & 15u) + 3;
-            if (len == kCap) {                         // capped at match time: extend (once per position)
+            if (hit && len == kCap) {                    // capped at match time: extend (once per position)
               if (cap_mp != mp) {
                 const uint32_t xpa = kWindow + pb + mp, xca = xpa - s_dist[pb + mp];
                 const uint32_t xmax = rend - (pb + mp) < 258u ? rend - (pb + mp) : 258u;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               }
               len = cap_len;
             }
-            pos = mp + len;
+            pos = hit ? mp + len : (act ? 8u : pos);
           }
           marks = mk;
           exit_abs = lb + (pos > 8 ? pos : 8u);
@@ -429,6 +429,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           const uint32_t ne = pm > lb ? pm - lb : 0u;  // where the chain enters this lane (>= nv: it jumps over it)
           const bool changed = ne != entry && nv != 0;
           if (!__any(changed)) break;
+          if constexpr (STAMPS) st_acc[7] += 1;  // diagnostic: reconcile rounds of wave 0
           if (changed) {
             entry = ne;
             if (ne >= nv) { marks = 0; exit_abs = 0; }
@@ -474,26 +475,21 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
           if ((marks >> k) & 1) {
-            if ((cm >> k) & 1) {
-              uint32_t l3 = (N >> (4 * k)) & 15u;    // capped len-3 from the match phase
-              if (l3 == kCap - 3) l3 = cap_len - 3;  // capped match: the walk extended it
-              const uint32_t d1 = ((dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) - 1;
-              if (!(dbg & 2)) {
-                gi[idx] = (uint16_t)(kItemMatch | flag | l3);
-                gi[idx + 1] = (uint16_t)d1;
-              }
-              idx += 2;
-              if (!(dbg & 1)) {
-                uint32_t eb, ev;
-                atomicAdd(&s_hist[len_symbol(l3, eb, ev)], 1u);
-                atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
-              }
-            } else {
-              const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
-              if (!(dbg & 2)) gi[idx] = (uint16_t)(b | flag);
-              idx += 1;
-              if (!(dbg & 1)) atomicAdd(&s_hist[b], 1u);
+            // one store and one histogram update serve both kinds of token; a match adds its distance half
+            const bool isM = (cm >> k) & 1;
+            uint32_t l3 = (N >> (4 * k)) & 15u;      // capped len-3 from the match phase
+            if (l3 == kCap - 3) l3 = cap_len - 3;    // capped match: the walk extended it
+            const uint32_t d1 = ((dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) - 1;
+            const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
+            uint32_t eb, ev;
+            const uint32_t sym = isM ? len_symbol(l3, eb, ev) : b;
+            if (!(dbg & 2)) gi[idx] = (uint16_t)((isM ? (kItemMatch | l3) : b) | flag);
+            if (!(dbg & 1)) atomicAdd(&s_hist[sym], 1u);
+            if (isM) {
+              if (!(dbg & 2)) gi[idx + 1] = (uint16_t)d1;
+              if (!(dbg & 1)) atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
             }
+            idx += isM ? 2u : 1u;
             flag = 0;
           }
         }

@@ -22,6 +22,7 @@ st = both[0][: (n // 32768 + per - 1) // per] / per
 names = ["stage", "match", "take", "walk", "segpre", "emit", "flush"]
 med = np.median(st[:, :7], axis=0)
 print("median cycles per chunk:", {k: int(v) for k, v in zip(names, med)}, "sum", int(med.sum()))
+print("reconcile rounds per wave-round (wave 0):", round(float(np.mean(st[:, 7])) * per / (per * 4), 2), "max", float(np.max(both[0][: st.shape[0], 7])) / (per * 4))
 print("shares:", {k: round(v / med.sum(), 3) for k, v in zip(names, med)})
 k2 = both[1]
 names2 = ["load", "ll_lengths", "d_lengths", "costs+rle", "cl_code", "header", "codes+store"]
