@@ -1,21 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X DEFLATE compressor.
 
-Workload (BASELINE.json configs[2]): 1 GiB synthetic enwik-like text per GPU,
-32,768 independent 32 KiB DEFLATE blocks, input resident in HBM when the timed
-region starts.  A "step" = one pass of the whole hot path (k_lz77 -> k_plan ->
-k_scan -> k_emit) over that input; with N > 1 every rank compresses its own 1 GiB
-shard (weak scaling) and the byte-aligned streams are concatenated on rank 0 over
-RCCL.  For N > 1 the sharding is block-cyclic in --rounds rounds (global piece g = k*N + rank),
-so the gather of round k (sizes all_gather + one point-to-point send per rank, straight to
-the final offset) overlaps the compression of round k+1 (starflate_amd/multigpu.py).
+Workload (BASELINE.json configs[2]): 1 GiB synthetic enwik-like text per GPU, compressed in strips of
+sfh_options.block_bytes (default 256 KiB: a 32 KiB window sliding over eight 32 KiB DEFLATE blocks), input
+resident in HBM when the timed region starts.  A "step" = one pass of the whole hot path (k_lz77 -> k_plan ->
+k_scan -> k_emit) over that input; with N > 1 every rank compresses its own 1 GiB (weak scaling) and the
+byte-aligned streams are concatenated on rank 0 over RCCL.  For N > 1 the sharding is block-cyclic in --rounds
+rounds (global piece g = k*N + rank), so the gather of round k (sizes all_gather + one point-to-point send per
+rank, straight to the final offset) overlaps the compression of round k+1 (starflate_amd/multigpu.py).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--bytes B] [--workload text|random|mixed]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_lz77),
-its launch time measured live with HIP events on the launch stream; `cpu_baseline`
-times the oracle's restatement of the reference decompress() on this host.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_lz77), its launch time measured live
+with HIP events on the launch stream; `cpu_baseline` times the oracle's restatement of the reference
+decompress() on this host; `e2e` is the same call from pinned host buffers (H2D + kernels + D2H); `workloads`
+carries the other two BASELINE workloads at a smaller size (N = 1 only).
 """
 import argparse
 import json
@@ -28,6 +28,108 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SEG = 32768
+
+
+def make_input(workload, n, rank, dev):
+    """The bench bytes: generated on the device (text, random) or on the host (mixed)."""
+    import torch
+
+    from starflate_amd import synth
+
+    if workload == "text":
+        return synth.gen_text_torch(n, seed=3 + 17 * rank, device=dev), f"{n / 2**30:g} GiB synthetic enwik-like text per GPU (gen_text_torch seed 3)"
+    if workload == "random":
+        g = torch.Generator(device=dev)
+        g.manual_seed(5 + rank)
+        return (torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=g),
+                f"{n / 2**30:g} GiB high-entropy bytes per GPU (stored-block path)")
+    return torch.from_numpy(synth.gen_mixed(n, seed=4 + rank)).to(dev), f"{n / 2**30:g} GiB mixed Silesia-like stripes per GPU"
+
+
+def run_steps(step, fence, steps, warmup):
+    """W untimed warm-up steps, then exactly K steps between two fences (barrier + device synchronise)."""
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return time.perf_counter() - t0
+
+
+def pipelined_step(compress_fn, pieces, gathered, container="raw", checksum_fn=None, group=None):
+    """One N > 1 step: block-cyclic rounds with the gather overlapped (what the driver's --gpus N runs)."""
+    from starflate_amd import multigpu
+
+    return multigpu.compress_pipelined(compress_fn, pieces, out=gathered, container=container, checksum_fn=checksum_fn, group=group)
+
+
+def verify_pieces(pieces, streams, sizes, wbits):
+    """Every rank inflates its own piece streams with zlib (a non-final piece is still inflatable)."""
+    ok, crcs = True, []
+    for k, piece in enumerate(pieces):
+        host_piece = piece.cpu().numpy().tobytes()
+        stream = streams[k][: sizes[k]].cpu().numpy().tobytes()
+        ok = ok and zlib.decompressobj(wbits).decompress(stream) == host_piece
+        crcs.append(zlib.crc32(host_piece))
+    return ok, crcs
+
+
+def verify_concatenation(whole_stream, wbits, total_in, piece_bytes, crcs_by_rank):
+    """Rank 0: the concatenation is ONE valid stream of all pieces in the order g = k*N + rank."""
+    whole = zlib.decompress(whole_stream, wbits)
+    world, K = len(crcs_by_rank), len(crcs_by_rank[0])
+    return len(whole) == total_in and all(
+        zlib.crc32(whole[(k * world + r) * piece_bytes:(k * world + r + 1) * piece_bytes]) == int(crcs_by_rank[r][k])
+        for k in range(K) for r in range(world))
+
+
+def zlib6_size(host_bytes):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    return len(co.compress(host_bytes)) + len(co.flush())
+
+
+def traffic_from_profile(kernel):
+    """HBM bytes per launch of `kernel` from the last committed PMC profile -- NOT measured in this run."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        e = d.get(kernel)
+        if not e:
+            return None
+        return {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "source": "profiles/pmc_traffic.json",
+                "profiled_at": d.get("_meta", {}).get("commit", "see profiles/"), "note": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of an earlier run; not collected live"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def secondary_workload(comp, workload, n, dev, block_bytes, steps=3):
+    """MiB/s + ratio of another BASELINE workload (configs[3] / [4] shapes) on this GPU."""
+    import torch
+
+    data, wl = make_input(workload, n, 0, dev)
+    out = torch.empty(comp.compress_bound(n), dtype=torch.uint8, device=dev)
+    nb = 0
+    for _ in range(2):
+        _, nb = comp.compress_tensor(data, out=out, block_bytes=block_bytes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, nb = comp.compress_tensor(data, out=out, block_bytes=block_bytes)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    zs = min(n, 32 << 20)
+    zl = zlib6_size(data[:zs].cpu().numpy().tobytes())
+    from starflate_amd import _capi
+    offs = comp.debug(_capi.DBG_OFFSETS, (n + SEG - 1) // SEG)
+    ours = int(offs[zs // SEG]) if zs < n else nb
+    ok = zlib.decompress(out[:nb].cpu().numpy().tobytes(), -15) == data.cpu().numpy().tobytes()
+    return {"workload": wl, "value": round(n / dt / 2**20, 1), "unit": "MiB/s", "ms": round(dt * 1e3, 3), "ratio": round(n / nb, 4),
+            "ratio_vs_zlib6": round((zs / ours) / (zs / zl), 4), "roundtrip_ok": ok,
+            "kernel_ms": {k: round(v, 4) for k, v in comp.stage_ms().items()}}
 
 
 def main():
@@ -37,14 +139,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=1 << 30, help="input bytes per GPU")
     ap.add_argument("--workload", default="text", choices=["text", "random", "mixed"])
+    ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default, 256 KiB at this size)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the e2e leg and the other two workloads")
     ap.add_argument("--cpu-sample-bytes", type=int, default=512 << 20)
+    ap.add_argument("--secondary-bytes", type=int, default=256 << 20)
     ap.add_argument("--rounds", type=int, default=4, help="N > 1: block-cyclic rounds per rank (gather/compute overlap)")
     ap.add_argument("--container", default="raw", choices=["raw", "zlib", "gzip"],
                     help="wrap the stream (RFC 1950 / 1952); the checksum kernels are then inside the timed step")
     ap.add_argument("--no-decompress", action="store_true", help="skip the GPU decompress leg (N = 1 only)")
-    ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N > 1 code path (RCCL group, rounds, gather) even with one rank")
     args = ap.parse_args()
@@ -53,7 +157,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from starflate_amd import Compressor, multigpu, synth
+    from starflate_amd import Compressor, _capi
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -70,50 +174,45 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.bytes
-    if args.workload == "text":
-        data = synth.gen_text_torch(n, seed=3 + 17 * rank, device=dev)
-        wl = f"{n / 2**30:g} GiB synthetic enwik-like text per GPU (gen_text_torch seed 3), 32 KiB blocks"
-    elif args.workload == "random":
-        g = torch.Generator(device=dev)
-        g.manual_seed(5 + rank)
-        data = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=g)
-        wl = f"{n / 2**30:g} GiB high-entropy bytes per GPU (stored-block path)"
-    else:
-        data = torch.from_numpy(synth.gen_mixed(n, seed=4 + rank)).to(dev)
-        wl = f"{n / 2**30:g} GiB mixed Silesia-like stripes per GPU"
-
+    data, wl = make_input(args.workload, n, rank, dev)
     comp = Compressor(local_rank)
     comp.set_profiling(True)
     K = max(1, args.rounds) if multi else 1
-    if n % (K * 32768):
-        raise SystemExit("--bytes must be a multiple of rounds * 32768")
+    # every piece is compressed with the strip size of the whole shard, so rounds do not change the stream's ratio
+    bb = _capi.resolve_block_bytes(args.block_bytes, n)
+    if n % (K * bb):
+        raise SystemExit("--bytes must be a multiple of rounds * block_bytes")
     pieces = list(data.chunk(K))
     bound = comp.compress_bound(n // K)
     scratch = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(K)]
-    gathered = torch.empty(bound * K * world + 32, dtype=torch.uint8, device=dev) if (multi and rank == 0) else None
+    size_dev = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(K)]
+    # rank 0 receives every rank's streams of one step: sized by the bound (what compress_pipelined checks)
+    gathered = torch.empty(bound * K * world + 64, dtype=torch.uint8, device=dev) if (multi and rank == 0) else None
     wbits = {"raw": -15, "zlib": 15, "gzip": 31}[args.container]
     stage_acc = {}
     result = {}
 
     def step():
         ms = {}
-        sizes = [0] * K
 
-        def compress_fn(piece, final, k):
-            out, nb = comp.compress_tensor(piece, out=scratch[k], final_stream=final,
-                                           container="raw" if multi else args.container, block_bytes=args.block_bytes)
-            sizes[k] = nb
+        def account():
             for name, v in comp.stage_ms().items():
                 ms[name] = ms.get(name, 0.0) + v
-            return out, nb
 
         if not multi:
-            out, total = compress_fn(data, True, 0)
+            out, total = comp.compress_tensor(data, out=scratch[0], container=args.container, block_bytes=bb)
+            account()
+            result["sizes"] = [total]
         else:
-            out, total = multigpu.compress_pipelined(
-                compress_fn, pieces, out=gathered, container=args.container,
+            def compress_fn(piece, final, k):  # enqueue only: the size stays on the device until the gather reads it
+                comp.compress_tensor_async(piece, scratch[k], size_dev[k], final_stream=final, block_bytes=bb)
+                return scratch[k], size_dev[k]
+
+            out, total = pipelined_step(
+                compress_fn, pieces, gathered, container=args.container,
                 checksum_fn=(lambda piece, k: comp.checksum_tensor(piece, args.container)) if args.container != "raw" else None)
-        result["sizes"], result["local_n"] = sizes, sum(sizes)
+            result["sizes"] = [int(s.item()) for s in size_dev]
+        result["local_n"] = sum(result["sizes"])
         result["out"], result["total"] = out, total
         for name, v in ms.items():
             stage_acc.setdefault(name, []).append(v)
@@ -126,12 +225,7 @@ def main():
     for _ in range(args.warmup):
         step()
     stage_acc.clear()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt = run_steps(step, fence, args.steps, 0)
     if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -143,18 +237,10 @@ def main():
     total_out = int(result["total"])
     local_n = int(result["local_n"])
 
-    # ---- verification (untimed): every rank inflates its own shard stream with zlib ----
+    # ---- verification (untimed): every rank inflates its own piece streams with zlib ----
     ok = None
     if not args.no_verify:
-        ok = True
-        my_crcs = []
-        for k in range(K):
-            host_piece = pieces[k].cpu().numpy().tobytes()
-            stream = scratch[k][: result["sizes"][k]].cpu().numpy().tobytes()
-            back = zlib.decompressobj(-15 if multi else wbits).decompress(stream)  # a non-final piece is still inflatable
-            ok = ok and back == host_piece
-            my_crcs.append(zlib.crc32(host_piece))
-            del back, host_piece
+        ok, my_crcs = verify_pieces(pieces, scratch, result["sizes"], -15 if multi else wbits)
         if multi:
             flag = torch.tensor([1 if ok else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -162,13 +248,9 @@ def main():
             crc = torch.tensor(my_crcs, dtype=torch.int64, device=dev)
             crcs = [torch.zeros(K, dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(crcs, crc)
-            if rank == 0:  # the concatenation is ONE valid stream of all pieces in the order g = k*N + rank
-                whole = zlib.decompress(result["out"][:total_out].cpu().numpy().tobytes(), wbits)
-                pb = n // K
-                ok = ok and len(whole) == total_in and all(
-                    zlib.crc32(whole[(k * world + r) * pb:(k * world + r + 1) * pb]) == int(crcs[r][k].item())
-                    for k in range(K) for r in range(world))
-                del whole
+            if rank == 0:
+                ok = ok and verify_concatenation(result["out"][:total_out].cpu().numpy().tobytes(), wbits, total_in, n // K,
+                                                 [c.tolist() for c in crcs])
 
     if rank != 0:
         dist.barrier()
@@ -176,42 +258,35 @@ def main():
         return
 
     # ---- ratio vs zlib -6 on a bounded sample of the same bytes ----
-    last = pieces[-1]  # the piece of the last compress call (its chunk offsets are still in the ctx)
+    stage_ms = {k: sum(v) / len(v) for k, v in stage_acc.items()}
+    if multi:  # the async entry point keeps no per-call events: time one synchronous call of the first piece
+        comp.compress_tensor(pieces[0], out=scratch[0], block_bytes=bb, final_stream=False)
+        stage_ms = {k: v * K for k, v in comp.stage_ms().items()}
+        last, last_n = pieces[0], None
+    else:
+        last, last_n = pieces[-1], result["sizes"][-1]
     zs = min(last.numel(), 64 << 20)
     host_sample = last[:zs].cpu().numpy().tobytes()
     tz = time.perf_counter()
-    co = zlib.compressobj(6, zlib.DEFLATED, -15)
-    zlen = len(co.compress(host_sample)) + len(co.flush())
+    zlen = zlib6_size(host_sample)
     tz = time.perf_counter() - tz
-    # our bytes for the same prefix: chunk offsets of the last timed call (no extra launch)
-    from starflate_amd import _capi
-    nchunks = (last.numel() + 32767) // 32768
-    offs = comp.debug(_capi.DBG_OFFSETS, nchunks)
-    ours_sample = int(offs[zs // 32768]) if zs < last.numel() else result["sizes"][-1]
+    nchunks = (last.numel() + SEG - 1) // SEG
+    offs = comp.debug(_capi.DBG_OFFSETS, nchunks)  # chunk offsets of the last call (no extra launch)
+    ours_sample = int(offs[zs // SEG]) if zs < last.numel() else last_n
     ratio = n / max(local_n, 1)
     ratio_zlib6 = zs / zlen
     ratio_ours_sample = zs / ours_sample
 
     # ---- roofline of the dominant kernel ----
-    stage_ms = {k: sum(v) / len(v) for k, v in stage_acc.items()}
     dom = max(stage_ms, key=stage_ms.get)
     alg_bytes = n + local_n  # read N + write C per launch of the path
     achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            with open(pmc_path) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_from_profile": traffic_from_profile(dom),
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
                 "read_frac": round(n / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     try:  # what hipDeviceProp_t implies; `peak` above stays the guide's figure
-        from starflate_amd import _capi as _c
-        dp = _c.device_props(local_rank)
+        dp = _capi.device_props(local_rank)
         roofline["device"] = {"name": dp["name"], "arch": dp["arch"], "compute_units": dp["compute_units"],
                               "memory_clock_khz": dp["memory_clock_khz"], "memory_bus_bits": dp["memory_bus_bits"],
                               # HBM3E moves 8 Gb/s per pin = 4 transfers per reported 2 GHz memory clock
@@ -223,7 +298,7 @@ def main():
     # ---- GPU decompress of the stream just made: the reference's own function, on the GPU ----
     decomp = None
     if not multi and not args.no_decompress:
-        out_t, nb = comp.compress_tensor(data, out=scratch[0], container=args.container)
+        out_t, nb = comp.compress_tensor(data, out=scratch[0], container=args.container, block_bytes=bb)
         index = comp.last_index(device=dev)
         subindex = comp.last_subindex(device=dev)
         stream_t = out_t[:nb].clone()
@@ -231,20 +306,44 @@ def main():
         decomp = {}
         for label, sub in (("sub_indexed", subindex), ("segment_indexed", None)):
             back.zero_()
-            comp.decompress_tensor(stream_t, index, n, out=back, subindex=sub)  # warm-up
+            comp.decompress_tensor(stream_t, index, n, out=back, subindex=sub, block_bytes=bb)  # warm-up
             torch.cuda.synchronize()
             reps = 3
             td = time.perf_counter()
             for _ in range(reps):
-                _, dstatus = comp.decompress_tensor(stream_t, index, n, out=back, subindex=sub)
+                _, dstatus = comp.decompress_tensor(stream_t, index, n, out=back, subindex=sub, block_bytes=bb)
             torch.cuda.synchronize()
             td = (time.perf_counter() - td) / reps
             decomp[label] = {"value": round(n / td / 2**20, 1), "unit": "MiB/s of output", "ms": round(td * 1e3, 3),
                              "status": dstatus, "equal_to_input": bool(torch.equal(back, data)),
                              "kernel_ms": {k: round(v, 4) for k, v in comp.inflate_ms().items()}}
-        decomp["note"] = ("sub_indexed: chunk offsets + 32 region entries per chunk (sfh_copy_index, sfh_copy_subindex), "
-                          "32 lanes per segment; segment_indexed: chunk offsets only, one lane per segment (any indexed stream)")
+        decomp["note"] = ("sub_indexed: chunk offsets + 32 entries per chunk (sfh_copy_index, sfh_copy_subindex), 32 lanes per "
+                          "segment; segment_indexed: chunk offsets only, one lane per segment (any indexed stream); "
+                          f"byte copies strip by strip (block_bytes {bb})")
         del back, stream_t
+
+    # ---- end to end from pinned host memory (H2D + kernels + D2H), and the other two workloads ----
+    e2e, others = None, None
+    if not multi and not args.no_secondary:
+        hin = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        hin.copy_(data)
+        hout = torch.empty(comp.compress_bound(n), dtype=torch.uint8, pin_memory=True)
+        src_np, dst_np = hin.numpy(), hout.numpy()
+        import ctypes as C
+        opt = _capi.make_options(container=args.container, block_bytes=bb)
+        out_n = C.c_size_t(0)
+        call = lambda: comp._check(comp._lib.sfh_compress(comp._h, src_np.ctypes.data, n, dst_np.ctypes.data, dst_np.size,  # noqa: E731
+                                                          C.byref(out_n), C.byref(opt)))
+        call()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            call()
+        te = (time.perf_counter() - t0) / reps
+        e2e = {"value": round(n / te / 2**20, 1), "unit": "MiB/s", "ms": round(te * 1e3, 3), "bytes_out": int(out_n.value),
+               "note": "sfh_compress from/to pinned host buffers: H2D of the input, the four kernels, D2H of the stream, synchronous"}
+        del hin, hout
+        others = {w: secondary_workload(comp, w, args.secondary_bytes, dev, 0) for w in ("text", "mixed", "random") if w != args.workload}
 
     # ---- CPU baseline: oracle restatement of the reference decompress(), 1 thread ----
     cpu = None
@@ -254,7 +353,7 @@ def main():
 
         cs = min(n, args.cpu_sample_bytes)
         sample = data[:cs].clone()
-        sout, sn = comp.compress_tensor(sample)
+        sout, sn = comp.compress_tensor(sample, block_bytes=bb)
         stream = sout[:sn].cpu().numpy()
         tc = time.perf_counter()
         st, w, back = O.decompress(stream, cs)
@@ -270,14 +369,9 @@ def main():
 
         nthreads = min(16, os.cpu_count() or 1)
         sl = [host_sample[i:i + (1 << 20)] for i in range(0, zs, 1 << 20)]
-
-        def _z(b):
-            co = zlib.compressobj(6, zlib.DEFLATED, -15)
-            return len(co.compress(b)) + len(co.flush())
-
         tp = time.perf_counter()
         with ThreadPoolExecutor(nthreads) as ex:
-            zpar = sum(ex.map(_z, sl))
+            zpar = sum(ex.map(zlib6_size, sl))
         tp = time.perf_counter() - tp
         cpu["zlib6_compress_MiBps_block_parallel"] = {"value": round(zs / tp / 2**20, 1), "threads": nthreads,
                                                       "ratio": round(zs / zpar, 4)}
@@ -288,13 +382,14 @@ def main():
         "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": wl, "block_bytes": 32768, "strategy": "auto", "container": args.container,
+        "config": {"workload": wl, "block_bytes": bb, "deflate_block_bytes": SEG, "window_bytes": 32768, "strategy": "auto",
+                   "container": args.container,
                    "parallelism": f"shard{world}" + (f" block-cyclic x{K}, gather overlapped" if multi else "")},
         "ratio": round(ratio, 4), "ratio_zlib6": round(ratio_zlib6, 4),
         "ratio_vs_zlib6": round(ratio_ours_sample / ratio_zlib6, 4),
         "compressed_bytes": total_out, "roundtrip_ok": ok,
         "kernel_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "kernels_total_ms": round(kern_total_ms, 4),
-        "roofline": roofline, "cpu_baseline": cpu, "decompress": decomp,
+        "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "workloads": others, "decompress": decomp,
     }
     print(json.dumps(line), flush=True)
     if multi:

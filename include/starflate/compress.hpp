@@ -31,20 +31,24 @@ enum class BlockStrategy : std::uint8_t { Auto, Stored, Fixed, Dynamic };
 struct compress_options {
   BlockStrategy strategy{BlockStrategy::Auto};
   bool final_stream{true};  // false: byte-aligned, non-final stream (a shard that is not the last)
-  bool lazy{true};
+  std::uint8_t lazy{3};     // 0..3 positions of look-ahead of the lazy match rule (sfh_options.lazy)
   bool stored_fast_path{true};  // skip the search of a chunk whose first 8 KiB are (almost) all literals
   Container container{Container::Raw};  // Zlib / Gzip: wrapper + GPU-computed Adler-32 / CRC-32 (needs final_stream)
   int device{0};
+  std::uint32_t block_bytes{0};  // bytes coded independently of what precedes them: a multiple of 32768, 0 = default
+                                 // (sfh_options.block_bytes); larger compresses better, 32768 = independent DEFLATE blocks
 };
 
-inline auto compress_bound(std::size_t n) -> std::size_t { return sfh_compress_bound(n); }
+inline auto compress_bound(std::size_t n, std::uint32_t block_bytes = 0) -> std::size_t { return sfh_compress_bound(n, block_bytes); }
 
 /// What makes a stream of this library decodable in parallel (on the GPU): the first stream byte of every
-/// 32 KiB segment plus the end of the last one, and optionally, per segment, 32 x {bit offset of a parse region's
-/// first token code, tokens before it}.  Side information: the stream itself is plain DEFLATE.
+/// 32 KiB segment plus the end of the last one, the strip size (no match reaches before its strip), and
+/// optionally, per segment, 32 x {bit offset of the first token code of every 1024 bytes, tokens before it}.
+/// Side information: the stream itself is plain DEFLATE.
 struct stream_index {
   std::vector<std::uint64_t> offsets;  // segments + 1
   std::vector<std::uint32_t> regions;  // segments * 64, or empty
+  std::uint32_t block_bytes{SFH_SEGMENT_BYTES};  // strip size the stream was written with
   [[nodiscard]] auto segments() const -> std::size_t { return offsets.empty() ? 0 : offsets.size() - 1; }
 };
 
@@ -64,9 +68,10 @@ inline auto to_c(const compress_options& o) -> sfh_options {
   sfh_default_options(&c);
   c.strategy = static_cast<std::uint32_t>(o.strategy);
   c.final_stream = o.final_stream ? 1U : 0U;
-  c.lazy = o.lazy ? 3U : 0U;
+  c.lazy = o.lazy;
   c.no_stored_fast_path = o.stored_fast_path ? 0U : 1U;
   c.container = static_cast<std::uint32_t>(o.container);
+  c.block_bytes = o.block_bytes;
   return c;
 }
 }  // namespace detail
@@ -102,6 +107,7 @@ class compressor {
     const std::size_t n = sfh_index_entries(ctx_);
     if (n == 0) return compat::unexpected{CompressStatus::InvalidArgument};
     ix.offsets.resize(n);
+    ix.block_bytes = sfh_last_block_bytes(ctx_);
     int rc = sfh_copy_index(ctx_, ix.offsets.data(), n, 0, nullptr);
     if (rc == SFH_OK && with_regions) {
       ix.regions.resize((n - 1) * SFH_SUBINDEX_WORDS);
@@ -118,7 +124,7 @@ class compressor {
       return DecompressStatus::Error;
     std::uint32_t st = 0;
     const int rc = sfh_decompress(ctx_, src.data(), src.size(), ix.offsets.data(), ix.regions.empty() ? nullptr : ix.regions.data(),
-                                  ix.segments(), dst.data(), dst.size(), &st);
+                                  ix.segments(), dst.data(), dst.size(), ix.block_bytes, &st);
     if (rc != SFH_OK || st > 7) return DecompressStatus::Error;
     return static_cast<DecompressStatus>(st);
   }
@@ -150,11 +156,23 @@ inline auto compress(std::span<compressor* const> gpus, std::span<const std::byt
   return n;
 }
 
+namespace detail {
+/// The calling thread's context for `device`, created on first use and kept for the thread's lifetime: the free
+/// function below does not pay for a stream, events and device scratch on every call.
+inline auto thread_compressor(int device) -> compressor& {
+  thread_local std::vector<std::pair<int, compressor>> cache;
+  for (auto& e : cache)
+    if (e.first == device) return e.second;
+  cache.emplace_back(device, compressor{device});
+  return cache.back().second;
+}
+}  // namespace detail
+
 /// Compresses `src` into `dst` (dst.size() >= compress_bound(src.size())); returns the stream size.
+/// Re-entrant like the reference's decompress() (src/decompress.hpp:63-71): each thread keeps its own context per device.
 inline auto compress(std::span<const std::byte> src, std::span<std::byte> dst, const compress_options& opt = {})
     -> compat::expected<std::size_t, CompressStatus> {
-  compressor c{opt.device};
-  return c.compress(src, dst, opt);
+  return detail::thread_compressor(opt.device).compress(src, dst, opt);
 }
 
 }  // namespace starflate

@@ -97,8 +97,11 @@ inline auto decompress(std::span<const std::byte> src, std::span<std::byte> dst,
       const auto le32 = [&](std::size_t k) { return u8(tr[k]) | (u8(tr[k + 1]) << 8U) | (u8(tr[k + 2]) << 16U) | (u8(tr[k + 3]) << 24U); };
       const std::uint32_t isize = le32(4);
       if (dst.size() < isize) return DecompressStatus::DstTooSmall;
-      const auto st = decompress(src.subspan(p, end - p), dst);
+      // the body must produce exactly ISIZE bytes: a longer one runs into DstTooSmall here, never past dst.first(isize)
+      std::ptrdiff_t written = 0;
+      const auto st = decompress(src.subspan(p, end - p), dst.first(isize), &written);
       if (st != DecompressStatus::Success) return st;
+      if (static_cast<std::uint64_t>(written) != isize) return DecompressStatus::Error;
       return crc32(dst.first(isize)) == le32(0) ? DecompressStatus::Success : DecompressStatus::Error;
     }
   }

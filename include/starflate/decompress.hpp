@@ -132,6 +132,16 @@ auto inflate_block(huffman::bit_span& bits, std::span<std::byte> dst, std::ptrdi
   }
 }
 
+/// Code lengths that claim more code space than there is (Kraft sum > 1) do not describe a prefix code: the
+/// reference builds a table of wrapped codes from them (an assert in debug builds, huffman/src/code.hpp), this
+/// decoder reports DecompressStatus::Error -- the status it gives every input on which the reference asserts.
+template <class Pairs>
+auto oversubscribed(const Pairs& pairs, unsigned maxbits) -> bool {
+  std::uint64_t used = 0;
+  for (const auto& [sym, len] : pairs) used += std::uint64_t{1} << (maxbits - len);
+  return used > (std::uint64_t{1} << maxbits);
+}
+
 /// one code-length sequence with its own repeat state (the reference keeps the HLIT and
 /// HDIST sequences apart; a run may neither start with 16 nor pass the end)
 inline auto read_lengths(huffman::bit_span& bits, const huffman::table<std::uint8_t>& cl, std::uint16_t n)
@@ -158,15 +168,20 @@ inline auto read_lengths(huffman::bit_span& bits, const huffman::table<std::uint
   std::vector<std::pair<huffman::symbol_span<std::uint16_t>, std::uint8_t>> pairs;
   for (std::uint16_t i = 0; i < n; ++i)
     if (lens[i]) pairs.emplace_back(huffman::symbol_span<std::uint16_t>{i}, lens[i]);
+  if (oversubscribed(pairs, 15)) return compat::unexpected{DecompressStatus::Error};
   return dyn_table{huffman::symbol_bitsize, pairs};
 }
 
 }  // namespace detail
 
 /// Decompresses raw DEFLATE `src` into `dst` (sized by the caller to the exact output length).
-inline auto decompress(std::span<const std::byte> src, std::span<std::byte> dst) -> DecompressStatus {
+/// produced (optional): bytes written -- an extra the reference does not report (src/decompress.hpp:63-64).
+inline auto decompress(std::span<const std::byte> src, std::span<std::byte> dst, std::ptrdiff_t* produced)
+    -> DecompressStatus {
   huffman::bit_span bits{src};
-  std::ptrdiff_t written{};
+  std::ptrdiff_t written_here{};
+  std::ptrdiff_t& written = produced ? *produced : written_here;
+  written = 0;
   for (bool was_final = false; !was_final;) {
     const auto header = detail::read_header(bits);
     if (!header) return header.error();
@@ -194,6 +209,7 @@ inline auto decompress(std::span<const std::byte> src, std::span<std::byte> dst)
         if (!v) return DecompressStatus::Error;
         if (*v) clp.emplace_back(huffman::symbol_span<std::uint8_t>{detail::kCodeLengthOrder[i]}, static_cast<std::uint8_t>(*v));
       }
+      if (detail::oversubscribed(clp, 7)) return DecompressStatus::Error;
       const huffman::table<std::uint8_t> cl{huffman::symbol_bitsize, clp};
       const auto lt = detail::read_lengths(bits, cl, static_cast<std::uint16_t>(257 + *hlit));
       if (!lt) return lt.error();
@@ -203,6 +219,10 @@ inline auto decompress(std::span<const std::byte> src, std::span<std::byte> dst)
     }
   }
   return DecompressStatus::Success;
+}
+
+inline auto decompress(std::span<const std::byte> src, std::span<std::byte> dst) -> DecompressStatus {
+  return decompress(src, dst, static_cast<std::ptrdiff_t*>(nullptr));
 }
 
 template <std::ranges::contiguous_range R>

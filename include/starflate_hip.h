@@ -128,12 +128,15 @@ int sfh_compress_device_async(sfh_ctx* ctx, const void* d_src, size_t n, void* d
 /* ---- measurement hooks (bench.py, tests) ---- */
 
 /* ---- block index + GPU decompress ----
- * A stream written by sfh_compress* consists of independently decodable segments, one per 32 KiB of input
- * (SFH_SEGMENT_BYTES): each starts on a byte, and no match reaches before it.  The index is the table of their
- * first bytes plus the end of the last one: nseg + 1 uint64 offsets into the stream (wrapper header included,
- * trailer excluded).  With it the reference's decompress() (src/decompress.hpp:63-71) runs on the GPU, all
- * segments at once; without it DEFLATE decoding is serial (README.md:5-6).  Any stream with such an index
- * qualifies, e.g. zlib output flushed with Z_FULL_FLUSH every 32 KiB. */
+ * A stream written by sfh_compress* is a sequence of byte-aligned segments, one DEFLATE block per 32 KiB of input
+ * (SFH_SEGMENT_BYTES).  The index is the table of their first bytes plus the end of the last one: nseg + 1
+ * uint64 offsets into the stream (wrapper header included, trailer excluded).  Segments group into strips of
+ * block_bytes of input (sfh_options.block_bytes, sfh_last_block_bytes): no match reaches before its strip, so
+ * strips decode independently; inside a strip the Huffman decoding of all segments still runs at once and only
+ * the byte copies go segment by segment.  With the index the reference's decompress()
+ * (src/decompress.hpp:63-71) runs on the GPU; without it DEFLATE decoding is serial (README.md:5-6).  Any
+ * stream with such an index qualifies, e.g. zlib output flushed with Z_FULL_FLUSH every 32 KiB (block_bytes =
+ * 32768: every segment independent). */
 #define SFH_SEGMENT_BYTES 32768u
 
 /* strip size (sfh_options.block_bytes after defaulting) of the last sfh_compress* call on this ctx; 0 before any */
@@ -144,8 +147,8 @@ size_t sfh_index_entries(const sfh_ctx* ctx);
 /* copies that index to `dst` (host memory, or device memory if dst_on_device); synchronises `stream` */
 int sfh_copy_index(sfh_ctx* ctx, uint64_t* dst, size_t entries, int dst_on_device, void* stream);
 
-/* Sub-index of the last sfh_compress* call: per segment, for each of its 32 parse regions (1024 bytes of output;
- * no match of this library's streams crosses them) {bit offset of the region's first token code counted from
+/* Sub-index of the last sfh_compress* call: per segment, for each of its 32 regions of 1024 bytes of output
+ * (no match of this library's streams crosses them) {bit offset of the region's first token code counted from
  * the segment's first byte, tokens before the region}: SFH_SUBINDEX_WORDS uint32 per segment, all zero for a
  * stored segment.  Optional side information: with it 32 lanes decode one segment's Huffman codes side by
  * side instead of one (the decoder checks it against the stream: a wrong sub-index is an error, never wrong
@@ -157,15 +160,17 @@ int sfh_copy_subindex(sfh_ctx* ctx, uint32_t* dst, size_t words, int dst_on_devi
  * d_src readable up to the next multiple of 4 bytes, as any device allocation is).
  * nseg must be ceil(dst_n / 32768)
  * (1 for dst_n = 0); segment i decodes stream bytes [index[i], index[i+1]) into dst[i*32768 ...) and must
- * produce exactly that many bytes.  Returns SFH_OK when the kernels ran; *status is then the reference's
+ * produce exactly that many bytes.  block_bytes: the strip size the stream was written with (a multiple of 32768;
+ * 0 = 32768, every segment independent): a match of segment i may reach back to the first byte of its strip,
+ * a farther one is InvalidDistance.  Returns SFH_OK when the kernels ran; *status is then the reference's
  * DecompressStatus (0 = Success) of the first failing segment in stream order; dst is complete only on 0.
  * Synchronises `stream` (NULL = the ctx's own). */
 int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const uint64_t* d_index,
-                          const uint32_t* d_subindex, size_t nseg, void* d_dst, size_t dst_n, uint32_t* status,
-                          void* stream);
+                          const uint32_t* d_subindex, size_t nseg, void* d_dst, size_t dst_n, uint32_t block_bytes,
+                          uint32_t* status, void* stream);
 /* Host buffers: H2D (stream + index [+ sub-index, may be NULL]), decode, D2H. */
 int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* index, const uint32_t* subindex,
-                   size_t nseg, void* dst, size_t dst_n, uint32_t* status);
+                   size_t nseg, void* dst, size_t dst_n, uint32_t block_bytes, uint32_t* status);
 
 #define SFH_INFLATE_NSTAGES 2 /* 0 k_inflate_tokens (Huffman decode), 1 k_inflate_bytes (match copies) */
 /* with profiling on: milliseconds per decoder kernel of the last sfh_decompress* call */

@@ -94,9 +94,9 @@ def lib():
     L.sfh_copy_index.restype = C.c_int
     L.sfh_copy_subindex.argtypes = [vp, vp, sz, C.c_int, vp]
     L.sfh_copy_subindex.restype = C.c_int
-    L.sfh_decompress_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, C.POINTER(C.c_uint32), vp]
+    L.sfh_decompress_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, C.c_uint32, C.POINTER(C.c_uint32), vp]
     L.sfh_decompress_device.restype = C.c_int
-    L.sfh_decompress.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, C.POINTER(C.c_uint32)]
+    L.sfh_decompress.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, C.c_uint32, C.POINTER(C.c_uint32)]
     L.sfh_decompress.restype = C.c_int
     L.sfh_last_inflate_ms.argtypes = [vp, C.POINTER(C.c_float * INFLATE_NSTAGES)]
     L.sfh_last_inflate_ms.restype = C.c_int

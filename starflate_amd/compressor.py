@@ -139,9 +139,10 @@ class Compressor:
         self._check(self._lib.sfh_copy_subindex(self._h, sub.data_ptr(), words, 1, C.c_void_p(s)))
         return sub
 
-    def decompress_tensor(self, stream, index, out_n, out=None, hip_stream=None, subindex=None):
+    def decompress_tensor(self, stream, index, out_n, out=None, hip_stream=None, subindex=None, block_bytes=32768):
         """stream: 1-D uint8 CUDA tensor (exactly the compressed bytes); index: int64 CUDA tensor of segments + 1
-        offsets; subindex: optional int32 CUDA tensor [segments, 32, 2] (last_subindex); out_n: decompressed size.
+        offsets; subindex: optional int32 CUDA tensor [segments, 32, 2] (last_subindex); out_n: decompressed size;
+        block_bytes: the strip size the stream was written with (last_block_bytes()).
         Returns (out tensor, DecompressStatus int, 0 = Success)."""
         import torch
 
@@ -161,10 +162,11 @@ class Compressor:
             raise ValueError("subindex must be a contiguous int32 CUDA tensor of segments * 64 words")
         self._check(self._lib.sfh_decompress_device(self._h, stream.data_ptr(), stream.numel(), index.data_ptr(),
                                                     subindex.data_ptr() if subindex is not None else None, nseg,
-                                                    out.data_ptr() if out_n else None, int(out_n), C.byref(st), C.c_void_p(s)))
+                                                    out.data_ptr() if out_n else None, int(out_n), int(block_bytes),
+                                                    C.byref(st), C.c_void_p(s)))
         return out[:out_n], st.value
 
-    def decompress(self, data, index, out_n, subindex=None):
+    def decompress(self, data, index, out_n, subindex=None, block_bytes=32768):
         """Host buffers: bytes-like stream + numpy uint64 index [+ numpy uint32 sub-index] -> (bytes, DecompressStatus int)."""
         src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         idx = np.ascontiguousarray(index, dtype=np.uint64)
@@ -175,7 +177,7 @@ class Compressor:
             raise ValueError("subindex must hold segments * 64 words")
         self._check(self._lib.sfh_decompress(self._h, src.ctypes.data, src.size, idx.ctypes.data,
                                              sub.ctypes.data if sub is not None else None, idx.size - 1,
-                                             dst.ctypes.data if out_n else None, int(out_n), C.byref(st)))
+                                             dst.ctypes.data if out_n else None, int(out_n), int(block_bytes), C.byref(st)))
         return (dst[:out_n].tobytes() if st.value == 0 else b""), st.value
 
     def inflate_ms(self):

@@ -36,6 +36,9 @@ struct sfh_ctx {
   int k1_stamps = 0;  // SFH_K1_STAMPS=1: diagnostic k_lz77 build with s_memtime stamps
   hipEvent_t ev[SFH_NSTAGES + 1] = {};
   bool ev_valid = false;
+  hipEvent_t ev_done = nullptr;  // end of the last call's device work: the next call, on any stream, starts behind it
+  bool busy = false;             // (the device scratch is shared by all calls on this ctx)
+  hipStream_t last_stream = nullptr;
   char err[256] = {0};
 };
 
@@ -139,6 +142,19 @@ uint32_t resolve_block_bytes(uint32_t block_bytes, size_t n) {
   return b;
 }
 
+// Calls on one ctx share its device scratch: a call enqueued on another stream than the previous one first waits
+// (on the device) for that one's work.
+int order_behind_last_call(sfh_ctx* ctx, hipStream_t s) {
+  if (ctx->busy && ctx->last_stream != s) SF_HIP(hipStreamWaitEvent(s, ctx->ev_done, 0), "wait for the previous call");
+  return SFH_OK;
+}
+int mark_call_end(sfh_ctx* ctx, hipStream_t s) {
+  SF_HIP(hipEventRecord(ctx->ev_done, s), "event");
+  ctx->busy = true;
+  ctx->last_stream = s;
+  return SFH_OK;
+}
+
 int check_opt(const sfh_options* o) {
   if (!o) return 0;
   if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 3 || o->no_stored_fast_path > 1) return -1;
@@ -168,6 +184,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
                        resolve_block_bytes(o.block_bytes, n)};
   ctx->last_block_bytes = ko.strip_bytes;
   const bool prof = ctx->profiling != 0;
+  if ((rc = order_behind_last_call(ctx, s)) != SFH_OK) return rc;
   if (prof) SF_HIP(hipEventRecord(ctx->ev[0], s), "event");
   SF_HIP(sf::launch_lz77((const uint8_t*)d_src, n, nchunks, ctx->ws, ko, s), "launch k_lz77");
   if (prof) SF_HIP(hipEventRecord(ctx->ev[1], s), "event");
@@ -184,7 +201,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   if (prof) SF_HIP(hipEventRecord(ctx->ev[5], s), "event");
   ctx->ev_valid = prof;
   ctx->index_valid = true;
-  return SFH_OK;
+  return mark_call_end(ctx, s);
 }
 
 }  // namespace
@@ -247,6 +264,10 @@ int sfh_create(sfh_ctx** out, int device) {
       sfh_destroy(ctx);
       return SFH_E_HIP;
     }
+  if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess) {
+    sfh_destroy(ctx);
+    return SFH_E_HIP;
+  }
   for (int k = 0; k <= SFH_INFLATE_NSTAGES; ++k)
     if (hipEventCreate(&ctx->ev_inf[k]) != hipSuccess) {
       sfh_destroy(ctx);
@@ -272,6 +293,7 @@ void sfh_destroy(sfh_ctx* ctx) {
   (void)hipFree(ctx->d_out);
   for (int k = 0; k <= SFH_NSTAGES; ++k)
     if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+  if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -351,13 +373,16 @@ int sfh_copy_subindex(sfh_ctx* ctx, uint32_t* dst, size_t words, int dst_on_devi
 }
 
 int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const uint64_t* d_index,
-                          const uint32_t* d_subindex, size_t nseg, void* d_dst, size_t dst_n, uint32_t* status,
-                          void* stream) {
+                          const uint32_t* d_subindex, size_t nseg, void* d_dst, size_t dst_n, uint32_t block_bytes,
+                          uint32_t* status, void* stream) {
   if (!ctx || !d_src || !d_index || !status || (!d_dst && dst_n)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
   if (((uintptr_t)d_src & 3) || ((uintptr_t)d_index & 7) || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_subindex & 3))
     return fail(ctx, SFH_E_INVALID_ARG, "device pointer alignment (src 4, index 8, dst 16, sub-index 4)", hipSuccess);
   if (dst_n > ((size_t)1 << 44) || nseg != (size_t)chunks_of(dst_n))
     return fail(ctx, SFH_E_INVALID_ARG, "nseg != ceil(dst_n / 32768)", hipSuccess);
+  if (block_bytes % sf::kChunk || block_bytes > sf::kMaxStrip)
+    return fail(ctx, SFH_E_INVALID_ARG, "block_bytes: a multiple of 32768 up to 16 MiB (0 = 32768)", hipSuccess);
+  const uint32_t sps = block_bytes ? block_bytes / sf::kChunk : 1u;  // segments per strip
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   (void)hipGetLastError();  // see enqueue()
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -367,16 +392,17 @@ int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const u
   ctx->index_valid = false;  // the decoder reuses the scratch: what sfh_debug_read returns now belongs to this call
   ctx->last_chunks = (uint32_t)nseg;
   const bool prof = ctx->profiling != 0;
+  if ((rc = order_behind_last_call(ctx, s)) != SFH_OK) return rc;
   if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[0], s), "event");
   if (d_subindex)
     SF_HIP(sf::launch_inflate_tokens_sub((const uint8_t*)d_src, src_n, d_index, d_subindex, (uint32_t)nseg, dst_n,
-                                         ctx->ws.tokens, ctx->ws.seginfo, s), "launch k_inflate_tokens_sub");
+                                         ctx->ws.tokens, ctx->ws.seginfo, sps, s), "launch k_inflate_tokens_sub");
   else
     SF_HIP(sf::launch_inflate_tokens((const uint8_t*)d_src, src_n, d_index, (uint32_t)nseg, dst_n, ctx->ws.tokens,
-                                     ctx->ws.seginfo, s), "launch k_inflate_tokens");
+                                     ctx->ws.seginfo, sps, s), "launch k_inflate_tokens");
   if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[1], s), "event");
   SF_HIP(sf::launch_inflate_bytes((const uint8_t*)d_src, src_n, (uint32_t)nseg, ctx->ws.tokens, ctx->ws.seginfo,
-                                  (uint8_t*)d_dst, s), "launch k_inflate_bytes");
+                                  (uint8_t*)d_dst, sps, s), "launch k_inflate_bytes");
   if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[2], s), "event");
   ctx->ev_inf_valid = prof;
   SF_HIP(sf::launch_inflate_status(ctx->ws.seginfo, (uint32_t)nseg, ctx->d_value, s), "launch k_inflate_status");
@@ -389,7 +415,7 @@ int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const u
 }
 
 int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* index, const uint32_t* subindex,
-                   size_t nseg, void* dst, size_t dst_n, uint32_t* status) {
+                   size_t nseg, void* dst, size_t dst_n, uint32_t block_bytes, uint32_t* status) {
   if (!ctx || !src || !index || !status || (!dst && dst_n)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   int rc = grow(ctx, &ctx->d_in, &ctx->d_in_cap, src_n ? src_n : 16, "input staging");
@@ -403,7 +429,7 @@ int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* 
   if (subindex)
     SF_HIP(hipMemcpyAsync(ctx->d_sub, subindex, nseg * SFH_SUBINDEX_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, s), "H2D sub-index");
   rc = sfh_decompress_device(ctx, ctx->d_in, src_n, ctx->d_index, subindex ? ctx->d_sub : nullptr, nseg, ctx->d_out,
-                             dst_n, status, s);
+                             dst_n, block_bytes, status, s);
   if (rc) return rc;
   if (*status == 0 && dst_n) {
     SF_HIP(hipMemcpyAsync(dst, ctx->d_out, dst_n, hipMemcpyDeviceToHost, s), "D2H");
@@ -433,6 +459,7 @@ int sfh_checksum_device(sfh_ctx* ctx, const void* d_src, size_t n, uint32_t kind
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   const uint32_t nchunks = chunks_of(n);
   int rc = ensure_sums(ctx, nchunks);
+  if (!rc) rc = order_behind_last_call(ctx, s);
   if (rc) return rc;
   SF_HIP(sf::launch_checksum((const uint8_t*)d_src, n, nchunks, kind, ctx->ws.sums, s), "launch k_checksum");
   SF_HIP(sf::launch_wrap(ctx->ws.sums, nchunks, n, kind, nullptr, nullptr, ctx->d_value, s), "launch k_wrap");

@@ -116,12 +116,14 @@ hipError_t launch_wrap(const uint32_t* sums, uint32_t nchunks, uint64_t n, uint3
                        uint64_t* d_total, uint32_t* d_value, hipStream_t s);
 // sf_inflate.hip
 hipError_t init_inflate_kernels();
+// sps: segments per strip (1: every segment independent); a segment's matches may reach its strip's earlier segments
 hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint64_t* index, uint32_t nseg, uint64_t dst_n,
-                                 uint32_t* tokens, SegInfo* info, hipStream_t s);
+                                 uint32_t* tokens, SegInfo* info, uint32_t sps, hipStream_t s);
 hipError_t launch_inflate_tokens_sub(const uint8_t* src, uint64_t src_n, const uint64_t* index, const uint32_t* subidx,
-                                     uint32_t nseg, uint64_t dst_n, uint32_t* tokens, SegInfo* info, hipStream_t s);
+                                     uint32_t nseg, uint64_t dst_n, uint32_t* tokens, SegInfo* info, uint32_t sps,
+                                     hipStream_t s);
 hipError_t launch_inflate_bytes(const uint8_t* src, uint64_t src_n, uint32_t nseg, const uint32_t* tokens, SegInfo* info,
-                                uint8_t* dst, hipStream_t s);
+                                uint8_t* dst, uint32_t sps, hipStream_t s);
 hipError_t launch_inflate_status(const SegInfo* info, uint32_t nseg, uint32_t* d_result, hipStream_t s);
 
 uint32_t crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);        // host arithmetic

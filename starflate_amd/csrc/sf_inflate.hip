@@ -30,12 +30,14 @@ constexpr uint32_t KT_LDS = KT_LANES * inflate::LaneLayout::kBytes;
 constexpr uint32_t KB_THREADS = 512;
 constexpr uint32_t KB_TPT = 2;     // tokens per thread per step
 constexpr uint32_t KB_SPAN = 3968;  // output bytes per step (pointer array)
-constexpr uint32_t KB_LDS = kChunk + 2 * KB_SPAN + 4 * KB_THREADS * KB_TPT + 8 * (KB_SPAN / 32) + 64;
+constexpr uint32_t KB_AUX = 2 * KB_SPAN + 4 * KB_THREADS * KB_TPT + 8 * (KB_SPAN / 32) + 64;
+constexpr uint32_t KB_LDS = kChunk + KB_AUX;            // independent segments: the segment's own 32 KiB
+constexpr uint32_t KB_LDS_STRIP = 2 * kChunk + KB_AUX;  // strips: a 64 KiB ring = the window + the segment
 
 __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __restrict__ src, uint64_t src_n,
                                                             const uint64_t* __restrict__ index, uint32_t nseg,
                                                             uint64_t dst_n, uint32_t* __restrict__ tokens,
-                                                            SegInfo* __restrict__ info) {
+                                                            SegInfo* __restrict__ info, uint32_t sps) {
   extern __shared__ __align__(16) uint8_t s_tables[];
   const uint32_t seg = blockIdx.x * KT_LANES + threadIdx.x;
   if (seg >= nseg) return;
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __re
   const uint64_t obase = (uint64_t)seg * kChunk;
   const uint32_t out_n = dst_n > obase ? (uint32_t)(dst_n - obase < kChunk ? dst_n - obase : kChunk) : 0u;
   const inflate::SegmentResult r = inflate::decode_segment(src, src_n, lo, hi, out_n, tokens + (uint64_t)seg * kChunk,
-                                                           s_tables + threadIdx.x * inflate::LaneLayout::kBytes);
+                                                           s_tables + threadIdx.x * inflate::LaneLayout::kBytes,
+                                                           (seg % sps) * kChunk);
   SegInfo si;
   si.status = r.status;
   si.ntok = r.ntok;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __r
                                                              const uint64_t* __restrict__ index,
                                                              const uint32_t* __restrict__ subidx, uint32_t nseg,
                                                              uint64_t dst_n, uint32_t* __restrict__ tokens,
-                                                             SegInfo* __restrict__ info) {
+                                                             SegInfo* __restrict__ info, uint32_t sps) {
   using L = inflate::SharedLayout;
   __shared__ __align__(16) uint8_t s_tab[2][L::kBytes];
   __shared__ uint32_t s_tokbuf[64][9];  // 8 waiting tokens per region lane (+1: bank spread)
@@ -155,13 +158,14 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __r
     tok0 = sub[2 * hl + 1];
     const uint32_t bit1 = hl + 1 < kSubRegions ? sub[2 * hl + 2] : 0u;
     const uint32_t tok1 = hl + 1 < kSubRegions ? sub[2 * hl + 3] : 0u;
-    const uint32_t ob = hl * kRegion < out_n ? hl * kRegion : out_n;
-    const uint32_t oe = (hl + 1) * kRegion < out_n ? (hl + 1) * kRegion : out_n;
+    const uint32_t ob = hl * kSubBytes < out_n ? hl * kSubBytes : out_n;
+    const uint32_t oe = (hl + 1) * kSubBytes < out_n ? (hl + 1) * kSubBytes : out_n;
     if ((hl == 0 && bit0 != s_open64[half][1]) || tok0 > ob) {
       st = inflate::kError;  // (tokens before a region) <= (bytes before it) also bounds the token stores
     } else {
       st = inflate::decode_region<L>(src, src_n, lo, hi, bit0, bit1, hl + 1 == kSubRegions, ob, oe,
-                                     tokens + (uint64_t)seg * kChunk + tok0, s_tab[half], n, s_tokbuf[lane]);
+                                     tokens + (uint64_t)seg * kChunk + tok0, s_tab[half], n, s_tokbuf[lane],
+                                     (seg % sps) * kChunk);
       if (st == inflate::kOk && hl + 1 < kSubRegions && tok0 + n != tok1) st = inflate::kError;
     }
   }
@@ -211,26 +215,31 @@ __device__ __forceinline__ uint32_t load_word_guarded(const uint8_t* base, uint6
 // one, however the matches of the step nest or overlap themselves; then the byte is fetched.  45 KiB of LDS (the
 // 32 KiB window + one step of pointers and token records): three workgroups share a CU and hide each other's
 // barriers.
-__global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __restrict__ src, uint64_t src_n,
-                                                              const uint32_t* __restrict__ tokens,
-                                                              SegInfo* __restrict__ info, uint8_t* __restrict__ dst) {
-  extern __shared__ __align__(16) uint8_t s_dyn[];
-  uint8_t* s_out = s_dyn;                                          // [32768] the segment's output window
-  uint16_t* s_ptr = reinterpret_cast<uint16_t*>(s_dyn + kChunk);  // [KB_SPAN] step-relative source, or kFinal
-  uint32_t* s_tinfo = reinterpret_cast<uint32_t*>(s_dyn + kChunk + 2 * KB_SPAN);  // [1024] start | match | byte or dist-1
+// One segment.  kRing: bytes of the output window in LDS -- kChunk for independent segments, 2 * kChunk for the
+// segments of a strip, whose matches may reach into the 32 KiB before the segment (position p of the strip lives
+// at p & (kRing - 1)).  segbase: the segment's first byte, strip-relative.  Returns false when the segment failed.
+template <uint32_t kRing>
+__device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t src_n, const uint32_t* __restrict__ tokens,
+                                      SegInfo* __restrict__ info, uint8_t* __restrict__ dst, uint32_t seg, uint32_t segbase,
+                                      uint8_t* s_dyn) {
+  uint8_t* s_out = s_dyn;                                          // [kRing] output window
+  uint16_t* s_ptr = reinterpret_cast<uint16_t*>(s_dyn + kRing);   // [KB_SPAN] step-relative source, or kFinal
+  uint32_t* s_tinfo = reinterpret_cast<uint32_t*>(s_dyn + kRing + 2 * KB_SPAN);  // [1024] start | match | byte or dist-1
   uint32_t* s_mark = s_tinfo + KB_THREADS * KB_TPT;                // [KB_SPAN / 32] bit: a token starts here
   uint32_t* s_wpre = s_mark + KB_SPAN / 32;                        // [KB_SPAN / 32] tokens starting before the word
   uint32_t* s_w = s_wpre + KB_SPAN / 32;                           // [8] wave totals, [2] next step
   uint32_t* s_next = s_w + KB_THREADS / 64;
   constexpr uint32_t kFinal = 0xFFFFu;
   constexpr uint32_t kWords = KB_SPAN / 32;
+  constexpr uint32_t kMask = kRing - 1;
   static_assert(kWords <= 128 && KB_SPAN % 32 == 0, "one wave scans the bitmap, two words per lane");
-  const uint32_t seg = blockIdx.x, t = threadIdx.x, lane = t & 63;
+  const uint32_t t = threadIdx.x, lane = t & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const SegInfo si = info[seg];
-  if (si.status != inflate::kOk) return;
+  if (si.status != inflate::kOk) return false;
   const uint32_t out_n = si.out_n;
   uint8_t* o = dst + (uint64_t)seg * kChunk;  // 16-byte aligned
+  const uint32_t wb = segbase & kMask;        // the segment's first byte in the window (multiple of kChunk)
 
   if (si.raw) {
     // stored segment: dword copy from an arbitrarily aligned stream position
@@ -245,7 +254,19 @@ __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __r
     }
     const uint32_t done = 4 * nd;
     if (t < out_n - done) o[done + t] = src[si.raw_off + done + t];
-    return;
+    if constexpr (kRing > kChunk) {
+      // later segments of the strip may copy from these bytes: into the window as well
+      __syncthreads();  // (the previous segment's last window reads are done)
+      uint32_t* w32 = reinterpret_cast<uint32_t*>(s_out + wb);
+      for (uint32_t k = t; k < nd; k += KB_THREADS) {
+        const uint32_t lo = load_word_guarded(src, src_n, w0 + k);
+        const uint32_t hi = mis ? load_word_guarded(src, src_n, w0 + k + 1) : 0u;
+        w32[k] = __builtin_amdgcn_alignbyte(hi, lo, mis);
+      }
+      if (t < out_n - done) s_out[wb + done + t] = src[si.raw_off + done + t];
+      __syncthreads();
+    }
+    return true;
   }
 
   const uint32_t ntok = si.ntok;
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __r
     const bool fA = vA && startA + lenA <= limit, fB = vB && startB + lenB <= limit;
     const uint32_t distA = (tokA & 0x7FFFu) + 1u, distB = (tokB & 0x7FFFu) + 1u;
     // k_inflate_tokens has validated every token; this keeps a corrupted token buffer inside the window
-    if ((fA && mA && distA > startA) || (fB && mB && distB > startB) || (vA && startA + lenA > out_n) ||
+    if ((fA && mA && distA > startA + segbase) || (fB && mB && distB > startB + segbase) || (vA && startA + lenA > out_n) ||
         (vB && startB + lenB > out_n))
       bad = true;
     {
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __r
     }
     if (__syncthreads_or(bad)) {
       if (t == 0) info[seg].status = inflate::kError;
-      return;
+      return false;
     }
     const uint32_t next_tok = tok_base + s_next[0], next_pos = s_next[1];
     const uint32_t span_n = next_pos - pos0;
@@ -336,12 +357,12 @@ __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __r
         const uint32_t idx = s_wpre[w] + (uint32_t)__popc(s_mark[w] & (0xFFFFFFFFu >> (31u - (j & 31u)))) - 1u;
         const uint32_t ti = s_tinfo[idx];
         if (!(ti & 0x1000u)) {
-          s_out[pos0 + j] = (uint8_t)(ti >> 16);
+          s_out[wb + pos0 + j] = (uint8_t)(ti >> 16);
           s_ptr[j] = (uint16_t)kFinal;
         } else {
           const uint32_t dist = (ti >> 16) + 1u;
           if (dist > j) {  // source before the step: final
-            s_out[pos0 + j] = s_out[pos0 + j - dist];
+            s_out[wb + pos0 + j] = s_out[(wb + pos0 + j - dist) & kMask];
             s_ptr[j] = (uint16_t)kFinal;
           } else {
             s_ptr[j] = (uint16_t)(j - dist);
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __r
       const uint32_t j = t + KB_THREADS * i;
       if (j < span_n) {
         const uint32_t p = s_ptr[j];
-        if (p != kFinal) s_out[pos0 + j] = s_out[pos0 + p];  // p is final since the paint phase
+        if (p != kFinal) s_out[wb + pos0 + j] = s_out[wb + pos0 + p];  // p is final since the paint phase
       }
     }
     if (t == 0) {
@@ -388,14 +409,36 @@ __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __r
   }
   if (pos0 != out_n) {
     if (t == 0) info[seg].status = inflate::kError;
-    return;
+    return false;
   }
-  const uint4* w16 = reinterpret_cast<const uint4*>(s_out);
+  const uint4* w16 = reinterpret_cast<const uint4*>(s_out + wb);
   uint4* o16 = reinterpret_cast<uint4*>(o);
   const uint32_t nq = out_n / 16;
   for (uint32_t k = t; k < nq; k += KB_THREADS) o16[k] = w16[k];
   const uint32_t done = 16 * nq;
-  if (t < out_n - done) o[done + t] = s_out[done + t];
+  if (t < out_n - done) o[done + t] = s_out[wb + done + t];
+  return true;
+}
+
+// The byte-copy kernel: one workgroup per strip of `sps` segments (sps = 1: independent segments), the
+// segments in order, the window carried in LDS from one to the next.
+template <uint32_t kRing>
+__global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __restrict__ src, uint64_t src_n,
+                                                              const uint32_t* __restrict__ tokens,
+                                                              SegInfo* __restrict__ info, uint8_t* __restrict__ dst,
+                                                              uint32_t nseg, uint32_t sps) {
+  extern __shared__ __align__(16) uint8_t s_dyn[];
+  const uint32_t seg0 = blockIdx.x * sps;
+  for (uint32_t k = 0; k < sps && seg0 + k < nseg; ++k) {
+    if (!inflate_segment_bytes<kRing>(src, src_n, tokens, info, dst, seg0 + k, k * kChunk, s_dyn)) {
+      // the later segments of the strip depend on this one: they fail with it (first failure in stream
+      // order is what the caller sees, k_inflate_status)
+      for (uint32_t j = k + 1 + threadIdx.x; j < sps && seg0 + j < nseg; j += KB_THREADS)
+        if (info[seg0 + j].status == inflate::kOk) info[seg0 + j].status = inflate::kError;
+      return;
+    }
+    __syncthreads();  // the segment's window writes precede the next segment's reads
+  }
 }
 
 constexpr uint32_t KS_THREADS = 1024;
@@ -425,27 +468,37 @@ hipError_t init_inflate_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_tokens),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)KT_LDS);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_bytes), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)KB_LDS);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_bytes<kChunk>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)KB_LDS);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_bytes<2 * kChunk>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_LDS_STRIP);
 }
 
 hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint64_t* index, uint32_t nseg, uint64_t dst_n,
-                                 uint32_t* tokens, SegInfo* info, hipStream_t s) {
+                                 uint32_t* tokens, SegInfo* info, uint32_t sps, hipStream_t s) {
   hipLaunchKernelGGL(k_inflate_tokens, dim3((nseg + KT_LANES - 1) / KT_LANES), dim3(KT_LANES), KT_LDS, s, src, src_n, index,
-                     nseg, dst_n, tokens, info);
+                     nseg, dst_n, tokens, info, sps);
   return hipGetLastError();
 }
 
 hipError_t launch_inflate_tokens_sub(const uint8_t* src, uint64_t src_n, const uint64_t* index, const uint32_t* subidx,
-                                     uint32_t nseg, uint64_t dst_n, uint32_t* tokens, SegInfo* info, hipStream_t s) {
+                                     uint32_t nseg, uint64_t dst_n, uint32_t* tokens, SegInfo* info, uint32_t sps,
+                                     hipStream_t s) {
   hipLaunchKernelGGL(k_inflate_tokens_sub, dim3((nseg + 1) / 2), dim3(64), 0, s, src, src_n, index, subidx, nseg, dst_n,
-                     tokens, info);
+                     tokens, info, sps);
   return hipGetLastError();
 }
 
 hipError_t launch_inflate_bytes(const uint8_t* src, uint64_t src_n, uint32_t nseg, const uint32_t* tokens, SegInfo* info,
-                                uint8_t* dst, hipStream_t s) {
-  hipLaunchKernelGGL(k_inflate_bytes, dim3(nseg), dim3(KB_THREADS), KB_LDS, s, src, src_n, tokens, info, dst);
+                                uint8_t* dst, uint32_t sps, hipStream_t s) {
+  const uint32_t nstrips = (nseg + sps - 1) / sps;
+  if (sps == 1)
+    hipLaunchKernelGGL(k_inflate_bytes<kChunk>, dim3(nstrips), dim3(KB_THREADS), KB_LDS, s, src, src_n, tokens, info, dst,
+                       nseg, sps);
+  else
+    hipLaunchKernelGGL(k_inflate_bytes<2 * kChunk>, dim3(nstrips), dim3(KB_THREADS), KB_LDS_STRIP, s, src, src_n, tokens,
+                       info, dst, nseg, sps);
   return hipGetLastError();
 }
 

@@ -360,10 +360,12 @@ SF_HD uint32_t read_tables(BitReader& br, uint8_t* m, uint32_t type) {
 
 // Symbol loop (src/decompress.cpp:122-187) until the end-of-block code or, if sooner, until `end_bit` bits of
 // the segment are consumed (a region lane stops where the next region starts).  out_pos: bytes of the segment
-// produced before / after; out_limit: where this caller's output must end at the latest.
+// produced before / after; out_limit: where this caller's output must end at the latest; hist: output bytes that
+// precede the segment and that its matches may reach (0 for an independent segment; the earlier segments of the
+// same strip otherwise -- the reference's one rule is distance <= bytes written, src/decompress.cpp:178).
 template <class L, class Sink>
 SF_HD uint32_t decode_symbols(BitReader& br, const uint8_t* m, Sink& sink, uint32_t& out_pos, uint32_t out_limit,
-                              uint32_t end_bit, bool& hit_eob) {
+                              uint32_t end_bit, bool& hit_eob, uint32_t hist) {
   hit_eob = false;
   while (br.bitpos < end_bit) {
     sink.tick();
@@ -394,7 +396,7 @@ SF_HD uint32_t decode_symbols(BitReader& br, const uint8_t* m, Sink& sink, uint3
     uint32_t dbase, dextra;
     distance_info(dsym, dbase, dextra);
     const uint32_t dist = dbase + br.drop_get(dl, dextra);
-    if (dist > out_pos) return kInvalidDistance;  // src/decompress.cpp:178
+    if (dist > out_pos + hist) return kInvalidDistance;  // src/decompress.cpp:178
     if (len > out_limit - out_pos) return kDstTooSmall;
     sink.put(kTokMatchBit | ((len - 3) << 16) | (dist - 1));
     out_pos += len;
@@ -404,9 +406,9 @@ SF_HD uint32_t decode_symbols(BitReader& br, const uint8_t* m, Sink& sink, uint3
 }
 
 // Decodes the blocks of one segment: stream bytes [seg_begin, seg_end) of `src`, which must produce exactly
-// out_n (<= 32768) bytes.  Tokens go to tokens[0..ntok).  `m`: LaneLayout::kBytes of scratch.
+// out_n (<= 32768) bytes.  Tokens go to tokens[0..ntok).  `m`: LaneLayout::kBytes of scratch.  hist: see decode_symbols.
 SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end,
-                                   uint32_t out_n, uint32_t* tokens, uint8_t* m) {
+                                   uint32_t out_n, uint32_t* tokens, uint8_t* m, uint32_t hist = 0) {
   SegmentResult r{kOk, 0, 0, 0};
   if (seg_begin > seg_end || seg_end > src_n) {
     r.status = kSrcTooSmall;
@@ -460,7 +462,7 @@ SF_HD SegmentResult decode_segment(const uint8_t* src, uint64_t src_n, uint64_t 
     status = read_tables<LaneLayout>(br, m, type);
     if (status != kOk) break;
     bool eob;
-    status = decode_symbols<LaneLayout>(br, m, sink, out_pos, out_n, ~0u, eob);
+    status = decode_symbols<LaneLayout>(br, m, sink, out_pos, out_n, ~0u, eob, hist);
   }
   if (status == kOk && out_pos != out_n) status = kSrcTooSmall;  // the index promised more bytes
   if (status == kOk && r.raw && sink.n != 0) status = kDstTooSmall;
@@ -513,7 +515,7 @@ SF_HD uint32_t open_segment(const uint8_t* src, uint64_t src_n, uint64_t seg_beg
 template <class L>
 SF_HD uint32_t decode_region(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end, uint32_t bit_begin,
                              uint32_t bit_end, bool until_eob, uint32_t out_begin, uint32_t out_end, uint32_t* tokens,
-                             const uint8_t* m, uint32_t& ntok, uint32_t* lane_buf = nullptr) {
+                             const uint8_t* m, uint32_t& ntok, uint32_t* lane_buf = nullptr, uint32_t hist = 0) {
   ntok = 0;
   if (seg_begin >= seg_end || seg_end > src_n) return kError;
   BitReader br;
@@ -528,12 +530,12 @@ SF_HD uint32_t decode_region(const uint8_t* src, uint64_t src_n, uint64_t seg_be
   uint32_t st;
   if (lane_buf) {
     BufferedSink sink{tokens, lane_buf, 0, 0, 0};
-    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0u : bit_end, eob);
+    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0u : bit_end, eob, hist);
     sink.flush();
     ntok = sink.n;
   } else {
     PlainSink sink{tokens, 0};
-    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0u : bit_end, eob);
+    st = decode_symbols<L>(br, m, sink, out_pos, out_end, until_eob ? ~0u : bit_end, eob, hist);
     ntok = sink.n;
   }
   if (st != kOk) return st;

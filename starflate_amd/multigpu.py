@@ -6,6 +6,8 @@ an all_gather of one int64 size per rank, then one point-to-point send per rank
 into rank 0's output at its prefix offset (a gather-v; each transfer rides one
 xGMI link, no ring).  Works with backend "nccl" (= RCCL on ROCm) on CUDA tensors
 and with "gloo" on CPU tensors (tests)."""
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -50,17 +52,30 @@ def concat_streams(local, local_n, group=None, out=None):
     return None, total
 
 
-def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw", checksum_fn=None):
-    """Block-cyclic sharding with overlap: the global input is K*world pieces in the order
-    g = k*world + rank; this rank holds `pieces[k]` for rounds k = 0..K-1.  Round k's streams are
-    gathered straight to their final offsets (they only depend on the sizes of rounds <= k, known
-    after one small all_gather), asynchronously, while round k+1 is being compressed -- so the
-    point-to-point gather over xGMI hides behind compression instead of following it.
+def _agree(ok, msg, dev, group):
+    """All ranks raise together (or none does): a rank that fails a local check must not leave its peers
+    waiting in the next collective."""
+    flag = torch.tensor([0 if ok else 1], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        raise ValueError(msg if not ok else "compress_pipelined: another rank rejected its arguments")
 
-    compress_fn(piece, final, k) -> (uint8 tensor, nbytes): this rank's stream for round k, in a
-    buffer that stays untouched until this function returns (use one buffer per round);
-    `final` is True only for the globally last piece.  Returns (out, total) on rank 0 and
-    (None, total) elsewhere; `out` (rank 0) must hold the whole concatenation if given.
+
+def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw", checksum_fn=None, bound_fn=None):
+    """Block-cyclic sharding with overlap.  BYTE ORDER CONTRACT: the global input is K*world pieces in the order
+    g = k*world + rank; this rank holds `pieces[k]` for rounds k = 0..K-1 (a file of N bytes is dealt in pieces of
+    N / (K*world) bytes, a multiple of the strip size: piece g goes to rank g % world as its round g // world).
+    Round k's streams are gathered straight to their final offsets (they only depend on the sizes of rounds <= k),
+    asynchronously, while round k+1 is being compressed -- so the point-to-point gather over xGMI hides behind
+    compression instead of following it.
+
+    compress_fn(piece, final, k) -> (uint8 tensor, nbytes): this rank's stream for round k, in a buffer that stays
+    untouched until this function returns (use one buffer per round); `final` is True only for the globally last
+    piece.  nbytes may be a Python int or a 1-element int64 tensor on the stream's device (an enqueue-only
+    compressor, sfh_compress_device_async): then nothing here waits for the compression itself -- the one host
+    wait per round is the read-back of the gathered sizes, and round k+1 is already enqueued when it happens.
+    Returns (out, total) on rank 0 and (None, total) elsewhere; `out` (rank 0) must hold the whole concatenation if
+    given (checked against bound_fn(piece bytes), default the library's bound, before any stream moves).
 
     container "zlib" / "gzip": the raw piece streams are wrapped once, on rank 0.  checksum_fn(piece, k)
     -> this rank's Adler-32 / CRC-32 of pieces[k] (Compressor.checksum_tensor on the GPU); the values ride
@@ -72,31 +87,82 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
     rank = dist.get_rank(group)
     K = len(pieces)
     wrapped = container != "raw"
-    if wrapped and checksum_fn is None:
-        raise ValueError("compress_pipelined: a container needs checksum_fn")
+    dev = pieces[0].device if K else torch.device("cpu")
     header = wrapper_bytes(container, 0, 0)[0] if wrapped else b""
+    # ---- arguments are judged before anything is enqueued, and by all ranks alike ----
+    ok, msg = True, ""
+    if K == 0:
+        ok, msg = False, "compress_pipelined: no pieces"
+    elif container not in ("raw", "zlib", "gzip"):
+        ok, msg = False, f"compress_pipelined: unknown container {container!r}"
+    elif wrapped and checksum_fn is None:
+        ok, msg = False, "compress_pipelined: a container needs checksum_fn"
+    lens = torch.tensor([int(p.numel()) for p in pieces] + [K], dtype=torch.int64, device=dev)
+    all_lens = [torch.zeros_like(lens) for _ in range(world)]
+    dist.all_gather(all_lens, lens, group=group)
+    all_lens = [[int(v) for v in x.tolist()] for x in all_lens]
+    if ok and any(r[-1] != K for r in all_lens):
+        ok, msg = False, "compress_pipelined: ranks disagree on the number of rounds"
+    if ok and rank == 0 and out is not None:
+        if bound_fn is None:
+            from ._capi import lib
+            bound_fn = lambda n: lib().sfh_compress_bound(int(n), 0)  # noqa: E731
+        need = len(header) + 8 + sum(bound_fn(n) for r in all_lens for n in r[:K])
+        if out.numel() < need:
+            ok, msg = False, f"compress_pipelined: `out` holds {out.numel()} bytes, the bound is {need}"
+    _agree(ok, msg, dev, group)
+
     works, keep, parts = [], [], []
     base = len(header)
     running, n_in = None, 0
-    for k, piece in enumerate(pieces):
-        local, n = compress_fn(piece, k == K - 1 and rank == world - 1, k)
-        dev = local.device
-        cs = int(checksum_fn(piece, k)) if wrapped else 0
-        mine = torch.tensor([int(n), cs, int(piece.numel())], dtype=torch.int64, device=dev)
-        rows = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+    enq = {}
+    # Rounds alternate between two side streams: round k's size exchange and sends are ordered behind round k's
+    # compression only, so they run beside round k+1's kernels.  (Two compressions never overlap each other: the
+    # library orders successive calls on one context, whatever their streams -- sfh_compress_device_async.)
+    side = None
+    if dev.type == "cuda":
+        cur = torch.cuda.current_stream(dev)
+        side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        for st in side:
+            st.wait_stream(cur)
+
+    def on(k):
+        return torch.cuda.stream(side[k % 2]) if side else contextlib.nullcontext()
+
+    def enqueue(k):
+        with on(k):
+            return _enqueue(k)
+
+    def _enqueue(k):
+        local, n = compress_fn(pieces[k], k == K - 1 and rank == world - 1, k)
+        cs = int(checksum_fn(pieces[k], k)) if wrapped else 0
+        if torch.is_tensor(n):
+            mine = torch.stack([n.reshape(()).to(torch.int64), torch.tensor(cs, dtype=torch.int64, device=n.device),
+                                torch.tensor(int(pieces[k].numel()), dtype=torch.int64, device=n.device)])
+        else:
+            mine = torch.tensor([int(n), cs, int(pieces[k].numel())], dtype=torch.int64, device=local.device)
+        enq[k] = (local, mine)
+
+    enqueue(0)
+    for k in range(K):
+        if k + 1 < K:
+            enqueue(k + 1)  # the next round is on the device's queue before this round's sizes are waited for
+        local, mine = enq.pop(k)
+        ctx = on(k)
+        ctx.__enter__()
+        rows = [torch.zeros(3, dtype=torch.int64, device=mine.device) for _ in range(world)]
         dist.all_gather(rows, mine, group=group)
         rows = [[int(v) for v in x.tolist()] for x in rows]
         sizes = [r[0] for r in rows]
+        n = sizes[rank]
         for _, c, ln in rows if wrapped else []:  # global order g = k*world + r
             running = c if running is None else checksum_combine(container, running, c, ln)
             n_in += ln
         if rank == 0:
             if out is not None:
-                if out.numel() < base + sum(sizes):
-                    raise ValueError("compress_pipelined: `out` is smaller than the concatenated stream")
                 dst, o0 = out, base
             else:  # no preallocated output: one buffer per round, concatenated at the end
-                dst, o0 = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device=dev), 0
+                dst, o0 = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device=local.device), 0
                 parts.append(dst[: sum(sizes)])
             dst[o0: o0 + sizes[0]] = local[: sizes[0]]
             ops, off = [], o0 + sizes[0]
@@ -108,10 +174,14 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
             ops = [dist.P2POp(dist.isend, local[:n], 0, group=group)] if n else []
         if ops:
             works.extend(dist.batch_isend_irecv(ops))
+        ctx.__exit__(None, None, None)
         keep.append(local)
         base += sum(sizes)
     for w in works:
         w.wait()
+    if side:
+        for st in side:
+            cur.wait_stream(st)
     del keep
     trailer = wrapper_bytes(container, running, n_in)[1] if wrapped else b""
     total = base + len(trailer)
@@ -122,15 +192,16 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
     as_t = lambda b: torch.tensor(list(b), dtype=torch.uint8, device=dev)  # noqa: E731
     if out is None:
         return torch.cat([as_t(header)] + parts + [as_t(trailer)]), total
-    if out.numel() < total:
-        raise ValueError("compress_pipelined: `out` is smaller than the wrapped stream")
     out[: len(header)] = as_t(header)
     out[base:total] = as_t(trailer)
     return out[:total], total
 
 
 def compress_sharded(compressor, shard, group=None, out=None, scratch=None, **kw):
-    """Compress this rank's shard (BFINAL only on the last rank) and concatenate on rank 0."""
+    """Compress this rank's shard (BFINAL only on the last rank) and concatenate on rank 0.  Raw streams only: a
+    wrapper spans all shards (compress_pipelined with container=..., or wrapper_bytes + checksum_combine)."""
+    if kw.get("container", "raw") != "raw":
+        raise ValueError("compress_sharded writes raw streams; wrap the concatenation with compress_pipelined(container=...)")
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     local, n = compressor.compress_tensor(shard, out=scratch, final_stream=(rank == world - 1), **kw)

@@ -124,10 +124,51 @@ auto main(int argc, char** argv) -> int {
   std::vector<std::byte> tiny(8);
   const auto r = gpu.compress(html, tiny);
   if (r || r.error() != CompressStatus::DstTooSmall) { std::printf("expected DstTooSmall\n"); ++fail; }
-  // free function
-  std::vector<std::byte> comp(compress_bound(html.size()));
+  // free function: 100 calls reuse the calling thread's context (no stream / scratch churn), same bytes every time
+  std::vector<std::byte> comp(compress_bound(html.size())), again(compress_bound(html.size()));
   const auto n = compress(html, comp);
   if (!n || *n == 0 || *n >= html.size()) { std::printf("free compress() failed\n"); ++fail; }
+  const sfh_ctx* const kept = detail::thread_compressor(0).native();
+  for (int k = 0; k < 100 && n; ++k) {
+    const auto m = compress(html, again);
+    if (!m || *m != *n || !std::equal(comp.begin(), comp.begin() + static_cast<std::ptrdiff_t>(*n), again.begin()) ||
+        detail::thread_compressor(0).native() != kept) {
+      std::printf("free compress() call %d differs or re-created its context\n", k);
+      ++fail;
+      break;
+    }
+  }
+  // strips: block_bytes = 65536 lets the second block of a strip match into the first -- smaller, same round trip
+  // through the serial decoder and through the GPU decoder (the index carries the strip size); lazy levels 0..3
+  {
+    compress_options opt;
+    opt.block_bytes = 65536;
+    std::vector<std::byte> strip(compress_bound(html.size(), opt.block_bytes));
+    const auto ns = gpu.compress(html, strip, opt);
+    const auto ix = gpu.index(true);
+    compress_options indep;
+    indep.block_bytes = 32768;
+    const auto ni = gpu.compress(html, comp, indep);
+    std::vector<std::byte> back(html.size()), serial(html.size());
+    if (!ns || !ni || !ix || ix->block_bytes != 65536 || *ns >= *ni) { std::printf("strips: sizes\n"); ++fail; }
+    else {
+      strip.resize(*ns);
+      if (gpu.decompress(strip, back, *ix) != DecompressStatus::Success || decompress(strip, serial) != DecompressStatus::Success ||
+          back != html || serial != html) { std::printf("strips: round trip\n"); ++fail; }
+    }
+    std::size_t prev = 0;
+    for (std::uint8_t lazy = 0; lazy <= 3; ++lazy) {
+      compress_options lo;
+      lo.lazy = lazy;
+      const auto nl = gpu.compress(html, comp, lo);
+      if (!nl || (lazy == 3 && *nl >= prev)) { std::printf("lazy %d\n", int(lazy)); ++fail; }
+      if (lazy == 0 && nl) prev = *nl;
+    }
+    compress_options bad;
+    bad.block_bytes = 1000;
+    const auto nb = gpu.compress(html, comp, bad);
+    if (nb || nb.error() != CompressStatus::InvalidArgument) { std::printf("expected InvalidArgument for block_bytes\n"); ++fail; }
+  }
   std::printf("compress_roundtrip: %d failures\n", fail);
   return fail ? 1 : 0;
 }

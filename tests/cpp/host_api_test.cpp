@@ -312,6 +312,64 @@ static void test_container(const std::string& golden, const std::string& wrapped
   }
 }
 
+// LSB-first bit writer for hand-made streams
+struct bit_writer {
+  std::vector<std::byte> out;
+  std::size_t nbits = 0;
+  void put(unsigned v, unsigned n) {
+    for (unsigned i = 0; i < n; ++i, ++nbits) {
+      if (nbits % 8 == 0) out.push_back(std::byte{0});
+      if ((v >> i) & 1U) out.back() |= static_cast<std::byte>(1U << (nbits % 8));
+    }
+  }
+};
+
+// Untrusted input must come back as a status, never as an abort or a table of wrapped codes: over-subscribed
+// code lengths (the reference asserts on them, huffman/src/code.hpp), then a seeded bit-flip fuzz of valid streams
+// (this test is built without NDEBUG, and under ASan + UBSan in the second configuration).
+static void test_untrusted_input(const std::string& golden) {
+  {
+    // dynamic block whose code-length code has three codes of length 1 (Kraft sum 1.5)
+    bit_writer w;
+    w.put(1, 1); w.put(2, 2);            // BFINAL, BTYPE = 10
+    w.put(0, 5); w.put(0, 5); w.put(0, 4);  // HLIT = 257, HDIST = 1, HCLEN = 4 -> lengths for symbols 16, 17, 18, 0
+    w.put(1, 3); w.put(1, 3); w.put(1, 3); w.put(0, 3);
+    w.put(0xFFFF, 16); w.put(0xFFFF, 16);
+    std::vector<std::byte> dst(64);
+    CHECK(starflate::decompress(w.out, dst) == DecompressStatus::Error);
+  }
+  {
+    // a complete code-length code (symbols 1 and 2, one bit each) spelling over-subscribed literal/length lengths:
+    // 257 lengths of 1 (HLIT = 0)
+    bit_writer w;
+    w.put(1, 1); w.put(2, 2);
+    w.put(0, 5); w.put(0, 5); w.put(14, 4);  // HCLEN = 18: order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1
+    const unsigned order[18] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1};
+    for (const unsigned sym : order) w.put((sym == 1 || sym == 2) ? 1U : 0U, 3);
+    for (int i = 0; i < 257 + 1; ++i) w.put(0, 1);  // code 0 = symbol 1: every length is 1
+    std::vector<std::byte> dst(64);
+    CHECK(starflate::decompress(w.out, dst) == DecompressStatus::Error);
+  }
+  for (const char* name : {"/starfleet.html.dynamic", "/starfleet.html.fixed"}) {
+    const auto good = read_file(golden + name);
+    const auto html = read_file(golden + "/starfleet.html");
+    std::vector<std::byte> dst(html.size());
+    std::uint64_t rng = 0x9E3779B97F4A7C15ULL;
+    const auto next = [&] { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    int ok = 0;
+    for (int it = 0; it < 3000; ++it) {
+      auto bad = good;
+      const int flips = 1 + static_cast<int>(next() % 3);
+      // bias towards the first block header: that is where the code lengths live
+      for (int f = 0; f < flips; ++f) bad[next() % (it % 2 ? 200 : bad.size())] ^= static_cast<std::byte>(1U << (next() % 8));
+      const auto st = starflate::decompress(bad, dst);
+      ok += st == DecompressStatus::Success;
+      CHECK(static_cast<unsigned>(st) <= 7);
+    }
+    CHECK(ok < 3000);
+  }
+}
+
 auto main(int argc, char** argv) -> int {
   const std::string golden = argc > 1 ? argv[1] : "tests/golden";
   test_container(golden, argc > 2 ? argv[2] : "");
@@ -324,6 +382,7 @@ auto main(int argc, char** argv) -> int {
   test_find();
   test_decode();
   test_decompress(golden);
+  test_untrusted_input(golden);
   std::printf("%d checks, %d failed\n", g_checks, g_fail);
   return g_fail ? 1 : 0;
 }

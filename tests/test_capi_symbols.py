@@ -30,11 +30,13 @@ def test_host_side_entry_points_without_gpu():
     lib = _capi.lib()
     o = _capi.Options()
     lib.sfh_default_options(C.byref(o))
-    assert (o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path, o.container) == (0, 1, 3, 0, 0)
+    assert (o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path, o.container, o.block_bytes) == (0, 1, 3, 0, 0, 0)
     assert all(v == 0 for v in o.reserved) and C.sizeof(o) == 32
-    assert lib.sfh_compress_bound(0) == 32768 + 4096 + 640
-    assert lib.sfh_compress_bound(32768) == 32768 + 4096 + 640
-    assert lib.sfh_compress_bound(32769) == 2 * (32768 + 4096 + 640)
+    for bb in (0, 32768, 262144):  # sfh_compress_bound(n, block_bytes); per 32 KiB DEFLATE block
+        assert lib.sfh_compress_bound(0, bb) == 32768 + 4096 + 640
+        assert lib.sfh_compress_bound(32768, bb) == 32768 + 4096 + 640
+        assert lib.sfh_compress_bound(32769, bb) == 2 * (32768 + 4096 + 640)
+    assert _capi.resolve_block_bytes(0, 1 << 30) == 262144 and _capi.resolve_block_bytes(0, 1 << 20) == 32768
     assert lib.sfh_stage_name(0) == b"k_lz77" and lib.sfh_stage_name(3) == b"k_emit" and lib.sfh_stage_name(9) == b""
     import zlib
     a, b = bytes(range(256)) * 300, b"starflate" * 5000  # host-side checksum combine rules against zlib

@@ -42,17 +42,19 @@ def _gpu_roundtrip(compressor, data, use_sub=False, **kw):
     index = compressor.last_index(device="cuda")
     sub = compressor.last_subindex(device="cuda") if use_sub else None
     stream = out[:n].clone()
-    back, status = compressor.decompress_tensor(stream, index, data.size, subindex=sub)
+    back, status = compressor.decompress_tensor(stream, index, data.size, subindex=sub, block_bytes=compressor.last_block_bytes())
     return stream.cpu().numpy(), index.cpu().numpy().astype(np.uint64), back.cpu().numpy(), status
 
 
+@pytest.mark.parametrize("block_bytes", [32768, 131072])
 @pytest.mark.parametrize("use_sub", [False, True])
 @pytest.mark.parametrize("strategy", ["auto", "stored", "fixed", "dynamic"])
-def test_inflate_own_streams_equals_reference_decoder(compressor, starfleet, strategy, use_sub):
+def test_inflate_own_streams_equals_reference_decoder(compressor, starfleet, strategy, use_sub, block_bytes):
     """use_sub: 32 region lanes per segment located by the sub-index (k_inflate_tokens_sub) instead of one lane per
-    segment (k_inflate_tokens); same bytes either way."""
+    segment (k_inflate_tokens); same bytes either way.  block_bytes = 131072: strips of four segments whose matches
+    reach into the strip's earlier segments (the byte-copy kernel then carries a 64 KiB window through the strip)."""
     for name, data in _inputs(starfleet).items():
-        stream, index, back, status = _gpu_roundtrip(compressor, data, use_sub=use_sub, strategy=strategy)
+        stream, index, back, status = _gpu_roundtrip(compressor, data, use_sub=use_sub, strategy=strategy, block_bytes=block_bytes)
         assert status == 0, (name, status)
         st, w, ref = O.decompress(stream, data.size)  # the reference restatement on the same stream
         assert st == 0 and w == data.size
@@ -66,10 +68,11 @@ def test_inflate_own_streams_equals_reference_decoder(compressor, starfleet, str
 def test_index_and_subindex_equal_oracle(compressor, starfleet, strategy):
     """The side information is part of the specification: chunk offsets and, per 1024-byte parse region, the bit
     offset of its first token code and the tokens before it -- bit-exact with sfo_compress_indexed."""
-    for name, data in _inputs(starfleet).items():
-        got = np.frombuffer(compressor.compress(data, strategy=strategy), np.uint8)
+    for k, (name, data) in enumerate(_inputs(starfleet).items()):
+        bb = [0, 65536, 32768][k % 3]
+        got = np.frombuffer(compressor.compress(data, strategy=strategy, block_bytes=bb), np.uint8)
         idx, sub = compressor.last_index(), compressor.last_subindex()
-        want, widx, wsub = O.compress_indexed(data, O.default_params(strategy=_capi.STRATEGY[strategy]))
+        want, widx, wsub = O.compress_indexed(data, O.default_params(strategy=_capi.STRATEGY[strategy], strip_bytes=bb))
         assert np.array_equal(got, want), name
         assert np.array_equal(idx, widx), name
         assert np.array_equal(sub, wsub), (name, np.argwhere(sub != wsub)[:4])
@@ -77,16 +80,32 @@ def test_index_and_subindex_equal_oracle(compressor, starfleet, strategy):
 
 def test_wrong_subindex_is_an_error_not_wrong_output(compressor, starfleet):
     data = np.frombuffer(starfleet, np.uint8)
-    stream = compressor.compress(data, strategy="dynamic")
+    stream = compressor.compress(data, strategy="dynamic", block_bytes=65536)
     idx, sub = compressor.last_index(), compressor.last_subindex()
-    assert compressor.decompress(stream, idx, data.size, subindex=sub) == (data.tobytes(), 0)
+    assert compressor.decompress(stream, idx, data.size, subindex=sub, block_bytes=65536) == (data.tobytes(), 0)
     for where, delta in (((1, 7, 0), 1), ((2, 0, 0), 3), ((0, 31, 1), 1), ((3, 12, 1), 5), ((1, 3, 0), 1 << 20)):
         bad = sub.copy()
         bad[where] += np.uint32(delta)
-        out, st = compressor.decompress(stream, idx, data.size, subindex=bad)
+        out, st = compressor.decompress(stream, idx, data.size, subindex=bad, block_bytes=65536)
         assert st != 0 and out == b"", (where, st)
     zero = np.zeros_like(sub)
-    assert compressor.decompress(stream, idx, data.size, subindex=zero)[1] != 0
+    assert compressor.decompress(stream, idx, data.size, subindex=zero, block_bytes=65536)[1] != 0
+
+
+def test_wrong_block_bytes_is_an_error_not_wrong_output(compressor):
+    """A stream whose matches reach into the previous segment, decoded as if every segment were independent (or with
+    strips that start elsewhere): InvalidDistance (7), as src/decompress.cpp:178 reports a distance beyond the bytes
+    written -- never other bytes."""
+    data = synth.gen_text(8 * CHUNK, seed=19)
+    stream = compressor.compress(data, block_bytes=4 * CHUNK)
+    idx = compressor.last_index()
+    assert compressor.decompress(stream, idx, data.size, block_bytes=4 * CHUNK) == (data.tobytes(), 0)
+    assert compressor.decompress(stream, idx, data.size, block_bytes=8 * CHUNK) == (data.tobytes(), 0)  # a coarser strip is fine
+    for bb in (CHUNK, 2 * CHUNK):
+        out, st = compressor.decompress(stream, idx, data.size, block_bytes=bb)
+        assert st == 7 and out == b"", (bb, st)
+    with pytest.raises(Exception):
+        compressor.decompress(stream, idx, data.size, block_bytes=CHUNK + 1)
 
 
 def test_decoder_tokens_equal_compressor_tokens(compressor):
@@ -96,18 +115,16 @@ def test_decoder_tokens_equal_compressor_tokens(compressor):
     data = synth.gen_text(CHUNK * 6 + 99, seed=13)
     nch = 7
     src = torch.from_numpy(data).cuda()
-    out, n = compressor.compress_tensor(src, strategy="dynamic")
+    out, n = compressor.compress_tensor(src, strategy="dynamic", block_bytes=4 * CHUNK)
     index = compressor.last_index(device="cuda")
     ntok_c = compressor.debug(_capi.DBG_NTOK, nch).copy()
-    tok_c = compressor.debug(_capi.DBG_TOKENS, nch).copy()
-    back, status = compressor.decompress_tensor(out[:n].clone(), index, data.size)
+    tok_c, _ = compressor.debug_tokens(nch)
+    back, status = compressor.decompress_tensor(out[:n].clone(), index, data.size, block_bytes=4 * CHUNK)
     assert status == 0 and np.array_equal(back.cpu().numpy(), data)
-    ntok_d = compressor.debug(_capi.DBG_NTOK, nch)  # untouched by the decoder: counts live in the segment records
-    tok_d = compressor.debug(_capi.DBG_TOKENS, nch)
-    assert np.array_equal(ntok_c, ntok_d)
+    tok_d = compressor.debug(_capi.DBG_TOKENS, nch)  # the decoder's own token buffer
     for c in range(nch):
         k = int(ntok_c[c])
-        assert np.array_equal(tok_c[c, :k] & np.uint32(0x80FFFFFF), tok_d[c, :k]), c  # minus the region-start flags
+        assert tok_c[c].size == k and np.array_equal(tok_c[c], tok_d[c, :k]), c
 
 
 @pytest.mark.parametrize("container", ["zlib", "gzip"])
@@ -138,6 +155,15 @@ def test_inflate_zlib_made_indexed_streams(compressor, starfleet, level, strateg
         got, status = compressor.decompress(stream, index, data.size)  # host-buffer entry point
         assert status == 0, (name, status)
         assert got == data.tobytes(), name
+        # the same with strips of four segments: the window survives Z_SYNC_FLUSH and restarts at Z_FULL_FLUSH
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        parts = []
+        for c in range(nch):
+            b = co.compress(data[c * CHUNK:(c + 1) * CHUNK].tobytes())
+            parts.append(b + co.flush(zlib.Z_FINISH if c == nch - 1 else (zlib.Z_FULL_FLUSH if c % 4 == 3 else zlib.Z_SYNC_FLUSH)))
+        index = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+        got, status = compressor.decompress(b"".join(parts), index, data.size, block_bytes=4 * CHUNK)
+        assert status == 0 and got == data.tobytes(), (name, "strips")
 
 
 def test_malformed_segments_report_reference_statuses(compressor, starfleet):
@@ -179,16 +205,18 @@ def test_inflate_large_roundtrip_and_timing(compressor):
     index = compressor.last_index(device="cuda")
     stream = out[:n].clone()
     sub = compressor.last_subindex(device="cuda")
+    bb = compressor.last_block_bytes()
+    assert bb == 262144
     compressor.set_profiling(True)
-    back, status = compressor.decompress_tensor(stream, index, data.size)
+    back, status = compressor.decompress_tensor(stream, index, data.size, block_bytes=bb)
     assert status == 0 and torch.equal(back, src)
     ms = compressor.inflate_ms()
-    back3, status3 = compressor.decompress_tensor(stream, index, data.size, subindex=sub)
+    back3, status3 = compressor.decompress_tensor(stream, index, data.size, subindex=sub, block_bytes=bb)
     assert status3 == 0 and torch.equal(back3, src)
     ms_sub = compressor.inflate_ms()
     compressor.set_profiling(False)
     print("inflate 64 MiB:", ms, "with sub-index:", ms_sub)
-    back2, status2 = compressor.decompress_tensor(stream, index, data.size)  # deterministic
+    back2, status2 = compressor.decompress_tensor(stream, index, data.size, block_bytes=bb)  # deterministic
     assert status2 == 0 and torch.equal(back2, back)
 
 
@@ -214,14 +242,15 @@ def test_beyond_4_gib_offsets(compressor):
     sub = compressor.last_subindex(device="cuda")
     assert nb > (1 << 30) and int(index[-1]) == nb and bool((index[1:] > index[:-1]).all())
     stream = out[:nb]
-    back, status = compressor.decompress_tensor(stream, index, n, subindex=sub)
+    back, status = compressor.decompress_tensor(stream, index, n, subindex=sub, block_bytes=compressor.last_block_bytes())
     assert status == 0 and torch.equal(back, src)
     del back
-    # the last 3 chunks (beyond 2^32) through zlib as an independent judge
+    # the last strip (beyond 2^32) through zlib as an independent judge
     nseg = index.numel() - 1
-    lo = int(index[nseg - 3])
+    first = (nseg - 1) // 8 * 8  # strips of 8 segments
+    lo = int(index[first])
     tail = stream[lo:nb].cpu().numpy().tobytes()
-    assert zlib.decompress(tail, -15) == src[(nseg - 3) * CHUNK:].cpu().numpy().tobytes()
+    assert zlib.decompress(tail, -15) == src[first * CHUNK:].cpu().numpy().tobytes()
 
 
 def test_corrupted_streams_never_succeed_wrongly(compressor, starfleet):
@@ -230,7 +259,7 @@ def test_corrupted_streams_never_succeed_wrongly(compressor, starfleet):
     code can yield another valid stream).  Nothing may crash or run away."""
     rng = np.random.default_rng(31337)
     data = np.frombuffer(starfleet, np.uint8)
-    stream = np.frombuffer(compressor.compress(data, strategy="dynamic"), np.uint8).copy()
+    stream = np.frombuffer(compressor.compress(data, strategy="dynamic", block_bytes=65536), np.uint8).copy()
     idx, sub = compressor.last_index(), compressor.last_subindex()
     agree = 0
     for it in range(60):
@@ -239,7 +268,7 @@ def test_corrupted_streams_never_succeed_wrongly(compressor, starfleet):
             bad[int(rng.integers(0, bad.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
         st_ref, w_ref, out_ref = O.decompress(bad, data.size)
         for s in (None, sub):
-            got, st = compressor.decompress(bad, idx, data.size, subindex=s)
+            got, st = compressor.decompress(bad, idx, data.size, subindex=s, block_bytes=65536)
             if st == 0:
                 # the serial decoder must then also succeed with the same bytes (it reads the same blocks)
                 assert st_ref == 0 and w_ref == data.size and got == out_ref[: data.size].tobytes(), (it, s is not None)
@@ -292,8 +321,9 @@ def test_fuzz_decoder_on_zlib_and_own_streams(compressor):
         index = np.concatenate([[0], np.cumsum([len(p) for p in zs])]).astype(np.uint64)
         got, st = compressor.decompress(b"".join(zs), index, data.size)
         assert st == 0 and got == data.tobytes(), (it, total, level, strat)
-        own = compressor.compress(data, strategy=["auto", "dynamic", "fixed"][it % 3])
+        bb = [32768, 65536, 131072][it % 3]
+        own = compressor.compress(data, strategy=["auto", "dynamic", "fixed"][it % 3], block_bytes=bb)
         idx, sub = compressor.last_index(), compressor.last_subindex()
         for s in (None, sub):
-            got, st = compressor.decompress(own, idx, data.size, subindex=s)
-            assert st == 0 and got == data.tobytes(), (it, total, s is not None)
+            got, st = compressor.decompress(own, idx, data.size, subindex=s, block_bytes=bb)
+            assert st == 0 and got == data.tobytes(), (it, total, s is not None, bb)

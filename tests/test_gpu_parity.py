@@ -15,8 +15,10 @@ pytestmark = pytest.mark.gpu
 CHUNK = 32768
 
 
-def _params(strategy="auto", final_stream=True, lazy=True):
-    return O.default_params(strategy=_capi.STRATEGY[strategy], final_stream=int(final_stream), lazy=3 if lazy is True else int(lazy))
+def _params(strategy="auto", final_stream=True, lazy=True, block_bytes=0):
+    """The oracle parameters that stand for the library's options (block_bytes 0 = the default rule of both)."""
+    return O.default_params(strategy=_capi.STRATEGY[strategy], final_stream=int(final_stream), lazy=3 if lazy is True else int(lazy),
+                            strip_bytes=block_bytes)
 
 
 def _inputs(starfleet):
@@ -58,35 +60,64 @@ def test_bit_exact_vs_oracle(compressor, starfleet, strategy):
         assert np.array_equal(got, want), f"{name}/{strategy}: first diff at {np.flatnonzero(got != want)[:4]}"
 
 
+@pytest.mark.parametrize("block_bytes", [32768, 65536, 262144, 1 << 20])
+def test_block_bytes_bit_exact_vs_oracle(compressor, starfleet, block_bytes):
+    """sfh_options.block_bytes (the strip that is coded independently): the window slides across the strip's
+    DEFLATE blocks, the stream still equals the specification's and round-trips; larger strips are never worse."""
+    text = synth.gen_text(40 * CHUNK + 321, seed=12)
+    cases = {"text": text, "mixed": synth.gen_mixed(3 << 20, seed=4, stripe=1 << 16)[: (2 << 20) + 13],
+             "starfleet": np.frombuffer(starfleet, np.uint8), "zeros": np.zeros(9 * CHUNK + 5, np.uint8),
+             "rand_then_text": np.concatenate([np.random.default_rng(3).integers(0, 256, 2 * CHUNK, dtype=np.uint8), text[: 3 * CHUNK]])}
+    for name, data in cases.items():
+        for strategy in ("auto", "fixed"):
+            got = np.frombuffer(compressor.compress(data, strategy=strategy, block_bytes=block_bytes), np.uint8)
+            assert compressor.last_block_bytes() == block_bytes
+            want = O.compress(data, _params(strategy, block_bytes=block_bytes))
+            assert np.array_equal(got, want), f"{name}/{strategy}/{block_bytes}"
+            _roundtrip(got, data)
+    small = len(compressor.compress(text, block_bytes=32768))
+    assert len(compressor.compress(text, block_bytes=block_bytes)) <= small
+    with pytest.raises(Exception):
+        compressor.compress(text, block_bytes=32768 + 512)  # not a multiple of 32 KiB
+
+
+def test_default_block_bytes_rule(compressor):
+    """block_bytes = 0 stands for a function of the input size alone (the oracle and the library share the rule)."""
+    for n in (0, 1, CHUNK, 50 * CHUNK, (8 << 20) + 5, 16 << 20, (64 << 20) + 1):
+        data = np.zeros(n, np.uint8)
+        compressor.compress(data, strategy="stored")
+        assert compressor.last_block_bytes() == _capi.resolve_block_bytes(0, n) == O.resolve_strip_bytes(O.default_params(), n), n
+
+
 def test_stage_parity(compressor, starfleet):
-    """tokens / histogram / code lengths / plan of every chunk against the oracle stages."""
-    data = np.frombuffer(starfleet, np.uint8)
-    p = _params()
-    compressor.compress(data)
-    nchunks = (data.size + CHUNK - 1) // CHUNK
-    ntok = compressor.debug(_capi.DBG_NTOK, nchunks)
-    toks = compressor.debug(_capi.DBG_TOKENS, nchunks)
-    hist = compressor.debug(_capi.DBG_HIST, nchunks)
-    lens = compressor.debug(_capi.DBG_LENS, nchunks)
-    plan = compressor.debug(_capi.DBG_PLAN, nchunks)
-    for c in range(nchunks):
-        d = data[c * CHUNK:(c + 1) * CHUNK]
-        ln, ds = O.match_chunk(d, p)
-        t, nt = O.parse_chunk(d, p, ln, ds)
-        flat = np.concatenate([t[r * p.region_bytes: r * p.region_bytes + nt[r]] for r in range(nt.size)])
-        assert ntok[c] == flat.size, f"chunk {c}: ntok"
-        # bit 30 + bits 24..28 are k_lz77 -> k_emit transport only: "first token of parse region r" (sub-index)
-        assert np.array_equal(toks[c, : flat.size] & np.uint32(0x80FFFFFF), flat), f"chunk {c}: tokens"
-        starts = np.concatenate([[0], np.cumsum(nt)[:-1]]).astype(np.int64)
-        flagged = np.flatnonzero(toks[c, : flat.size] & np.uint32(0x40000000))
-        assert np.array_equal(flagged, starts[nt > 0]), f"chunk {c}: region flags"
-        assert np.array_equal((toks[c, flagged] >> 24) & 31, np.flatnonzero(nt > 0)), f"chunk {c}: region ids"
-        ll, dd = O.histogram(t, nt, p.region_bytes)
-        assert np.array_equal(hist[c, :286], ll) and np.array_equal(hist[c, 288:318], dd), f"chunk {c}: hist"
-        pl = O.plan_chunk(ll, dd, d.size, c + 1 == nchunks, p)
-        assert np.array_equal(lens[c, :288], np.frombuffer(pl.ll_lens, np.uint8)), f"chunk {c}: ll lens"
-        assert np.array_equal(lens[c, 288:320], np.frombuffer(pl.d_lens, np.uint8)), f"chunk {c}: d lens"
-        assert plan[c, 0] == pl.btype and plan[c, 1] == pl.out_bytes, f"chunk {c}: plan {plan[c]} vs {pl.btype},{pl.out_bytes}"
+    """tokens / histogram / code lengths / plan of every chunk against the oracle stages (strips of two chunks:
+    the second chunk of a strip matches into the first)."""
+    data = np.concatenate([np.frombuffer(starfleet, np.uint8), synth.gen_text(3 * CHUNK + 99, seed=13)])
+    for block_bytes in (2 * CHUNK, 0):
+        p = _params(block_bytes=block_bytes)
+        compressor.compress(data, block_bytes=block_bytes)
+        nchunks = (data.size + CHUNK - 1) // CHUNK
+        ntok = compressor.debug(_capi.DBG_NTOK, nchunks)
+        toks, flags = compressor.debug_tokens(nchunks)
+        hist = compressor.debug(_capi.DBG_HIST, nchunks)
+        lens = compressor.debug(_capi.DBG_LENS, nchunks)
+        plan = compressor.debug(_capi.DBG_PLAN, nchunks)
+        ref = O.chunk_tokens(data, p)
+        assert len(ref) == nchunks
+        per_sub = 1024 // p.region_bytes  # parse regions per sub-index entry
+        for c in range(nchunks):
+            flat, nt, tarr = ref[c]
+            assert ntok[c] == flat.size == toks[c].size, f"chunk {c}: ntok"
+            assert np.array_equal(toks[c], flat), f"chunk {c}: tokens"
+            # the first token of every 1024 bytes is flagged with its index (sub-index transport, k_lz77 -> k_emit)
+            starts = np.concatenate([[0], np.cumsum(nt)[:-1]]).astype(np.int64)[::per_sub]
+            assert flags[c] == [(int(k), r) for r, k in enumerate(starts)], f"chunk {c}: region flags"
+            ll, dd = O.histogram(tarr, nt, p.region_bytes)
+            assert np.array_equal(hist[c, :286], ll) and np.array_equal(hist[c, 288:318], dd), f"chunk {c}: hist"
+            pl = O.plan_chunk(ll, dd, min(CHUNK, data.size - c * CHUNK), c + 1 == nchunks, p)
+            assert np.array_equal(lens[c, :288], np.frombuffer(pl.ll_lens, np.uint8)), f"chunk {c}: ll lens"
+            assert np.array_equal(lens[c, 288:320], np.frombuffer(pl.d_lens, np.uint8)), f"chunk {c}: d lens"
+            assert plan[c, 0] == pl.btype and plan[c, 1] == pl.out_bytes, f"chunk {c}: plan {plan[c]} vs {pl.btype},{pl.out_bytes}"
 
 
 def test_lazy_levels(compressor, starfleet):
@@ -114,6 +145,10 @@ def test_stored_fast_path(compressor):
             assert np.array_equal(got, want)
             _roundtrip(got, data)
     assert len(compressor.compress(rnd)) == rnd.size + 5 * 6  # six stored blocks
+    # a skipped block is not inserted into the hash tables either: the next block of the strip sees none of it
+    two = np.concatenate([rnd[:CHUNK], rnd[:CHUNK]])
+    assert np.array_equal(np.frombuffer(compressor.compress(two, block_bytes=2 * CHUNK), np.uint8),
+                          O.compress(two, O.default_params(strip_bytes=2 * CHUNK)))
 
 
 def test_device_tensor_path_and_shard_concat(compressor):
@@ -326,8 +361,8 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
     import os
 
     for it in range(int(os.environ.get("SF_FUZZ_N", "300"))):  # SF_FUZZ_N=5000 for a soak run
-        total = int(rng.choice([0, 1, 2, 3, 5, 100, 1023, 1024, 1025, 8191, 8192, 8193, CHUNK - 1, CHUNK, CHUNK + 1,
-                                int(rng.integers(0, 5 * CHUNK))]))
+        total = int(rng.choice([0, 1, 2, 3, 5, 100, 511, 512, 513, 1023, 1024, 1025, 8191, 8192, 8193, CHUNK - 1, CHUNK, CHUNK + 1,
+                                int(rng.integers(0, 5 * CHUNK)), int(rng.integers(0, 9 * CHUNK))]))
         parts, left = [], total
         while left > 0:
             n = int(min(left, rng.integers(1, 20000)))
@@ -338,13 +373,14 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
         strategy = ["auto", "auto", "dynamic", "fixed"][it % 4]
         lazy = [3, 0, 1, 2, 3][it % 5]
         fast = it % 7 != 0
-        got = np.frombuffer(compressor.compress(data, strategy=strategy, lazy=lazy, stored_fast_path=fast), np.uint8)
-        want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=int(fast)))
-        assert np.array_equal(got, want), (it, total, strategy, lazy, fast, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
+        bb = [0, 32768, 65536, 131072][it % 3 if it % 11 else 3]
+        got = np.frombuffer(compressor.compress(data, strategy=strategy, lazy=lazy, stored_fast_path=fast, block_bytes=bb), np.uint8)
+        want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=int(fast), strip_bytes=bb))
+        assert np.array_equal(got, want), (it, total, strategy, lazy, fast, bb, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
         if it % 10 == 0:
             _roundtrip(got, data)
             idx, sub = compressor.last_index(), compressor.last_subindex()
-            back, st = compressor.decompress(got, idx, data.size, subindex=sub)
+            back, st = compressor.decompress(got, idx, data.size, subindex=sub, block_bytes=compressor.last_block_bytes())
             assert st == 0 and back == data.tobytes(), it
 
 
@@ -377,7 +413,7 @@ def test_repeated_calls_do_not_leak_or_drift():
             key = (n, 0, "d")
             if it % 5 == 0:
                 idx, sub = c.last_index(device="cuda"), c.last_subindex(device="cuda")
-                back, st = c.decompress_tensor(out[:nb].clone(), idx, n, subindex=sub)
+                back, st = c.decompress_tensor(out[:nb].clone(), idx, n, subindex=sub, block_bytes=c.last_block_bytes())
                 assert st == 0 and torch.equal(back, big[:n])
         assert ref.setdefault(key, got) == got
     torch.cuda.synchronize()

@@ -88,6 +88,107 @@ def _worker_pipelined(rank, world, port, piece_bytes, K, q, container="raw"):
     dist.destroy_process_group()
 
 
+def _worker_bench_logic(rank, world, port, piece_bytes, K, q):
+    """bench.py's own N > 1 step and verification (run_steps, pipelined_step, verify_pieces, verify_concatenation)
+    over gloo, the compressor replaced by a stub that returns the oracle's stream -- what the driver's
+    `bench.py --gpus N` does, minus the GPU."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    import oracle_lib as O
+    from starflate_amd import synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = torch.from_numpy(synth.gen_text(piece_bytes * K, seed=40 + rank))  # this rank's shard, as bench.py makes it
+    pieces = list(data.chunk(K))
+    bound = O.lib().sfo_compress_bound(piece_bytes, O.default_params())
+    scratch = [torch.zeros(bound, dtype=torch.uint8) for _ in range(K)]
+    gathered = torch.zeros(bound * K * world + 64, dtype=torch.uint8) if rank == 0 else None
+    sizes, result = [0] * K, {}
+
+    def compress_fn(piece, final, k):
+        s = O.compress(piece.numpy(), O.default_params(final_stream=int(final), strip_bytes=65536))
+        scratch[k][: s.size] = torch.from_numpy(s)
+        sizes[k] = s.size
+        return scratch[k], torch.tensor([s.size], dtype=torch.int64)  # the enqueue-only form: size as a tensor
+
+    def step():
+        result["out"], result["total"] = bench.pipelined_step(compress_fn, pieces, gathered)
+
+    dt = bench.run_steps(step, dist.barrier, 2, 1)
+    ok, crcs = bench.verify_pieces(pieces, scratch, sizes, -15)
+    crc = torch.tensor(crcs, dtype=torch.int64)
+    allc = [torch.zeros(K, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allc, crc)
+    if rank == 0:
+        whole_ok = bench.verify_concatenation(result["out"][: result["total"]].numpy().tobytes(), -15, piece_bytes * K * world,
+                                              piece_bytes, [c.tolist() for c in allc])
+        q.put((ok, whole_ok, dt > 0, int(result["total"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _worker_bad_args(rank, world, port, q):
+    """A check that fails on one rank only (rank 0's `out` is too small) raises on EVERY rank, before any
+    stream moves -- nobody is left waiting in a collective."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from starflate_amd import multigpu
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pieces = [torch.zeros(32768, dtype=torch.uint8)]
+    raised = False
+    try:
+        multigpu.compress_pipelined(lambda p, f, k: (torch.zeros(10, dtype=torch.uint8), 5), pieces,
+                                    out=torch.zeros(16, dtype=torch.uint8) if rank == 0 else None, bound_fn=lambda n: n + 100)
+    except ValueError:
+        raised = True
+    try:
+        multigpu.compress_pipelined(lambda p, f, k: (torch.zeros(10, dtype=torch.uint8), 5), pieces, container="gzip")
+    except ValueError:
+        raised = raised and True
+    else:
+        raised = False
+    q.put((rank, raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_and_verify_logic_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world, piece, K = 2, 2 * 65536, 2
+    procs = [ctx.Process(target=_worker_bench_logic, args=(r, world, port, piece, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok, whole_ok, timed, total = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok and whole_ok and timed and total > 0
+
+
+def test_argument_errors_raise_on_every_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bad_args, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == [(0, True), (1, True)]
+
+
 @pytest.mark.parametrize("world,K,container", [(2, 3, "gzip"), (2, 1, "zlib"), (3, 2, "zlib")])
 def test_pipelined_wrapped_gloo(world, K, container):
     """Shard checksums travel with the sizes and are combined in global piece order on every rank;
