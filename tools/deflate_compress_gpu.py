@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Drop-in for the reference's fixture generator (/root/reference/tools/deflate_compress.py: --src FILE [--fixed],
 raw DEFLATE on stdout), producing the stream with the MI355X kernels instead of zlib.  Extra switches: --zlib /
---gzip put back the wrapper that tool strips; --index FILE additionally saves the block index and region
-sub-index (numpy .npz) that let `decompress()` run on the GPU."""
+--gzip put back the wrapper that tool strips; --block-bytes N sets the independently coded strip (sfh_options.block_bytes);
+--index FILE additionally saves the block index, the region sub-index and the strip size (numpy .npz) that let
+`decompress()` run on the GPU."""
 import argparse
 import os
 import sys
@@ -19,9 +20,10 @@ def main(args):
         data = f.read()
     comp = Compressor(args.device)
     container = "zlib" if args.zlib else "gzip" if args.gzip else "raw"
-    out = comp.compress(data, strategy="fixed" if args.fixed else "auto", container=container)
+    out = comp.compress(data, strategy="fixed" if args.fixed else "auto", container=container, block_bytes=args.block_bytes)
     if args.index:
-        np.savez(args.index, offsets=comp.last_index(), regions=comp.last_subindex(), size=np.uint64(len(data)))
+        np.savez(args.index, offsets=comp.last_index(), regions=comp.last_subindex(), size=np.uint64(len(data)),
+                 block_bytes=np.uint32(comp.last_block_bytes()))
     sys.stdout.buffer.write(out)
 
 
@@ -31,6 +33,7 @@ parser.add_argument("--fixed", help="use fixed strategy", action="store_true")
 parser.add_argument("--zlib", help="RFC 1950 wrapper", action="store_true")
 parser.add_argument("--gzip", help="RFC 1952 wrapper", action="store_true")
 parser.add_argument("--index", help="save block index + sub-index to this .npz")
+parser.add_argument("--block-bytes", type=int, default=0, help="strip size, a multiple of 32768 (0: the library's default)")
 parser.add_argument("--device", type=int, default=0)
 
 if __name__ == "__main__":
