@@ -202,7 +202,7 @@ enum sfh_debug_what {
   SFH_DBG_ITEMS = 8,  /* compressor: uint16[32768] per chunk, first nitems valid (literal: byte; match: 0x8000 | len-3,
                          then dist-1; 0x4000 + region index in bits 8..12 on a parse region's first item) */
   SFH_DBG_NITEMS = 9, /* uint32 per chunk */
-  SFH_DBG_HIST = 2,   /* uint32[320] per chunk: ll[0..285], d at [288..317] */
+  SFH_DBG_HIST = 2,   /* uint32[576] per chunk: ll[0..285], d at [288..317], raw len-3 counts at [320..575] */
   SFH_DBG_PLAN = 3,   /* uint32[4] per chunk: btype, out_bytes, header_bits, body_bits */
   SFH_DBG_LENS = 4,   /* uint8[320] per chunk: ll lens [0..287], d lens [288..319] */
   SFH_DBG_OFFSETS = 5, /* uint64 per chunk */

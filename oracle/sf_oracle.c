@@ -486,6 +486,11 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
       }
     /* candidate evaluation */
     for (uint32_t i = b; i < e; i++) {
+      uint32_t shift = 0; /* analysis knob: only one parity is searched ... */
+      if (p->x_stride2 && (i & 1) != (p->x_stride2 & 1)) {
+        if (!(p->x_stride2 & 4) || i + 1 >= e) continue;
+        shift = 1; /* ... the other tries its successor's candidates, moved back by one */
+      }
       uint32_t rend = (i / R + 1) * R;
       uint32_t maxlen = n - i < 258 ? n - i : 258;
       if (rend - i < maxlen) maxlen = rend - i;
@@ -493,16 +498,16 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
       uint32_t best = 0, bdist = 0;
       for (uint32_t t = 0; t < NT; t++) {
         uint32_t need = t ? LB : MM;
-        if (i + need > n) continue;
-        uint32_t h = t ? hash_long(d + i, p) : hash_of(load32(d + i), p);
+        if (i + shift + need > n) continue;
+        uint32_t h = t ? hash_long(d + i + shift, p) : hash_of(load32(d + i + shift), p);
         uint32_t cand[8], nc = 0;
         if (t ? p->x_long_near : p->use_near) {
           uint32_t c = ent_pos(T[(t * D) * HS + h], W);
-          if (c < i) cand[nc++] = c;
+          if (c < i + shift && c >= shift) cand[nc++] = c - shift;
         }
         for (uint32_t k = 0; k < (t && p->x_long_levels ? p->x_long_levels : D); k++) {
-          uint32_t v = far[((i - b) * NT + t) * D + k];
-          if (v) cand[nc++] = ent_pos(v, W);
+          uint32_t v = far[((i + shift - b) * NT + t) * D + k];
+          if (v && ent_pos(v, W) >= shift) cand[nc++] = ent_pos(v, W) - shift;
         }
         for (uint32_t k = 0; k < nc; k++) {
           uint32_t dist = i - cand[k];
@@ -517,6 +522,20 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
        * distance code + up to 13 extra bits): drop it */
       if (p->far4_dist && best == 4 && bdist > p->far4_dist) best = 0;
       if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)bdist; }
+    }
+    if (p->x_stride2 && !(p->x_stride2 & 4)) {
+      /* the other parity inherits its successor's match, one byte longer, when the byte before it matches too */
+      for (uint32_t i = b; i < e; i++) {
+        if ((i & 1) == (p->x_stride2 & 1) || i + 1 >= n || (i + 1) % R == 0) continue;
+        if (i + 1 >= e) continue; /* successor belongs to the next step: not known yet */
+        uint32_t l = len16[i + 1], dd = dist16[i + 1];
+        if (l && dd <= i && d[i] == d[i - dd]) {
+          uint32_t nl = l + 1;
+          if (p->cap && nl > p->cap) nl = p->cap;
+          len16[i] = (uint16_t)nl;
+          dist16[i] = (uint16_t)dd;
+        }
+      }
     }
   }
 }

@@ -107,6 +107,7 @@ typedef struct sfo_params {
   uint32_t rank_bytes;   /* >0: a position's candidates are ranked by min(match length, rank_bytes) (ties: smallest
                             distance); only the winner is then compared up to `cap` bytes.  0: all compared to `cap` */
   uint32_t x_window;     /* analysis knob: 0 = SFO_WINDOW */
+  uint32_t x_stride2;    /* analysis knob: 1 / 2 = only odd / even positions are searched, the others inherit */
 } sfo_params;
 
 #define SFO_WINDOW 32768u

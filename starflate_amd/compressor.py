@@ -218,7 +218,7 @@ class Compressor:
         shapes = {
             _capi.DBG_NTOK: ((nchunks,), np.uint32),
             _capi.DBG_TOKENS: ((nchunks, CHUNK_BYTES), np.uint32),
-            _capi.DBG_HIST: ((nchunks, 320), np.uint32),
+            _capi.DBG_HIST: ((nchunks, 576), np.uint32),  # ll at 0, d at 288, raw len-3 counts at 320
             _capi.DBG_PLAN: ((nchunks, 4), np.uint32),
             _capi.DBG_LENS: ((nchunks, 320), np.uint8),
             _capi.DBG_OFFSETS: ((nchunks,), np.uint64),

@@ -46,8 +46,9 @@ constexpr uint32_t kChecksumAdler32 = 1;  // = SFH_ZLIB
 constexpr uint32_t kChecksumCrc32 = 2;    // = SFH_GZIP
 constexpr uint32_t kCrcPoly = 0xEDB88320u;  // RFC 1952 section 8, reflected
 
-constexpr uint32_t kHistStride = 320;   // ll[0..285] at 0, d[0..29] at 288
+constexpr uint32_t kHistStride = 576;   // ll[0..285] at 0, d[0..29] at 288, raw len-3 counts [0..255] at 320
 constexpr uint32_t kHistD = 288;
+constexpr uint32_t kHistLen = 320;      // k_lz77 counts match lengths raw; k_plan folds them into ll[257..285]
 constexpr uint32_t kHeaderWords = 152;  // 608 bytes >= 4495-bit worst-case dynamic header + 3
 
 // per-chunk plan record written by K2, read by K3/K4

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
   };
   if constexpr (STAMPS) st_t = __builtin_amdgcn_s_memtime();
 
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // static LDS (its address is a compile-time constant: no base register, no add per access)
+  __shared__ __attribute__((aligned(16))) uint8_t smem[K1_LDS];
   uint32_t* s_data = reinterpret_cast<uint32_t*>(smem + L_DATA);
   uint8_t* s_bytes = smem + L_DATA;
   uint32_t* s_len4 = reinterpret_cast<uint32_t*>(smem + L_LEN4);
@@ -443,20 +444,14 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       const uint32_t mine = (uint32_t)__popc(marks) | ((uint32_t)__popc(cm) << 16);
       const uint32_t incl = wave_incl_add(mine);
       if (lane == 63) s_wtot[wave] = incl;
-      __syncthreads();
-      uint32_t wbase = 0, rtotal = 0;
+      if (!(dbg & 4)) __syncthreads();  // dbg 4: timing experiment only (wrong item offsets)
+      uint32_t wbase, rtotal;
       {
-        const uint4* w4 = reinterpret_cast<const uint4*>(s_wtot);
-#pragma unroll
-        for (uint32_t q = 0; q < K1_WAVES / 4; ++q) {
-          const uint4 v = w4[q];
-          const uint32_t e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (uint32_t k = 0; k < 4; ++k) {
-            rtotal += e[k];
-            wbase += (4 * q + k < wave) ? e[k] : 0u;
-          }
-        }
+        // totals of the waves before this one, and of all: one scan over the sixteen entries
+        const uint32_t w = lane < K1_WAVES ? s_wtot[lane] : 0u;
+        const uint32_t wi = wave_incl_add(w);
+        rtotal = (uint32_t)__builtin_amdgcn_readlane((int)wi, K1_WAVES - 1);
+        wbase = (uint32_t)__builtin_amdgcn_readlane((int)(wi - w), (int)wave);
       }
       // tokens before each 1024-byte sub-index region (two waves): where the decoder's region lanes start
       if ((wave & (kSubBytes / kRegion - 1)) == 0 && lane == 0)
@@ -481,12 +476,12 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             if (l3 == kCap - 3) l3 = cap_len - 3;    // capped match: the walk extended it
             const uint32_t d1 = ((dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) - 1;
             const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
-            uint32_t eb, ev;
-            const uint32_t sym = isM ? len_symbol(l3, eb, ev) : b;
+            const uint32_t sym = isM ? kHistLen + l3 : b;  // match lengths are counted raw: k_plan folds them into symbols
             if (!(dbg & 2)) gi[idx] = (uint16_t)((isM ? (kItemMatch | l3) : b) | flag);
             if (!(dbg & 1)) atomicAdd(&s_hist[sym], 1u);
             if (isM) {
               if (!(dbg & 2)) gi[idx + 1] = (uint16_t)d1;
+              uint32_t eb, ev;
               if (!(dbg & 1)) atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
             }
             idx += isM ? 2u : 1u;
@@ -796,7 +791,7 @@ __device__ uint32_t rle_parallel(PlanSmem& S, const uint8_t* lens, uint32_t n, u
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
-                                             const uint32_t* __restrict__ hist,
+                                             uint32_t* __restrict__ hist,
                                              ChunkPlan* __restrict__ plan, ChunkCodes* __restrict__ codes,
                                              uint32_t strategy, uint32_t final_stream,
                                              uint64_t* __restrict__ stamps) {
@@ -821,6 +816,14 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   for (uint32_t s = lane; s < kHistStride; s += 64) S.freq[s] = hist[(uint64_t)chunk * kHistStride + s];
   for (uint32_t s = lane; s < 320; s += 64) S.lens[s] = 0;
   __syncthreads();
+  // k_lz77 counted match lengths raw (len-3 at kHistLen + 0..255): fold them into the length symbols 257..285
+  for (uint32_t l3 = lane; l3 < 256; l3 += 64) {
+    const uint32_t f = S.freq[kHistLen + l3];
+    uint32_t eb, ev;
+    if (f) atomicAdd(&S.freq[len_symbol(l3, eb, ev)], f);
+  }
+  __syncthreads();
+  if (lane < 29) hist[(uint64_t)chunk * kHistStride + 257 + lane] = S.freq[257 + lane];  // the folded counts, for parity tests
 
   stamp();  // 0 load
   build_lengths<5>(S, S.freq, 286, 15, S.lens, lane);
@@ -1229,22 +1232,10 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-hipError_t init_kernels() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz77<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz77<true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
+hipError_t init_kernels() { return hipSuccess; }
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
                        const Options& opt, hipStream_t s) {
-  // diagnostic: SFH_K1_EXTRA_LDS=<bytes> inflates the LDS request (e.g. 16384 -> one workgroup per CU)
-  static const uint32_t extra = [] {
-    const char* e = getenv("SFH_K1_EXTRA_LDS");
-    return e ? (uint32_t)atoi(e) : 0u;
-  }();
-  const uint32_t K1_LDS = sf::K1_LDS + extra;
   static const uint32_t dbg = [] {
     const char* e = getenv("SFH_K1_DBG");
     return e ? (uint32_t)atoi(e) : 0u;
@@ -1253,10 +1244,10 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
   const uint32_t per = opt.strip_bytes / kChunk;
   const uint32_t nstrips = (nchunks + per - 1) / per;
   if (ws.stamps)
-    hipLaunchKernelGGL(k_lz77<true>, dim3(nstrips), dim3(K1_THREADS), K1_LDS, s, src, n, opt.strip_bytes, ws.items,
+    hipLaunchKernelGGL(k_lz77<true>, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items,
                        ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, ws.stamps, dbg);
   else
-    hipLaunchKernelGGL(k_lz77<false>, dim3(nstrips), dim3(K1_THREADS), K1_LDS, s, src, n, opt.strip_bytes, ws.items,
+    hipLaunchKernelGGL(k_lz77<false>, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items,
                        ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, (uint64_t*)nullptr, dbg);
   return hipGetLastError();
 }

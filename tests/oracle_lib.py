@@ -37,6 +37,7 @@ class Params(C.Structure):
         ("x_long_near", C.c_uint32),
         ("rank_bytes", C.c_uint32),
         ("x_window", C.c_uint32),
+        ("x_stride2", C.c_uint32),
     ]
 
 
