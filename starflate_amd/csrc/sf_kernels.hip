@@ -533,10 +533,12 @@ __device__ __forceinline__ void or_bits(uint32_t* stage, uint32_t bitpos, uint64
   if (v2) atomicOr(&stage[w + 2], v2);
 }
 
+// 6 KiB per workgroup (one wave): the CU holds as many chunks in flight as its wave slots allow, which is what a
+// latency-bound kernel wants.  Node weights fit 16 bits (a chunk has at most kChunk tokens + the end-of-block).
 struct PlanSmem {
-  uint32_t freq[kHistStride];
-  uint32_t key[288];
-  uint32_t w[576];
+  uint32_t freq[320];  // ll [0..285], d [288..317]
+  uint32_t key[288];   // sorted (freq << 9 | symbol); entries 32.. double as the header bit image (see kHeaderAt)
+  uint16_t w[576];
   uint16_t parent[576];
   uint32_t cnt[16];
   uint8_t lens[320];  // ll [0..287], d [288..319]
@@ -545,9 +547,13 @@ struct PlanSmem {
   uint32_t clfreq[32];
   uint8_t rle_sym[320];
   uint8_t rle_ext[320];
-  uint32_t header[kHeaderWords];
   uint32_t misc[8];
 };
+// The header image is built after the literal/length and distance trees are done; the code-length tree that is
+// built in between only touches key[0..18].
+constexpr uint32_t kHeaderAt = 32;
+static_assert(kHeaderAt + kHeaderWords <= 288 && kHeaderAt >= 19, "header image inside key[]");
+static_assert(kChunk + 1 <= 65535, "node weights are 16 bits");
 
 // Length-limited Huffman code lengths; all 64 lanes call it.  Specification (DESIGN.md,
 // "code lengths"): two-queue Huffman, clamp, Kraft repair, lengths dealt longest-first
@@ -596,7 +602,7 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
   for (uint32_t g = 0; g < NG; ++g)
     if (key[g] != 0xFFFFFFFFu) S.key[rank[g]] = key[g];
   __syncthreads();
-  for (uint32_t k = lane; k < m; k += 64) S.w[k] = S.key[k] >> 9;
+  for (uint32_t k = lane; k < m; k += 64) S.w[k] = (uint16_t)(S.key[k] >> 9);
   __syncthreads();
   // two-queue merge (serial; leaves first on ties).  Both queues are consumed in index order,
   // so their next heads are fetched from LDS two picks ahead of use.
@@ -612,7 +618,7 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
       if (a0 <= b0) { y = i++; wy = a0; a0 = a1; a1 = a2; a2 = i + 2 < m ? S.w[i + 2] : INF; }
       else          { y = j++; wy = b0; b0 = b1; b1 = j + 1 < k ? S.w[j + 1] : INF; }
       const uint32_t sum = wx + wy;
-      S.w[k] = sum;
+      S.w[k] = (uint16_t)sum;
       S.parent[x] = (uint16_t)k;
       S.parent[y] = (uint16_t)k;
       if (j == k) b0 = sum;          // the new node is the internal queue's head ...
@@ -796,6 +802,7 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
                                              uint32_t strategy, uint32_t final_stream,
                                              uint64_t* __restrict__ stamps) {
   __shared__ PlanSmem S;
+  uint32_t* const s_header = S.key + kHeaderAt;
   // diagnostic (stamps != nullptr, SFH_K1_STAMPS=1): cycles per phase at stamps[chunk*8 + 8*nchunks..]
   uint64_t st_t = stamps ? __builtin_amdgcn_s_memtime() : 0;
   uint32_t st_k = 0;
@@ -813,12 +820,12 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   const uint32_t n_raw = (uint32_t)((n_total - cbase) < (uint64_t)kChunk ? (n_total - cbase) : kChunk);
   const bool fin = (chunk + 1 == nchunks) && final_stream;
 
-  for (uint32_t s = lane; s < kHistStride; s += 64) S.freq[s] = hist[(uint64_t)chunk * kHistStride + s];
+  for (uint32_t s = lane; s < 320; s += 64) S.freq[s] = hist[(uint64_t)chunk * kHistStride + s];
   for (uint32_t s = lane; s < 320; s += 64) S.lens[s] = 0;
   __syncthreads();
   // k_lz77 counted match lengths raw (len-3 at kHistLen + 0..255): fold them into the length symbols 257..285
   for (uint32_t l3 = lane; l3 < 256; l3 += 64) {
-    const uint32_t f = S.freq[kHistLen + l3];
+    const uint32_t f = hist[(uint64_t)chunk * kHistStride + kHistLen + l3];
     uint32_t eb, ev;
     if (f) atomicAdd(&S.freq[len_symbol(l3, eb, ev)], f);
   }
@@ -854,7 +861,7 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
 
   // dynamic header: HLIT/HDIST, RLE, code-length code -- all wave-parallel
   if (lane < 32) S.clfreq[lane] = 0;
-  for (uint32_t k = lane; k < kHeaderWords; k += 64) S.header[k] = 0;
+  for (uint32_t k = lane; k < kHeaderWords; k += 64) s_header[k] = 0;
   __syncthreads();
   uint32_t hlit, hdist;
   {
@@ -879,8 +886,8 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
     hclen = hclen < 4 ? 4u : hclen;
     // BFINAL, BTYPE=10, HLIT, HDIST, HCLEN: 17 bits; then hclen 3-bit code-length-code lengths
     if (lane == 0)
-      or_bits(S.header, 0, (uint64_t)((fin ? 1u : 0u) | (2u << 1) | ((hlit - 257) << 3) | ((hdist - 1) << 8) | ((hclen - 4) << 13)));
-    if (lane < hclen) or_bits(S.header, 17 + 3 * lane, (uint64_t)S.cl_lens[c_cl_order[lane]]);
+      or_bits(s_header, 0, (uint64_t)((fin ? 1u : 0u) | (2u << 1) | ((hlit - 257) << 3) | ((hdist - 1) << 8) | ((hclen - 4) << 13)));
+    if (lane < hclen) or_bits(s_header, 17 + 3 * lane, (uint64_t)S.cl_lens[c_cl_order[lane]]);
     uint32_t bitbase = 17 + 3 * hclen;
 #pragma unroll
     for (uint32_t g = 0; g < 5; ++g) {
@@ -897,7 +904,7 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
         nb = cl + eb;
       }
       const uint32_t incl = wave_incl_scan(nb, lane);
-      if (nb) or_bits(S.header, bitbase + incl - nb, v);
+      if (nb) or_bits(s_header, bitbase + incl - nb, v);
       bitbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     if (lane == 0) S.misc[3] = bitbase;  // includes the 3 block-header bits
@@ -927,16 +934,16 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   __syncthreads();
   if (bt == 1) {
     for (uint32_t s = lane; s < 320; s += 64) S.lens[s] = s < 288 ? (uint8_t)fixed_ll_len(s) : (uint8_t)5;
-    if (lane == 0) S.header[0] = (fin ? 1u : 0u) | (1u << 1);
+    if (lane == 0) s_header[0] = (fin ? 1u : 0u) | (1u << 1);
     __syncthreads();
   } else if (bt == 0) {
-    if (lane == 0) S.header[0] = fin ? 1u : 0u;
+    if (lane == 0) s_header[0] = fin ? 1u : 0u;
     __syncthreads();
   }
   canonical_codes(S.lens, 288, C.lcode, lane);
   canonical_codes(S.lens + 288, 32, C.dcode, lane);
   const uint32_t hbits = bt == 2 ? dyn_hbits : 3;
-  for (uint32_t k = lane; k < (hbits + 31) / 32; k += 64) C.header[k] = S.header[k];
+  for (uint32_t k = lane; k < (hbits + 31) / 32; k += 64) C.header[k] = s_header[k];
   if (lane == 0) {
     ChunkPlan P;
     P.btype = bt;
@@ -1006,16 +1013,21 @@ __device__ __forceinline__ void literal_bits(uint32_t byte, const uint32_t* lcod
   value = lc & 0xFFFF;
   nb = lc >> 16;
 }
-__device__ __forceinline__ void match_bits(uint32_t l3, uint32_t d1, const uint32_t* lcode, const uint32_t* dcode,
+// lenlut[l3] = the length code of len-3 with its extra bits appended (value in bits 0..23, bit count in 24..28):
+// built once per chunk from the chunk's code, one LDS read per match instead of the symbol arithmetic
+__device__ __forceinline__ uint32_t lenlut_entry(uint32_t l3, const uint32_t* lcode) {
+  uint32_t le, lv;
+  const uint32_t lc = lcode[len_symbol(l3, le, lv)];
+  const uint32_t p = lc >> 16;
+  return (lc & 0xFFFFu) | (lv << p) | ((p + le) << 24);
+}
+__device__ __forceinline__ void match_bits(uint32_t l3, uint32_t d1, const uint32_t* lenlut, const uint32_t* dcode,
                                            uint64_t& value, uint32_t& nb) {
-  uint32_t le, lv, de, dv;
-  const uint32_t ls = len_symbol(l3, le, lv);
+  uint32_t de, dv;
   const uint32_t ds = dist_symbol(d1, de, dv);
-  const uint32_t lc = lcode[ls], dc = dcode[ds];
-  uint32_t p = lc >> 16;
-  uint64_t v = lc & 0xFFFF;
-  v |= (uint64_t)lv << p;
-  p += le;
+  const uint32_t le = lenlut[l3], dc = dcode[ds];
+  uint32_t p = le >> 24;
+  uint64_t v = le & 0xFFFFFFu;
   v |= (uint64_t)(dc & 0xFFFF) << p;
   p += dc >> 16;
   v |= (uint64_t)dv << p;
@@ -1037,6 +1049,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[K4_STAGE_WORDS];
   __shared__ uint32_t s_lcode[288];
   __shared__ uint32_t s_dcode[32];
+  __shared__ uint32_t s_lenlut[256];
   __shared__ uint32_t s_wtot[2][K4_WAVES];
   __shared__ uint32_t s_rtok[kSubRegions];
 
@@ -1100,6 +1113,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
     sub[2 * t + 1] = r0;
   }
   __syncthreads();
+  if (t < 256) s_lenlut[t] = lenlut_entry(t, s_lcode);
   {
     uint8_t* sb = reinterpret_cast<uint8_t*>(s_stage) + sh;
     const uint8_t* hb = reinterpret_cast<const uint8_t*>(C.header);
@@ -1119,8 +1133,11 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
   // (reads past nit stay inside the chunk's kChunk-slot item area; they are masked below)
   auto load_batch = [&](uint32_t i0, uint4& q, uint32_t& before, uint32_t& after) {
     q = *reinterpret_cast<const uint4*>(it + i0);
-    before = i0 ? it[i0 - 1] : 0u;
-    after = (i0 + K4_IPT < nit) ? it[i0 + K4_IPT] : 0u;
+    // the neighbouring items sit in the neighbouring lanes' registers; only a wave's edge lanes go to memory
+    before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q.w >> 16), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    after = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q.x & 0xFFFFu), 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+    if (lane == 0) before = i0 ? it[i0 - 1] : 0u;
+    if (lane == 63) after = (i0 + K4_IPT < nit) ? it[i0 + K4_IPT] : 0u;
   };
   uint4 q_next = make_uint4(0, 0, 0, 0);
   uint32_t before_next = 0, after_next = 0;
@@ -1143,7 +1160,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
       val[k] = 0;
       nb[k] = 0;
       if (!cont && i0 + k < nit) {
-        if (cur & kItemMatch) match_bits(cur & 0xFFu, e[k + 2] & 0x7FFFu, s_lcode, s_dcode, val[k], nb[k]);
+        if (cur & kItemMatch) match_bits(cur & 0xFFu, e[k + 2] & 0x7FFFu, s_lenlut, s_dcode, val[k], nb[k]);
         else literal_bits(cur & 0xFFu, s_lcode, val[k], nb[k]);
         if (cur & kItemRegion) starts |= 1u << k;
       }
