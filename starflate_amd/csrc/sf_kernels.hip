@@ -153,6 +153,18 @@ __device__ __forceinline__ uint32_t cmp8(const uint32_t* d32, uint32_t a0, uint3
   return min(base + (f >> 3), 8u);
 }
 
+// The same for ranking candidates: a candidate whose first four bytes differ can never become a match
+// (kMinMatch = 4), so it ranks as 0 whatever its shorter common prefix is -- the result only has to be exact from 4 up.
+__device__ __forceinline__ uint32_t rank8(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t c) {
+  static_assert(kMinMatch == 4, "rank8: the first dword decides whether a candidate counts");
+  const uint32_t cw = c >> 2, csh = c & 3;
+  const uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2];
+  const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
+  const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
+  const uint32_t f = (uint32_t)(__builtin_ffs((int)x1) - 1);  // 0xFFFFFFFF when bytes 4..7 are equal
+  return x0 ? 0u : 4u + min(f >> 3, 4u);
+}
+
 // 16-bit step code -> position relative to the epoch's first step: (sc-1)*1024 + t with
 // v = sc << 10 | (1023 - t); ordered like the specification's ((step+1) << 12) | (4095 - t), so MAX
 // keeps the same winner (the first position of the latest step)
@@ -294,8 +306,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = f1 != 0 && ad - c1 <= kWindow;
         const uint32_t q0 = ok0 ? c0 : ad, q1 = ok1 ? c1 : ad;
         // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
-        const uint32_t l0 = cmp8(s_data, a0, a1, q0);
-        const uint32_t l1 = cmp8(s_data, a0, a1, q1);
+        const uint32_t l0 = rank8(s_data, a0, a1, q0);
+        const uint32_t l1 = rank8(s_data, a0, a1, q1);
         const uint32_t lf0 = ok0 ? l0 : 0u, lf1 = ok1 ? l1 : 0u;
         __syncthreads();  // every far read of this step precedes every insertion of this step
         {
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t nc = entry_pos(nv) + K;
         const bool okn = nv != 0 && nc < ad;
         const uint32_t qnr = okn ? nc : ad;
-        const uint32_t ln = cmp8(s_data, a0, a1, qnr);
+        const uint32_t ln = rank8(s_data, a0, a1, qnr);
         const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
         uint32_t maxlen = (rel < qn) ? (qn - rel < kCap ? qn - rel : kCap) : 0u;
         maxlen = rend - rel < maxlen ? rend - rel : maxlen;
@@ -325,15 +337,14 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           const uint32_t lx = kRank + cmp8(s_data, a2, a3, bq + kRank);
           best = best == kRank ? (lx < maxlen ? lx : maxlen) : best;
         }
-        // a 4-byte match farther than kFar4 costs more bits than four literals: drop it
-        const bool ok = best >= kMinMatch && (p + kMinMatch <= n) && !(best == 4 && bd > kFar4);
-        s_dist[rel] = (uint16_t)(ok ? bd : 0u);
-        // eight lanes' 4-bit lengths -> one dword, gathered with DPP moves (no LDS round trip)
+        // a 4-byte match farther than kFar4 costs more bits than four literals: drop it.  (maxlen <= n - p, so a
+        // position without kMinMatch bytes left cannot reach kMinMatch.)
+        const bool ok = best >= kMinMatch && !(best == 4 && bd > kFar4);
+        s_dist[rel] = (uint16_t)bd;  // only read where the length says there is a match
+        // two lanes' 4-bit lengths -> one byte (the odd lane's value comes over the DPP network)
         uint32_t v = ok ? best - 3 : 0u;
         v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
-        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA /* quad_perm:[2,2,2,2] */, 0xF, 0xF, true) << 8;
-        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104 /* row_shl:4 */, 0xF, 0xF, true) << 16;
-        if ((t & 7) == 0) s_len4[rel >> 3] = v;
+        if ((t & 1) == 0) reinterpret_cast<uint8_t*>(s_len4)[rel >> 1] = (uint8_t)v;
       }
       __syncthreads();
       stamp(1);
