@@ -106,19 +106,20 @@ def traffic_from_profile(kernel):
         return None
 
 
-def secondary_workload(comp, workload, n, dev, block_bytes, steps=3):
-    """MiB/s + ratio of another BASELINE workload (configs[3] / [4] shapes) on this GPU."""
+def secondary_workload(comp, workload, n, dev, block_bytes, steps=3, effort="default", data=None, wl=None):
+    """MiB/s + ratio of another BASELINE workload (configs[3] / [4] shapes), or of the main one at another effort."""
     import torch
 
-    data, wl = make_input(workload, n, 0, dev)
+    if data is None:
+        data, wl = make_input(workload, n, 0, dev)
     out = torch.empty(comp.compress_bound(n), dtype=torch.uint8, device=dev)
     nb = 0
     for _ in range(2):
-        _, nb = comp.compress_tensor(data, out=out, block_bytes=block_bytes)
+        _, nb = comp.compress_tensor(data, out=out, block_bytes=block_bytes, effort=effort)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        _, nb = comp.compress_tensor(data, out=out, block_bytes=block_bytes)
+        _, nb = comp.compress_tensor(data, out=out, block_bytes=block_bytes, effort=effort)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     zs = min(n, 32 << 20)
@@ -139,6 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=1 << 30, help="input bytes per GPU")
     ap.add_argument("--workload", default="text", choices=["text", "random", "mixed"])
+    ap.add_argument("--effort", default="default", choices=["default", "fast"], help="sfh_options.effort of the timed steps")
     ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default, 256 KiB at this size)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -200,12 +202,12 @@ def main():
                 ms[name] = ms.get(name, 0.0) + v
 
         if not multi:
-            out, total = comp.compress_tensor(data, out=scratch[0], container=args.container, block_bytes=bb)
+            out, total = comp.compress_tensor(data, out=scratch[0], container=args.container, block_bytes=bb, effort=args.effort)
             account()
             result["sizes"] = [total]
         else:
             def compress_fn(piece, final, k):  # enqueue only: the size stays on the device until the gather reads it
-                comp.compress_tensor_async(piece, scratch[k], size_dev[k], final_stream=final, block_bytes=bb)
+                comp.compress_tensor_async(piece, scratch[k], size_dev[k], final_stream=final, block_bytes=bb, effort=args.effort)
                 return scratch[k], size_dev[k]
 
             out, total = pipelined_step(
@@ -344,6 +346,8 @@ def main():
                "note": "sfh_compress from/to pinned host buffers: H2D of the input, the four kernels, D2H of the stream, synchronous"}
         del hin, hout
         others = {w: secondary_workload(comp, w, args.secondary_bytes, dev, 0) for w in ("text", "mixed", "random") if w != args.workload}
+        # the same bytes at sfh_options.effort = SFH_EFFORT_FAST (one history level per hash bucket)
+        others["effort_fast"] = secondary_workload(comp, args.workload, n, dev, bb, effort="fast", data=data, wl=wl)
 
     # ---- CPU baseline: oracle restatement of the reference decompress(), 1 thread ----
     cpu = None
@@ -382,7 +386,7 @@ def main():
         "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": wl, "block_bytes": bb, "deflate_block_bytes": SEG, "window_bytes": 32768, "strategy": "auto",
+        "config": {"workload": wl, "effort": args.effort, "block_bytes": bb, "deflate_block_bytes": SEG, "window_bytes": 32768, "strategy": "auto",
                    "container": args.container,
                    "parallelism": f"shard{world}" + (f" block-cyclic x{K}, gather overlapped" if multi else "")},
         "ratio": round(ratio, 4), "ratio_zlib6": round(ratio_zlib6, 4),

@@ -71,12 +71,17 @@ typedef struct sfh_options {
                             as one byte-aligned DEFLATE block per 32 KiB; inside it the 32 KiB window slides across
                             those blocks (src/decompress.cpp:178 only requires distance <= bytes written), so
                             larger strips compress better; 32768 makes every DEFLATE block independent */
-  uint32_t reserved[2];  /* must be 0 */
+  uint32_t effort;       /* enum sfh_effort: SFH_EFFORT_DEFAULT tries both history levels of a hash bucket plus the
+                            step-local candidate; SFH_EFFORT_FAST only the newer level (a third fewer compares,
+                            about 3 % more output) */
+  uint32_t reserved;     /* must be 0 */
 } sfh_options;
+
+enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1 };
 
 #define SFH_DEFAULT_BLOCK_BYTES 262144u
 
-/* fills *o with defaults: AUTO, final_stream=1, lazy=3, block_bytes=0 */
+/* fills *o with defaults: AUTO, final_stream=1, lazy=3, block_bytes=0, effort=SFH_EFFORT_DEFAULT */
 void sfh_default_options(sfh_options* o);
 
 int sfh_device_count(void);

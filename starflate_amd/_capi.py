@@ -32,7 +32,7 @@ EXPORTS = [
 class Options(C.Structure):
     _fields_ = [("strategy", C.c_uint32), ("final_stream", C.c_uint32), ("lazy", C.c_uint32),
                 ("no_stored_fast_path", C.c_uint32), ("container", C.c_uint32), ("block_bytes", C.c_uint32),
-                ("reserved", C.c_uint32 * 2)]
+                ("effort", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class DeviceProps(C.Structure):
@@ -128,7 +128,11 @@ def device_props(device=0):
     return {k: (getattr(p, k).decode() if isinstance(getattr(p, k), bytes) else getattr(p, k)) for k, _ in p._fields_ if k != "reserved"}
 
 
-def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw", block_bytes=0):
+EFFORT = {"default": 0, "fast": 1}
+
+
+def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw", block_bytes=0,
+                 effort="default"):
     o = Options()
     lib().sfh_default_options(C.byref(o))
     o.strategy = STRATEGY[strategy] if isinstance(strategy, str) else int(strategy)
@@ -137,6 +141,7 @@ def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path
     o.no_stored_fast_path = int(not stored_fast_path)
     o.container = CONTAINER[container] if isinstance(container, str) else int(container)
     o.block_bytes = int(block_bytes)
+    o.effort = EFFORT[effort] if isinstance(effort, str) else int(effort)
     return o
 
 

@@ -54,19 +54,19 @@ class Compressor:
 
     # ---- host buffers (PCIe inclusive) ----
     def compress(self, data, strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw",
-                 block_bytes=0):
+                 block_bytes=0, effort="default"):
         src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         cap = self.compress_bound(src.size)
         dst = np.empty(cap, dtype=np.uint8)
         out_n = C.c_size_t(0)
-        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container, block_bytes)
+        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container, block_bytes, effort)
         self._check(self._lib.sfh_compress(self._h, src.ctypes.data if src.size else None, src.size,
                                            dst.ctypes.data, cap, C.byref(out_n), C.byref(opt)))
         return dst[: out_n.value].tobytes()
 
     # ---- device buffers (torch uint8 CUDA tensors) ----
     def compress_tensor(self, src, out=None, strategy="auto", final_stream=True, lazy=True, stream=None,
-                        stored_fast_path=True, container="raw", block_bytes=0):
+                        stored_fast_path=True, container="raw", block_bytes=0, effort="default"):
         """src: 1-D uint8 tensor on this device. Returns (out tensor, stream byte count)."""
         import torch
 
@@ -77,14 +77,14 @@ class Compressor:
             out = torch.empty(cap, dtype=torch.uint8, device=src.device)
         self._check_tensor(out)
         out_n = C.c_size_t(0)
-        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container, block_bytes)
+        opt = _capi.make_options(strategy, final_stream, lazy, stored_fast_path, container, block_bytes, effort)
         s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
         self._check(self._lib.sfh_compress_device(self._h, src.data_ptr() if n else None, n, out.data_ptr(),
                                                   out.numel(), C.byref(out_n), C.byref(opt), C.c_void_p(s)))
         return out, out_n.value
 
     def compress_tensor_async(self, src, out, size_out, strategy="auto", final_stream=True, lazy=True, stream=None,
-                              container="raw", block_bytes=0):
+                              container="raw", block_bytes=0, effort="default"):
         """Enqueue only. size_out: 1-element int64 CUDA tensor receiving the stream size."""
         import torch
 
@@ -92,7 +92,7 @@ class Compressor:
         self._check_tensor(out)
         if size_out.dtype not in (torch.int64, torch.uint64) or not size_out.is_cuda:
             raise ValueError("size_out must be a 1-element int64 CUDA tensor")
-        opt = _capi.make_options(strategy, final_stream, lazy, container=container, block_bytes=block_bytes)
+        opt = _capi.make_options(strategy, final_stream, lazy, container=container, block_bytes=block_bytes, effort=effort)
         s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
         n = src.numel()
         self._check(self._lib.sfh_compress_device_async(self._h, src.data_ptr() if n else None, n, out.data_ptr(),

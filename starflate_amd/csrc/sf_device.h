@@ -96,6 +96,7 @@ struct Options {
   uint32_t lazy;
   uint32_t fast_skip;
   uint32_t strip_bytes;  // multiple of kChunk
+  uint32_t depth2;       // 1: both history levels of a hash bucket are tried, 0: the newer one only
 };
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,

@@ -173,7 +173,9 @@ __device__ __forceinline__ uint32_t entry_pos(uint32_t v) { return v - 1u - 2u *
 
 // STAMPS: diagnostic build only (SFH_K1_STAMPS=1), s_memtime at phase boundaries into `stamps`
 // [strip][8] = cycles in {stage, match, take, walk, segpre, emit, flush}; never used for timing claims.
-template <bool STAMPS>
+// DEPTH2: both history levels of a bucket are tried (effort 0); otherwise only the newer one (effort 1: a third
+// fewer compares, about 3 % more output)
+template <bool STAMPS, bool DEPTH2>
 __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     const uint8_t* __restrict__ src, uint64_t n_total, uint32_t strip_bytes, uint16_t* __restrict__ items,
     uint32_t* __restrict__ nitems_out, uint32_t* __restrict__ ntok_out, uint32_t* __restrict__ hist_out,
@@ -303,11 +305,11 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         // the far candidates only need the (immutable) window: compare them ahead of the barriers
         const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
         const uint32_t c0 = entry_pos(f0) + K, c1 = entry_pos(f1) + K;
-        const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = f1 != 0 && ad - c1 <= kWindow;
+        const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 != 0 && ad - c1 <= kWindow;
         const uint32_t q0 = ok0 ? c0 : ad, q1 = ok1 ? c1 : ad;
         // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
         const uint32_t l0 = rank8(s_data, a0, a1, q0);
-        const uint32_t l1 = rank8(s_data, a0, a1, q1);
+        const uint32_t l1 = DEPTH2 ? rank8(s_data, a0, a1, q1) : 0u;
         const uint32_t lf0 = ok0 ? l0 : 0u, lf1 = ok1 ? l1 : 0u;
         __syncthreads();  // every far read of this step precedes every insertion of this step
         {
@@ -1271,12 +1273,15 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
   if (opt.strip_bytes == 0 || opt.strip_bytes % kChunk || opt.strip_bytes > kMaxStrip) return hipErrorInvalidValue;
   const uint32_t per = opt.strip_bytes / kChunk;
   const uint32_t nstrips = (nchunks + per - 1) / per;
-  if (ws.stamps)
-    hipLaunchKernelGGL(k_lz77<true>, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items,
-                       ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, ws.stamps, dbg);
-  else
-    hipLaunchKernelGGL(k_lz77<false>, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items,
-                       ws.nitems, ws.ntok, ws.hist, ws.rtok, opt.lazy, opt.fast_skip, (uint64_t*)nullptr, dbg);
+  const auto launch = [&](auto kernel, uint64_t* stamps) {
+    hipLaunchKernelGGL(kernel, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items, ws.nitems, ws.ntok,
+                       ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps, dbg);
+  };
+  if (ws.stamps) {
+    if (opt.depth2) launch(k_lz77<true, true>, ws.stamps); else launch(k_lz77<true, false>, ws.stamps);
+  } else {
+    if (opt.depth2) launch(k_lz77<false, true>, (uint64_t*)nullptr); else launch(k_lz77<false, false>, (uint64_t*)nullptr);
+  }
   return hipGetLastError();
 }
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,

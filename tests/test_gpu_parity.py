@@ -81,6 +81,18 @@ def test_block_bytes_bit_exact_vs_oracle(compressor, starfleet, block_bytes):
         compressor.compress(text, block_bytes=32768 + 512)  # not a multiple of 32 KiB
 
 
+def test_effort_fast_bit_exact_vs_oracle(compressor, starfleet):
+    """sfh_options.effort = SFH_EFFORT_FAST: one history level per hash bucket (the specification's depth = 1)."""
+    text = synth.gen_text(20 * CHUNK + 77, seed=14)
+    for data in (text, np.frombuffer(starfleet, np.uint8), synth.gen_mixed(1 << 20, seed=4, stripe=1 << 15)):
+        for bb in (0, 131072):
+            got = np.frombuffer(compressor.compress(data, effort="fast", block_bytes=bb), np.uint8)
+            want = O.compress(data, O.default_params(depth=1, strip_bytes=bb))
+            assert np.array_equal(got, want)
+            _roundtrip(got, data)
+            assert got.size >= len(compressor.compress(data, block_bytes=bb))
+
+
 def test_default_block_bytes_rule(compressor):
     """block_bytes = 0 stands for a function of the input size alone (the oracle and the library share the rule)."""
     for n in (0, 1, CHUNK, 50 * CHUNK, (8 << 20) + 5, 16 << 20, (64 << 20) + 1):
