@@ -6,9 +6,15 @@ Every dispatch of the profiled command processes the same 1 GiB, so per launch =
 import json
 import sys
 
+import subprocess
+
 src, dst = sys.argv[1], sys.argv[2]
 d = json.load(open(src))
-out = {}
+try:
+    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:  # noqa: BLE001  (the GPU box has no .git: the caller fills it in)
+    commit = "unknown"
+out = {"_meta": {"commit": commit, "source": src, "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary"}}
 for name, v in d.items():
     if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue

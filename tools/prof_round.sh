@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 tag=${1:-r01}
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- $CMD > $out/kt.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $CMD > $out/pmc_fetch.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $CMD > $out/pmc_write.log 2>&1
@@ -18,3 +18,4 @@ f=$(find $out/kt -name '*kernel_stats.csv' | head -1)
 (head -1 $f; grep 'sf::' $f) > $out/${tag}_kernel_stats.csv
 cat $out/${tag}_kernel_stats.csv
 tail -1 $out/kt.log > $out/${tag}_bench_under_rocprof.json
+python tools/pmc_traffic.py $out/${tag}_pmc_summary.json $out/pmc_traffic.json > /dev/null
