@@ -34,6 +34,7 @@ struct sfh_ctx {
   size_t d_in_cap = 0, d_out_cap = 0;
   int profiling = 0;
   int k1_stamps = 0;  // SFH_K1_STAMPS=1: diagnostic k_lz77 build with s_memtime stamps
+  uint32_t batch_chunks = sf::kBatchChunks;  // SFH_BATCH_CHUNKS=<n>: smaller batches (tests of the batch loop)
   hipEvent_t ev[SFH_NSTAGES + 1] = {};
   bool ev_valid = false;
   hipEvent_t ev_done = nullptr;  // end of the last call's device work: the next call, on any stream, starts behind it
@@ -93,25 +94,28 @@ int ensure_sums(sfh_ctx* ctx, uint32_t nchunks) {
   return grow(ctx, &ctx->ws.sums, &ctx->sums_cap, (size_t)nchunks * sizeof(uint32_t), "checksum scratch");
 }
 
+// The per-batch arrays hold min(nchunks, kBatchChunks) chunks, the index arrays (offsets, sub-index, segment records)
+// every chunk of the call.
 int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
   if (nchunks <= ctx->cap_chunks) return SFH_OK;
   free_ws(ctx);
-  const size_t nc = nchunks;
+  // (a strip larger than a batch is its own batch: kMaxStrip / kChunk = 512 chunks at most)
+  const size_t nc = nchunks, nb = std::min<uint32_t>(nchunks, std::max<uint32_t>(ctx->batch_chunks, sf::kMaxStrip / sf::kChunk));
   hipError_t e;
-  if ((e = hipMalloc(&ctx->ws.items, nc * sf::kChunk * sizeof(uint16_t))) != hipSuccess ||
-      (e = hipMalloc(&ctx->ws.nitems, nc * sizeof(uint32_t))) != hipSuccess ||
-      (e = hipMalloc(&ctx->ws.ntok, nc * sizeof(uint32_t))) != hipSuccess ||
-      (e = hipMalloc(&ctx->ws.hist, nc * sf::kHistStride * sizeof(uint32_t))) != hipSuccess ||
-      (e = hipMalloc(&ctx->ws.plan, nc * sizeof(sf::ChunkPlan))) != hipSuccess ||
-      (e = hipMalloc(&ctx->ws.codes, nc * sizeof(sf::ChunkCodes))) != hipSuccess ||
+  if ((e = hipMalloc(&ctx->ws.items, nb * sf::kChunk * sizeof(uint16_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.nitems, nb * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.ntok, nb * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.hist, nb * sf::kHistStride * sizeof(uint32_t))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.plan, nb * sizeof(sf::ChunkPlan))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.codes, nb * sizeof(sf::ChunkCodes))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.rtok, nb * sf::kSubRegions * sizeof(uint32_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.offsets, (nc + 1) * sizeof(uint64_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.seginfo, nc * sizeof(sf::SegInfo))) != hipSuccess ||
-      (e = hipMalloc(&ctx->ws.rtok, nc * sf::kSubRegions * sizeof(uint32_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.subidx, nc * 2 * sf::kSubRegions * sizeof(uint32_t))) != hipSuccess) {
     free_ws(ctx);
     return fail(ctx, SFH_E_NOMEM, "workspace hipMalloc", e);
   }
-  if (ctx->k1_stamps && (e = hipMalloc(&ctx->ws.stamps, nc * 16 * sizeof(uint64_t))) != hipSuccess) {
+  if (ctx->k1_stamps && (e = hipMalloc(&ctx->ws.stamps, nb * 16 * sizeof(uint64_t))) != hipSuccess) {
     free_ws(ctx);
     return fail(ctx, SFH_E_NOMEM, "stamps hipMalloc", e);
   }
@@ -184,15 +188,31 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   ctx->last_block_bytes = ko.strip_bytes;
   const bool prof = ctx->profiling != 0;
   if ((rc = order_behind_last_call(ctx, s)) != SFH_OK) return rc;
-  if (prof) SF_HIP(hipEventRecord(ctx->ev[0], s), "event");
-  SF_HIP(sf::launch_lz77((const uint8_t*)d_src, n, nchunks, ctx->ws, ko, s), "launch k_lz77");
-  if (prof) SF_HIP(hipEventRecord(ctx->ev[1], s), "event");
-  SF_HIP(sf::launch_plan(n, nchunks, ctx->ws, ko, s), "launch k_plan");
-  if (prof) SF_HIP(hipEventRecord(ctx->ev[2], s), "event");
-  SF_HIP(sf::launch_scan(nchunks, ctx->ws, sf::wrapper_header_bytes(o.container), d_out_n, s), "launch k_scan");
-  if (prof) SF_HIP(hipEventRecord(ctx->ev[3], s), "event");
-  SF_HIP(sf::launch_emit((const uint8_t*)d_src, n, nchunks, ctx->ws, (uint8_t*)d_dst, s), "launch k_emit");
-  if (prof) SF_HIP(hipEventRecord(ctx->ev[4], s), "event");
+  // Batches of whole strips, at most kBatchChunks chunks each, one after the other on the stream: strips are coded
+  // independently, so the stream is the same as from one launch over everything.  (Per-kernel events: the first batch.)
+  const uint32_t per_strip = ko.strip_bytes / sf::kChunk;
+  const uint32_t batch = std::max(per_strip, ctx->batch_chunks / per_strip * per_strip);
+  for (uint32_t c0 = 0; c0 < nchunks; c0 += batch) {
+    const uint32_t nb = std::min(batch, nchunks - c0);
+    const bool first = c0 == 0, last = c0 + nb == nchunks;
+    const uint8_t* bsrc = (const uint8_t*)d_src + (size_t)c0 * sf::kChunk;
+    const size_t bn = std::min((size_t)nb * sf::kChunk, n - (size_t)c0 * sf::kChunk);
+    sf::Workspace w = ctx->ws;  // this batch's view: index arrays advance, batch arrays start over
+    w.offsets += c0;
+    w.subidx += (size_t)c0 * 2 * sf::kSubRegions;
+    sf::Options bo = ko;
+    bo.final_stream = last ? ko.final_stream : 0u;
+    const bool ev = prof && first;
+    if (ev) SF_HIP(hipEventRecord(ctx->ev[0], s), "event");
+    SF_HIP(sf::launch_lz77(bsrc, bn, nb, w, bo, s), "launch k_lz77");
+    if (ev) SF_HIP(hipEventRecord(ctx->ev[1], s), "event");
+    SF_HIP(sf::launch_plan(bn, nb, w, bo, s), "launch k_plan");
+    if (ev) SF_HIP(hipEventRecord(ctx->ev[2], s), "event");
+    SF_HIP(sf::launch_scan(nb, w, sf::wrapper_header_bytes(o.container), !first, d_out_n, s), "launch k_scan");
+    if (ev) SF_HIP(hipEventRecord(ctx->ev[3], s), "event");
+    SF_HIP(sf::launch_emit(bsrc, bn, nb, w, (uint8_t*)d_dst, s), "launch k_emit");
+    if (ev) SF_HIP(hipEventRecord(ctx->ev[4], s), "event");
+  }
   if (o.container) {
     SF_HIP(sf::launch_checksum((const uint8_t*)d_src, n, nchunks, o.container, ctx->ws.sums, s), "launch k_checksum");
     SF_HIP(sf::launch_wrap(ctx->ws.sums, nchunks, n, o.container, (uint8_t*)d_dst, d_out_n, nullptr, s), "launch k_wrap");
@@ -249,6 +269,8 @@ int sfh_create(sfh_ctx** out, int device) {
   {
     const char* e = getenv("SFH_K1_STAMPS");
     ctx->k1_stamps = (e && e[0] == '1');
+    const char* b = getenv("SFH_BATCH_CHUNKS");
+    if (b && atoi(b) > 0) ctx->batch_chunks = std::min<uint32_t>((uint32_t)atoi(b), sf::kBatchChunks);
   }
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
@@ -580,7 +602,9 @@ const char* sfh_stage_name(int stage) {
 
 int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes) {
   if (!ctx || !host_dst || !ctx->last_chunks) return SFH_E_INVALID_ARG;
-  const size_t nc = ctx->last_chunks;
+  // per-batch arrays hold the last batch of the call (all of it for up to kBatchChunks chunks)
+  const size_t nc = std::min<size_t>(ctx->last_chunks, std::max<uint32_t>(ctx->batch_chunks, sf::kMaxStrip / sf::kChunk));
+  const size_t nall = ctx->last_chunks;
   const void* p = nullptr;
   size_t avail = 0;
   switch (what) {
@@ -590,8 +614,8 @@ int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes) {
     case SFH_DBG_NITEMS: p = ctx->ws.nitems; avail = nc * 4; break;
     case SFH_DBG_HIST: p = ctx->ws.hist; avail = nc * sf::kHistStride * 4; break;
     case SFH_DBG_PLAN: p = ctx->ws.plan; avail = nc * sizeof(sf::ChunkPlan); break;
-    case SFH_DBG_OFFSETS: p = ctx->ws.offsets; avail = nc * 8; break;
-    case SFH_DBG_SUBINDEX: p = ctx->ws.subidx; avail = nc * SFH_SUBINDEX_WORDS * 4; break;
+    case SFH_DBG_OFFSETS: p = ctx->ws.offsets; avail = nall * 8; break;
+    case SFH_DBG_SUBINDEX: p = ctx->ws.subidx; avail = nall * SFH_SUBINDEX_WORDS * 4; break;
     case SFH_DBG_STAMPS: p = ctx->ws.stamps; avail = p ? nc * 128 : 0; break;
     case SFH_DBG_LENS: {
       if (bytes > nc * 320) return SFH_E_INVALID_ARG;

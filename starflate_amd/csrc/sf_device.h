@@ -74,8 +74,12 @@ struct SegInfo {
   uint64_t raw_off;
 };
 
+// Arrays marked (batch) hold one batch of at most kBatchChunks chunks: a call on a larger input runs the four kernels
+// batch after batch on the same stream, so the scratch of a call is bounded (2.2 bytes per input byte of one batch).
+constexpr uint32_t kBatchChunks = 32768;  // 1 GiB of input
+
 struct Workspace {
-  uint16_t* items;    // [nchunks][kChunk] token items (K1 -> K4)
+  uint16_t* items;    // (batch) [nchunks][kChunk] token items (K1 -> K4)
   uint32_t* nitems;   // [nchunks]
   uint32_t* tokens;   // [nseg][kChunk] decoder only (k_inflate_tokens* -> k_inflate_bytes)
   uint32_t* ntok;     // [nchunks] tokens (a match counts once)
@@ -103,8 +107,9 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
                        const Options& opt, hipStream_t s);
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,
                        hipStream_t s);
-// offsets start at `base` (bytes of wrapper header in front of the stream); *d_total = base + stream bytes
-hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, uint64_t* d_total, hipStream_t s);
+// offsets start at `base` (bytes of wrapper header in front of the stream), or with `carry` at the current *d_total
+// (the end of the previous batch); *d_total = the end of this batch
+hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, bool carry, uint64_t* d_total, hipStream_t s);
 hipError_t launch_emit(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
                        uint8_t* dst, hipStream_t s);
 hipError_t init_kernels();

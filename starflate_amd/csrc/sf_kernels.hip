@@ -415,7 +415,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 const uint32_t xpa = kWindow + pb + mp, xca = xpa - s_dist[pb + mp];
                 const uint32_t xmax = rend - (pb + mp) < 258u ? rend - (pb + mp) : 258u;
                 uint32_t l = kCap;
-                while (l < xmax) {
+                while (l < xmax && !(dbg & 8)) {  // dbg 8: timing experiment only (capped matches stay capped)
                   const uint32_t ia = xpa + l, ja = xca + l;
                   const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
                   const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
@@ -972,10 +972,12 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
 // K3: exclusive scan of chunk sizes (single workgroup).
 // ---------------------------------------------------------------------------
 constexpr uint32_t K3_THREADS = 1024;
+// `carry` (a batch after the first): the offsets continue where *total -- the previous batch's end -- left off
 __global__ __launch_bounds__(K3_THREADS) void k_scan(uint32_t nchunks, const ChunkPlan* __restrict__ plan,
-                                                     uint64_t base, uint64_t* __restrict__ offsets,
+                                                     uint64_t base, uint32_t carry, uint64_t* __restrict__ offsets,
                                                      uint64_t* __restrict__ total) {
   __shared__ uint64_t s_wave[K3_THREADS / 64];
+  if (carry) base = *total;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t per = (nchunks + K3_THREADS - 1) / K3_THREADS;
   const uint32_t b = t * per, e = (b + per < nchunks) ? b + per : nchunks;
@@ -1290,8 +1292,8 @@ hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const 
                      opt.strategy, opt.final_stream, ws.stamps);
   return hipGetLastError();
 }
-hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, uint64_t* d_total, hipStream_t s) {
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(K3_THREADS), 0, s, nchunks, ws.plan, base, ws.offsets, d_total);
+hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, bool carry, uint64_t* d_total, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(K3_THREADS), 0, s, nchunks, ws.plan, base, carry ? 1u : 0u, ws.offsets, d_total);
   return hipGetLastError();
 }
 hipError_t launch_emit(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,

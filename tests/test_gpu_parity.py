@@ -93,6 +93,25 @@ def test_effort_fast_bit_exact_vs_oracle(compressor, starfleet):
             assert got.size >= len(compressor.compress(data, block_bytes=bb))
 
 
+def test_batches_give_the_stream_of_one_launch(monkeypatch):
+    """Inputs beyond one batch (1 GiB) run the four kernels batch after batch with bounded scratch; a small batch
+    size (SFH_BATCH_CHUNKS, read at sfh_create) exercises the loop: same stream, same index, wrapped or not."""
+    from starflate_amd import Compressor
+
+    data = synth.gen_text(37 * CHUNK + 999, seed=15)
+    for bc, bb in ((4, 32768), (8, 65536), (3, 131072), (16, 0)):
+        monkeypatch.setenv("SFH_BATCH_CHUNKS", str(bc))
+        c = Compressor(0)
+        for container in ("raw", "gzip"):
+            got = np.frombuffer(c.compress(data, block_bytes=bb, container=container), np.uint8)
+            want, widx, wsub = O.compress_indexed(data, O.default_params(strip_bytes=bb, container=_capi.CONTAINER[container]))
+            assert np.array_equal(got, want), (bc, bb, container)
+            assert np.array_equal(c.last_index(), widx) and np.array_equal(c.last_subindex(), wsub)
+            back, st = c.decompress(got, c.last_index(), data.size, subindex=c.last_subindex(), block_bytes=c.last_block_bytes())
+            assert st == 0 and back == data.tobytes()
+        c.close()
+
+
 def test_default_block_bytes_rule(compressor):
     """block_bytes = 0 stands for a function of the input size alone (the oracle and the library share the rule)."""
     for n in (0, 1, CHUNK, 50 * CHUNK, (8 << 20) + 5, 16 << 20, (64 << 20) + 1):
