@@ -457,7 +457,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       const uint32_t mine = (uint32_t)__popc(marks) | ((uint32_t)__popc(cm) << 16);
       const uint32_t incl = wave_incl_add(mine);
       if (lane == 63) s_wtot[wave] = incl;
-      if (!(dbg & 4)) __syncthreads();  // dbg 4: timing experiment only (wrong item offsets)
+      __syncthreads();
       uint32_t wbase, rtotal;
       {
         // totals of the waves before this one, and of all: one scan over the sixteen entries
