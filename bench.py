@@ -355,7 +355,8 @@ def main():
             call()
         te = (time.perf_counter() - t0) / reps
         e2e = {"value": round(n / te / 2**20, 1), "unit": "MiB/s", "ms": round(te * 1e3, 3), "bytes_out": int(out_n.value),
-               "note": "sfh_compress from/to pinned host buffers: H2D of the input, the four kernels, D2H of the stream, synchronous"}
+               "note": "sfh_compress from/to pinned host buffers, the call as a whole (synchronous): inside it 64 MiB batches are pipelined -- "
+                       "H2D of batch b beside the kernels of batch b-1 beside the D2H of batch b-2's stream bytes"}
         del hin, hout
         others = {w: secondary_workload(comp, w, args.secondary_bytes, dev, 0) for w in ("text", "mixed", "random") if w != args.workload}
         # the same bytes at sfh_options.effort = SFH_EFFORT_FAST (one history level per hash bucket)

@@ -107,7 +107,9 @@ const char* sfh_last_error(const sfh_ctx* ctx);
  * (SURVEY.md 8(b) signature; the bound is per 32 KiB DEFLATE block, so today it does not depend on it) */
 size_t sfh_compress_bound(size_t n, uint32_t block_bytes);
 
-/* Host buffers: H2D copy, compress, D2H copy, synchronous.  *out_n = stream bytes. */
+/* Host buffers, synchronous.  *out_n = stream bytes.  Inside the call the input goes up, through the kernels and the
+ * stream comes down in 64 MiB batches on three streams, so with pinned buffers the call takes about as long as the
+ * larger of its two copies (pageable buffers make the copies themselves synchronous). */
 int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap, size_t* out_n,
                  const sfh_options* opt);
 

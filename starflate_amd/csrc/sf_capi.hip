@@ -37,6 +37,11 @@ struct sfh_ctx {
   uint32_t batch_chunks = sf::kBatchChunks;  // SFH_BATCH_CHUNKS=<n>: smaller batches (tests of the batch loop)
   hipEvent_t ev[SFH_NSTAGES + 1] = {};
   bool ev_valid = false;
+  // host-buffer path (sfh_compress): copies of one batch run beside the kernels of its neighbours
+  static constexpr int kPipe = 4;
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_in[kPipe] = {}, ev_batch[kPipe] = {};
+  uint64_t* h_tot = nullptr;     // pinned: the stream's end after each batch in flight
   hipEvent_t ev_done = nullptr;  // end of the last call's device work: the next call, on any stream, starts behind it
   bool busy = false;             // (the device scratch is shared by all calls on this ctx)
   hipStream_t last_stream = nullptr;
@@ -168,8 +173,19 @@ int check_opt(const sfh_options* o) {
   return 0;
 }
 
+// Host buffers of sfh_compress: with them the batch loop also moves the data -- batch b's input goes up on one copy
+// stream while batch b-1 is in the kernels and batch b-2's stream bytes go down on another.
+struct HostPipe {
+  const uint8_t* src;
+  uint8_t* dst;
+  size_t cap;
+  size_t copied = 0;   // stream bytes already on their way to dst
+  bool overflow = false;
+};
+constexpr uint32_t kPipeBatchChunks = 2048;  // 64 MiB of input per batch on the host-buffer path
+
 int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, uint64_t* d_out_n,
-            const sfh_options* opt, hipStream_t s) {
+            const sfh_options* opt, hipStream_t s, HostPipe* pipe = nullptr) {
   if (!ctx || (!d_src && n) || !d_dst || !d_out_n || check_opt(opt)) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
   if (((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 3)) return fail(ctx, SFH_E_INVALID_ARG, "device pointer alignment (src 16, dst 4)", hipSuccess);
   if (cap < sfh_compress_bound(n, 0)) return fail(ctx, SFH_E_DST_TOO_SMALL, "cap < sfh_compress_bound(n)", hipSuccess);
@@ -191,12 +207,32 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   // Batches of whole strips, at most kBatchChunks chunks each, one after the other on the stream: strips are coded
   // independently, so the stream is the same as from one launch over everything.  (Per-kernel events: the first batch.)
   const uint32_t per_strip = ko.strip_bytes / sf::kChunk;
-  const uint32_t batch = std::max(per_strip, ctx->batch_chunks / per_strip * per_strip);
-  for (uint32_t c0 = 0; c0 < nchunks; c0 += batch) {
+  const uint32_t want = pipe ? std::min(ctx->batch_chunks, kPipeBatchChunks) : ctx->batch_chunks;
+  const uint32_t batch = std::max(per_strip, want / per_strip * per_strip);
+  const size_t hdr = sf::wrapper_header_bytes(o.container);
+  if (pipe) pipe->copied = hdr;  // the wrapper header is written last (k_wrap) and copied last
+  // the stream bytes of batch `b` (its end is in h_tot once ev_batch fires) go down while later batches run
+  auto drain = [&](uint32_t b) -> int {
+    SF_HIP(hipEventSynchronize(ctx->ev_batch[b % sfh_ctx::kPipe]), "wait for a batch");
+    const size_t end = (size_t)ctx->h_tot[b % sfh_ctx::kPipe];
+    if (end > pipe->cap) { pipe->overflow = true; return SFH_OK; }
+    if (end > pipe->copied)
+      SF_HIP(hipMemcpyAsync(pipe->dst + pipe->copied, (const uint8_t*)d_dst + pipe->copied, end - pipe->copied,
+                            hipMemcpyDeviceToHost, ctx->s_out), "D2H");
+    pipe->copied = end;
+    return SFH_OK;
+  };
+  uint32_t bi = 0;
+  for (uint32_t c0 = 0; c0 < nchunks; c0 += batch, ++bi) {
     const uint32_t nb = std::min(batch, nchunks - c0);
     const bool first = c0 == 0, last = c0 + nb == nchunks;
     const uint8_t* bsrc = (const uint8_t*)d_src + (size_t)c0 * sf::kChunk;
     const size_t bn = std::min((size_t)nb * sf::kChunk, n - (size_t)c0 * sf::kChunk);
+    if (pipe && bn) {
+      SF_HIP(hipMemcpyAsync(const_cast<uint8_t*>(bsrc), pipe->src + (size_t)c0 * sf::kChunk, bn, hipMemcpyHostToDevice, ctx->s_in), "H2D");
+      SF_HIP(hipEventRecord(ctx->ev_in[bi % sfh_ctx::kPipe], ctx->s_in), "event");
+      SF_HIP(hipStreamWaitEvent(s, ctx->ev_in[bi % sfh_ctx::kPipe], 0), "wait for the input");
+    }
     sf::Workspace w = ctx->ws;  // this batch's view: index arrays advance, batch arrays start over
     w.offsets += c0;
     w.subidx += (size_t)c0 * 2 * sf::kSubRegions;
@@ -212,7 +248,13 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
     if (ev) SF_HIP(hipEventRecord(ctx->ev[3], s), "event");
     SF_HIP(sf::launch_emit(bsrc, bn, nb, w, (uint8_t*)d_dst, s), "launch k_emit");
     if (ev) SF_HIP(hipEventRecord(ctx->ev[4], s), "event");
+    if (pipe) {
+      if (bi >= 1 && (rc = drain(bi - 1)) != SFH_OK) return rc;  // (its slot is free again before batch bi + kPipe - 1 needs it)
+      SF_HIP(hipMemcpyAsync(&ctx->h_tot[bi % sfh_ctx::kPipe], d_out_n, sizeof(uint64_t), hipMemcpyDeviceToHost, s), "copy size");
+      SF_HIP(hipEventRecord(ctx->ev_batch[bi % sfh_ctx::kPipe], s), "event");
+    }
   }
+  if (pipe && (rc = drain(bi - 1)) != SFH_OK) return rc;
   if (o.container) {
     SF_HIP(sf::launch_checksum((const uint8_t*)d_src, n, nchunks, o.container, ctx->ws.sums, s), "launch k_checksum");
     SF_HIP(sf::launch_wrap(ctx->ws.sums, nchunks, n, o.container, (uint8_t*)d_dst, d_out_n, nullptr, s), "launch k_wrap");
@@ -315,6 +357,13 @@ void sfh_destroy(sfh_ctx* ctx) {
   for (int k = 0; k <= SFH_NSTAGES; ++k)
     if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+  for (int k = 0; k < sfh_ctx::kPipe; ++k) {
+    if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
+    if (ctx->ev_batch[k]) (void)hipEventDestroy(ctx->ev_batch[k]);
+  }
+  if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
+  if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
+  if (ctx->h_tot) (void)hipHostFree(ctx->h_tot);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -355,15 +404,40 @@ int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap,
   int rc = grow(ctx, &ctx->d_in, &ctx->d_in_cap, n ? n : 16, "input staging");
   if (!rc) rc = grow(ctx, &ctx->d_out, &ctx->d_out_cap, bound, "output staging");
   if (rc) return rc;
+  if (!ctx->s_in) {  // the copy streams, their events and the pinned size slots: on first use
+    SF_HIP(hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking), "stream");
+    SF_HIP(hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking), "stream");
+    for (int k = 0; k < sfh_ctx::kPipe; ++k) {
+      SF_HIP(hipEventCreateWithFlags(&ctx->ev_in[k], hipEventDisableTiming), "event");
+      SF_HIP(hipEventCreateWithFlags(&ctx->ev_batch[k], hipEventDisableTiming), "event");
+    }
+    SF_HIP(hipHostMalloc((void**)&ctx->h_tot, sfh_ctx::kPipe * sizeof(uint64_t), hipHostMallocDefault), "pinned slots");
+  }
   hipStream_t s = ctx->stream;
-  if (n) SF_HIP(hipMemcpyAsync(ctx->d_in, src, n, hipMemcpyHostToDevice, s), "H2D");
-  size_t total = 0;
-  rc = sfh_compress_device(ctx, ctx->d_in, n, ctx->d_out, bound, &total, opt, s);
-  if (rc) return rc;
-  if (total > cap) return fail(ctx, SFH_E_DST_TOO_SMALL, "dst capacity below stream size", hipSuccess);
-  SF_HIP(hipMemcpyAsync(dst, ctx->d_out, total, hipMemcpyDeviceToHost, s), "D2H");
+  // the staging buffers may still be read by copies of the previous call: they were all waited for below
+  HostPipe pipe{(const uint8_t*)src, (uint8_t*)dst, cap};
+  rc = enqueue(ctx, ctx->d_in, n, ctx->d_out, bound, ctx->d_total, opt, s, &pipe);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->s_in);
+    (void)hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(ctx->s_out);
+    return rc;
+  }
+  uint64_t total = 0;
+  SF_HIP(hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, s), "copy size");
   SF_HIP(hipStreamSynchronize(s), "stream sync");
-  *out_n = total;
+  if (pipe.overflow || total > cap) {
+    (void)hipStreamSynchronize(ctx->s_out);
+    return fail(ctx, SFH_E_DST_TOO_SMALL, "dst capacity below stream size", hipSuccess);
+  }
+  // a wrapped stream: the header in front and the trailer behind the raw bytes came last (k_wrap)
+  const sfh_options* o = opt;
+  const size_t hdr = (o && o->container) ? sf::wrapper_header_bytes(o->container) : 0;
+  if (hdr) SF_HIP(hipMemcpyAsync(dst, ctx->d_out, hdr, hipMemcpyDeviceToHost, ctx->s_out), "D2H header");
+  if (total > pipe.copied)
+    SF_HIP(hipMemcpyAsync((uint8_t*)dst + pipe.copied, ctx->d_out + pipe.copied, total - pipe.copied, hipMemcpyDeviceToHost, ctx->s_out), "D2H trailer");
+  SF_HIP(hipStreamSynchronize(ctx->s_out), "stream sync");
+  *out_n = (size_t)total;
   return SFH_OK;
 }
 
