@@ -19,6 +19,8 @@
 //                     is copied straight from the stream.
 //   k_inflate_status  first non-zero segment status in stream order = what the serial decoder would report.
 #include "sf_device.h"
+
+#include <stdlib.h>
 #include "sf_inflate_core.h"
 
 namespace sf {
@@ -31,8 +33,9 @@ constexpr uint32_t KB_THREADS = 512;
 constexpr uint32_t KB_TPT = 2;     // tokens per thread per step
 constexpr uint32_t KB_SPAN = 3968;  // output bytes per step (pointer array)
 constexpr uint32_t KB_AUX = 2 * KB_SPAN + 4 * KB_THREADS * KB_TPT + 8 * (KB_SPAN / 32) + 64;
-constexpr uint32_t KB_LDS = kChunk + KB_AUX;            // independent segments: the segment's own 32 KiB
-constexpr uint32_t KB_LDS_STRIP = 2 * kChunk + KB_AUX;  // strips: a 64 KiB ring = the window + the segment
+constexpr uint32_t KB_RING = kWindow + 4096;             // the window + the step in flight (KB_SPAN bytes at most)
+constexpr uint32_t KB_LDS = KB_RING + KB_AUX;            // 49,952 B: three workgroups per CU
+static_assert(KB_SPAN <= KB_RING - kWindow && KB_RING % 16 == 0 && kChunk % 4 == 0, "ring geometry");
 
 __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __restrict__ src, uint64_t src_n,
                                                             const uint64_t* __restrict__ index, uint32_t nseg,
@@ -215,13 +218,15 @@ __device__ __forceinline__ uint32_t load_word_guarded(const uint8_t* base, uint6
 // one, however the matches of the step nest or overlap themselves; then the byte is fetched.  45 KiB of LDS (the
 // 32 KiB window + one step of pointers and token records): three workgroups share a CU and hide each other's
 // barriers.
-// One segment.  kRing: bytes of the output window in LDS -- kChunk for independent segments, 2 * kChunk for the
-// segments of a strip, whose matches may reach into the 32 KiB before the segment (position p of the strip lives
-// at p & (kRing - 1)).  segbase: the segment's first byte, strip-relative.  Returns false when the segment failed.
-template <uint32_t kRing>
+// One segment.  The output window is a ring of KB_RING bytes in LDS: the 32 KiB a match may reach back plus the
+// step being produced; byte p of the strip lives at p mod KB_RING.  Every step's bytes go to `dst` as soon as they
+// are final (whole dwords; the odd bytes with the next step), so the ring never has to hold a whole segment.
+// rb: ring position of the segment's first byte; segbase: that byte's position in its strip (bytes of history).
+// Returns false when the segment failed.
 __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t src_n, const uint32_t* __restrict__ tokens,
                                       SegInfo* __restrict__ info, uint8_t* __restrict__ dst, uint32_t seg, uint32_t segbase,
-                                      uint8_t* s_dyn) {
+                                      uint32_t rb, uint8_t* s_dyn) {
+  constexpr uint32_t kRing = KB_RING;
   uint8_t* s_out = s_dyn;                                          // [kRing] output window
   uint16_t* s_ptr = reinterpret_cast<uint16_t*>(s_dyn + kRing);   // [KB_SPAN] step-relative source, or kFinal
   uint32_t* s_tinfo = reinterpret_cast<uint32_t*>(s_dyn + kRing + 2 * KB_SPAN);  // [1024] start | match | byte or dist-1
@@ -231,15 +236,19 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
   uint32_t* s_next = s_w + KB_THREADS / 64;
   constexpr uint32_t kFinal = 0xFFFFu;
   constexpr uint32_t kWords = KB_SPAN / 32;
-  constexpr uint32_t kMask = kRing - 1;
   static_assert(kWords <= 128 && KB_SPAN % 32 == 0, "one wave scans the bitmap, two words per lane");
   const uint32_t t = threadIdx.x, lane = t & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // ring index of the segment's byte q (q < kChunk + kRing)
+  auto ring = [&](uint32_t q) -> uint32_t {
+    uint32_t a = rb + q;
+    a = a >= kRing ? a - kRing : a;
+    return a >= kRing ? a - kRing : a;
+  };
   const SegInfo si = info[seg];
   if (si.status != inflate::kOk) return false;
   const uint32_t out_n = si.out_n;
   uint8_t* o = dst + (uint64_t)seg * kChunk;  // 16-byte aligned
-  const uint32_t wb = segbase & kMask;        // the segment's first byte in the window (multiple of kChunk)
 
   if (si.raw) {
     // stored segment: dword copy from an arbitrarily aligned stream position
@@ -254,16 +263,16 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     }
     const uint32_t done = 4 * nd;
     if (t < out_n - done) o[done + t] = src[si.raw_off + done + t];
-    if constexpr (kRing > kChunk) {
-      // later segments of the strip may copy from these bytes: into the window as well
+    {
+      // later segments of the strip may copy from these bytes: their last kWindow go into the ring as well
       __syncthreads();  // (the previous segment's last window reads are done)
-      uint32_t* w32 = reinterpret_cast<uint32_t*>(s_out + wb);
-      for (uint32_t k = t; k < nd; k += KB_THREADS) {
+      const uint32_t k0 = out_n > kWindow ? (out_n - kWindow) / 4 : 0u;  // (rb and 4 * k are multiples of 4: dwords do not wrap)
+      for (uint32_t k = k0 + t; k < nd; k += KB_THREADS) {
         const uint32_t lo = load_word_guarded(src, src_n, w0 + k);
         const uint32_t hi = mis ? load_word_guarded(src, src_n, w0 + k + 1) : 0u;
-        w32[k] = __builtin_amdgcn_alignbyte(hi, lo, mis);
+        *reinterpret_cast<uint32_t*>(s_out + ring(4 * k)) = __builtin_amdgcn_alignbyte(hi, lo, mis);
       }
-      if (t < out_n - done) s_out[wb + done + t] = src[si.raw_off + done + t];
+      if (t < out_n - done) s_out[ring(done + t)] = src[si.raw_off + done + t];
       __syncthreads();
     }
     return true;
@@ -272,6 +281,7 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
   const uint32_t ntok = si.ntok;
   const uint32_t* tk = tokens + (uint64_t)seg * kChunk;
   uint32_t tok_base = 0, pos0 = 0;  // uniform: first token / output byte of the step
+  uint32_t flushed = 0;             // uniform: bytes of the segment already in dst (a multiple of 4)
   bool bad = false;
   if (t == 0) {
     s_next[0] = 0;  // tokens placed by the step
@@ -357,12 +367,13 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
         const uint32_t idx = s_wpre[w] + (uint32_t)__popc(s_mark[w] & (0xFFFFFFFFu >> (31u - (j & 31u)))) - 1u;
         const uint32_t ti = s_tinfo[idx];
         if (!(ti & 0x1000u)) {
-          s_out[wb + pos0 + j] = (uint8_t)(ti >> 16);
+          s_out[ring(pos0 + j)] = (uint8_t)(ti >> 16);
           s_ptr[j] = (uint16_t)kFinal;
         } else {
           const uint32_t dist = (ti >> 16) + 1u;
           if (dist > j) {  // source before the step: final
-            s_out[wb + pos0 + j] = s_out[(wb + pos0 + j - dist) & kMask];
+            // (pos0 + j + kRing - dist stays below kChunk + kRing: dist >= 1)
+            s_out[ring(pos0 + j)] = s_out[ring(pos0 + j + kRing - dist)];
             s_ptr[j] = (uint16_t)kFinal;
           } else {
             s_ptr[j] = (uint16_t)(j - dist);
@@ -395,7 +406,7 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
       const uint32_t j = t + KB_THREADS * i;
       if (j < span_n) {
         const uint32_t p = s_ptr[j];
-        if (p != kFinal) s_out[wb + pos0 + j] = s_out[wb + pos0 + p];  // p is final since the paint phase
+        if (p != kFinal) s_out[ring(pos0 + j)] = s_out[ring(pos0 + p)];  // p is final since the paint phase
       }
     }
     if (t == 0) {
@@ -404,6 +415,13 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     }
     if (t < kWords) s_mark[t] = 0;
     __syncthreads();
+    // the step's bytes are final: whole dwords go out now (ring and dst are dword-aligned alike)
+    {
+      const uint32_t end4 = next_pos & ~3u;
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+      for (uint32_t q = flushed + 4 * t; q < end4; q += 4 * KB_THREADS) o32[q >> 2] = *reinterpret_cast<const uint32_t*>(s_out + ring(q));
+      flushed = end4;
+    }
     tok_base = next_tok;
     pos0 = next_pos;
   }
@@ -411,32 +429,29 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     if (t == 0) info[seg].status = inflate::kError;
     return false;
   }
-  const uint4* w16 = reinterpret_cast<const uint4*>(s_out + wb);
-  uint4* o16 = reinterpret_cast<uint4*>(o);
-  const uint32_t nq = out_n / 16;
-  for (uint32_t k = t; k < nq; k += KB_THREADS) o16[k] = w16[k];
-  const uint32_t done = 16 * nq;
-  if (t < out_n - done) o[done + t] = s_out[wb + done + t];
+  if (t < out_n - flushed) o[flushed + t] = s_out[ring(flushed + t)];  // the last odd bytes
   return true;
 }
 
 // The byte-copy kernel: one workgroup per strip of `sps` segments (sps = 1: independent segments), the
 // segments in order, the window carried in LDS from one to the next.
-template <uint32_t kRing>
 __global__ __launch_bounds__(KB_THREADS) void k_inflate_bytes(const uint8_t* __restrict__ src, uint64_t src_n,
                                                               const uint32_t* __restrict__ tokens,
                                                               SegInfo* __restrict__ info, uint8_t* __restrict__ dst,
                                                               uint32_t nseg, uint32_t sps) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
   const uint32_t seg0 = blockIdx.x * sps;
+  uint32_t rb = 0;  // ring position of the segment's first byte: (k * kChunk) mod KB_RING
   for (uint32_t k = 0; k < sps && seg0 + k < nseg; ++k) {
-    if (!inflate_segment_bytes<kRing>(src, src_n, tokens, info, dst, seg0 + k, k * kChunk, s_dyn)) {
+    if (!inflate_segment_bytes(src, src_n, tokens, info, dst, seg0 + k, k * kChunk, rb, s_dyn)) {
       // the later segments of the strip depend on this one: they fail with it (first failure in stream
       // order is what the caller sees, k_inflate_status)
       for (uint32_t j = k + 1 + threadIdx.x; j < sps && seg0 + j < nseg; j += KB_THREADS)
         if (info[seg0 + j].status == inflate::kOk) info[seg0 + j].status = inflate::kError;
       return;
     }
+    rb += kChunk;
+    rb = rb >= KB_RING ? rb - KB_RING : rb;
     __syncthreads();  // the segment's window writes precede the next segment's reads
   }
 }
@@ -468,11 +483,8 @@ hipError_t init_inflate_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_tokens),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)KT_LDS);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_bytes<kChunk>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)KB_LDS);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_bytes<2 * kChunk>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_LDS_STRIP);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_inflate_bytes), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)KB_LDS);
 }
 
 hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint64_t* index, uint32_t nseg, uint64_t dst_n,
@@ -485,7 +497,11 @@ hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint6
 hipError_t launch_inflate_tokens_sub(const uint8_t* src, uint64_t src_n, const uint64_t* index, const uint32_t* subidx,
                                      uint32_t nseg, uint64_t dst_n, uint32_t* tokens, SegInfo* info, uint32_t sps,
                                      hipStream_t s) {
-  hipLaunchKernelGGL(k_inflate_tokens_sub, dim3((nseg + 1) / 2), dim3(64), 0, s, src, src_n, index, subidx, nseg, dst_n,
+  static const uint32_t extra = [] {  // diagnostic: SFH_D1_EXTRA_LDS=<bytes> lowers the occupancy
+    const char* e = getenv("SFH_D1_EXTRA_LDS");
+    return e ? (uint32_t)atoi(e) : 0u;
+  }();
+  hipLaunchKernelGGL(k_inflate_tokens_sub, dim3((nseg + 1) / 2), dim3(64), extra, s, src, src_n, index, subidx, nseg, dst_n,
                      tokens, info, sps);
   return hipGetLastError();
 }
@@ -493,12 +509,7 @@ hipError_t launch_inflate_tokens_sub(const uint8_t* src, uint64_t src_n, const u
 hipError_t launch_inflate_bytes(const uint8_t* src, uint64_t src_n, uint32_t nseg, const uint32_t* tokens, SegInfo* info,
                                 uint8_t* dst, uint32_t sps, hipStream_t s) {
   const uint32_t nstrips = (nseg + sps - 1) / sps;
-  if (sps == 1)
-    hipLaunchKernelGGL(k_inflate_bytes<kChunk>, dim3(nstrips), dim3(KB_THREADS), KB_LDS, s, src, src_n, tokens, info, dst,
-                       nseg, sps);
-  else
-    hipLaunchKernelGGL(k_inflate_bytes<2 * kChunk>, dim3(nstrips), dim3(KB_THREADS), KB_LDS_STRIP, s, src, src_n, tokens,
-                       info, dst, nseg, sps);
+  hipLaunchKernelGGL(k_inflate_bytes, dim3(nstrips), dim3(KB_THREADS), KB_LDS, s, src, src_n, tokens, info, dst, nseg, sps);
   return hipGetLastError();
 }
 

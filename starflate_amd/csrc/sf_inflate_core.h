@@ -52,10 +52,10 @@ struct LaneLayout {  // k_inflate_tokens: one segment per LANE, 64 of these per 
   static constexpr uint32_t kBytes = 2308;  // 577 dwords: an odd stride spreads the lanes over the LDS banks
 };
 struct SharedLayout {  // k_inflate_tokens_sub: one segment per WAVE, its 32 region lanes share the tables
-  static constexpr uint32_t kFastL = 10, kFastD = 8;
-  static constexpr uint32_t kOffFastL = 0, kOffSymL = 2048, kOffCntL = 2624, kOffFastD = 2656, kOffSymD = 3168,
-                            kOffCntD = 3232, kOffLens = 3264;
-  static constexpr uint32_t kBytes = 3584;
+  static constexpr uint32_t kFastL = 9, kFastD = 7;
+  static constexpr uint32_t kOffFastL = 0, kOffSymL = 1024, kOffCntL = 1600, kOffFastD = 1632, kOffSymD = 1888,
+                            kOffCntD = 1952, kOffLens = 1984;
+  static constexpr uint32_t kBytes = 2304;
 };
 constexpr uint32_t kOffClLut = 32;  // u8[128] inside the (not yet built) literal/length fast table
 
