@@ -497,11 +497,7 @@ hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint6
 hipError_t launch_inflate_tokens_sub(const uint8_t* src, uint64_t src_n, const uint64_t* index, const uint32_t* subidx,
                                      uint32_t nseg, uint64_t dst_n, uint32_t* tokens, SegInfo* info, uint32_t sps,
                                      hipStream_t s) {
-  static const uint32_t extra = [] {  // diagnostic: SFH_D1_EXTRA_LDS=<bytes> lowers the occupancy
-    const char* e = getenv("SFH_D1_EXTRA_LDS");
-    return e ? (uint32_t)atoi(e) : 0u;
-  }();
-  hipLaunchKernelGGL(k_inflate_tokens_sub, dim3((nseg + 1) / 2), dim3(64), extra, s, src, src_n, index, subidx, nseg, dst_n,
+  hipLaunchKernelGGL(k_inflate_tokens_sub, dim3((nseg + 1) / 2), dim3(64), 0, s, src, src_n, index, subidx, nseg, dst_n,
                      tokens, info, sps);
   return hipGetLastError();
 }

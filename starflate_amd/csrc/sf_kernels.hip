@@ -179,7 +179,7 @@ template <bool STAMPS, bool DEPTH2>
 __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     const uint8_t* __restrict__ src, uint64_t n_total, uint32_t strip_bytes, uint16_t* __restrict__ items,
     uint32_t* __restrict__ nitems_out, uint32_t* __restrict__ ntok_out, uint32_t* __restrict__ hist_out,
-    uint32_t* __restrict__ rtok_out, uint32_t lazy, uint32_t fast_skip, uint64_t* __restrict__ stamps, uint32_t dbg) {
+    uint32_t* __restrict__ rtok_out, uint32_t lazy, uint32_t fast_skip, uint64_t* __restrict__ stamps) {
   uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t st_t = 0;
   auto stamp = [&](int slot) {
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 const uint32_t xpa = kWindow + pb + mp, xca = xpa - s_dist[pb + mp];
                 const uint32_t xmax = rend - (pb + mp) < 258u ? rend - (pb + mp) : 258u;
                 uint32_t l = kCap;
-                while (l < xmax && !(dbg & 8)) {  // dbg 8: timing experiment only (capped matches stay capped)
+                while (l < xmax) {
                   const uint32_t ia = xpa + l, ja = xca + l;
                   const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
                   const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
@@ -490,12 +490,12 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             const uint32_t d1 = ((dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) - 1;
             const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
             const uint32_t sym = isM ? kHistLen + l3 : b;  // match lengths are counted raw: k_plan folds them into symbols
-            if (!(dbg & 2)) gi[idx] = (uint16_t)((isM ? (kItemMatch | l3) : b) | flag);
-            if (!(dbg & 1)) atomicAdd(&s_hist[sym], 1u);
+            gi[idx] = (uint16_t)((isM ? (kItemMatch | l3) : b) | flag);
+            atomicAdd(&s_hist[sym], 1u);
             if (isM) {
-              if (!(dbg & 2)) gi[idx + 1] = (uint16_t)d1;
+              gi[idx + 1] = (uint16_t)d1;
               uint32_t eb, ev;
-              if (!(dbg & 1)) atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
+              atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
             }
             idx += isM ? 2u : 1u;
             flag = 0;
@@ -1268,16 +1268,12 @@ hipError_t init_kernels() { return hipSuccess; }
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
                        const Options& opt, hipStream_t s) {
-  static const uint32_t dbg = [] {
-    const char* e = getenv("SFH_K1_DBG");
-    return e ? (uint32_t)atoi(e) : 0u;
-  }();
   if (opt.strip_bytes == 0 || opt.strip_bytes % kChunk || opt.strip_bytes > kMaxStrip) return hipErrorInvalidValue;
   const uint32_t per = opt.strip_bytes / kChunk;
   const uint32_t nstrips = (nchunks + per - 1) / per;
   const auto launch = [&](auto kernel, uint64_t* stamps) {
     hipLaunchKernelGGL(kernel, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items, ws.nitems, ws.ntok,
-                       ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps, dbg);
+                       ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps);
   };
   if (ws.stamps) {
     if (opt.depth2) launch(k_lz77<true, true>, ws.stamps); else launch(k_lz77<true, false>, ws.stamps);
