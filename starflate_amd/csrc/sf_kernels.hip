@@ -480,6 +480,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t dd[4] = {D.x, D.y, D.z, D.w};
         // first token of a sub-index region (its position is always a token start)
         uint32_t flag = (t & (kSubBytes / 8 - 1)) == 0 ? (kItemRegion | ((rc * kRSubs + pb / kSubBytes) << 8)) : 0u;
+        // item `i` of the chunk: uniform base + a 32-bit byte offset (one shift per store, no 64-bit address arithmetic)
+        auto put_item = [&](uint32_t i, uint32_t v) {
+          *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(uint32_t)(2u * i)) = (uint16_t)v;
+        };
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
           if ((marks >> k) & 1) {
@@ -490,10 +494,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             const uint32_t d1 = ((dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) - 1;
             const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
             const uint32_t sym = isM ? kHistLen + l3 : b;  // match lengths are counted raw: k_plan folds them into symbols
-            gi[idx] = (uint16_t)((isM ? (kItemMatch | l3) : b) | flag);
+            put_item(idx, (isM ? (kItemMatch | l3) : b) | flag);
             atomicAdd(&s_hist[sym], 1u);
             if (isM) {
-              gi[idx + 1] = (uint16_t)d1;
+              put_item(idx + 1, d1);
               uint32_t eb, ev;
               atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
             }
