@@ -354,6 +354,34 @@ def test_async_entry_point_and_independent_contexts():
     b.close()
 
 
+def test_one_context_on_two_streams_is_ordered(compressor):
+    """Calls on ONE context share its device scratch; the library orders a call behind the previous one even when
+    they are enqueued on different streams (an event between them), so interleaved enqueues on two streams give
+    the bytes of synchronous calls."""
+    import torch
+
+    da = torch.from_numpy(synth.gen_text(40 * CHUNK + 5, seed=51)).cuda()
+    db = torch.from_numpy(synth.gen_mixed(2 << 20, seed=52, stripe=1 << 15)).cuda()
+    want_a, na = compressor.compress_tensor(da)
+    want_a = want_a[:na].clone()
+    want_b, nb = compressor.compress_tensor(db, container="zlib")
+    want_b = want_b[:nb].clone()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    oa = [torch.zeros(compressor.compress_bound(da.numel()), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    ob = [torch.zeros(compressor.compress_bound(db.numel()), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    za = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(3)]
+    zb = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    for k in range(3):  # no host synchronisation in between
+        compressor.compress_tensor_async(da, oa[k], za[k], stream=sa.cuda_stream)
+        compressor.compress_tensor_async(db, ob[k], zb[k], stream=sb.cuda_stream, container="zlib")
+    sa.synchronize()
+    sb.synchronize()
+    for k in range(3):
+        assert int(za[k].item()) == na and torch.equal(oa[k][:na], want_a), k
+        assert int(zb[k].item()) == nb and torch.equal(ob[k][:nb], want_b), k
+
+
 def test_fuzz_bit_exact_vs_oracle(compressor):
     """Seeded fuzz: 300 inputs stitched from generators with very different match structure (runs, short and long
     periods, text, noise, low-entropy noise, counters, sparse bytes), sizes 0..160 KiB with ragged chunk tails."""
