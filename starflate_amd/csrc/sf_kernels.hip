@@ -155,14 +155,29 @@ __device__ __forceinline__ uint32_t cmp8(const uint32_t* d32, uint32_t a0, uint3
 
 // The same for ranking candidates: a candidate whose first four bytes differ can never become a match
 // (kMinMatch = 4), so it ranks as 0 whatever its shorter common prefix is -- the result only has to be exact from 4 up.
-__device__ __forceinline__ uint32_t rank8(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t c) {
+// All dwords are loaded up front and pinned there (empty asm): left alone, the compiler sinks the third load
+// of every candidate behind a branch on the first compare, which turns one LDS round trip per step into several
+// dependent ones.
+__device__ __forceinline__ uint32_t rank_of(uint32_t a0, uint32_t a1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t csh) {
   static_assert(kMinMatch == 4, "rank8: the first dword decides whether a candidate counts");
-  const uint32_t cw = c >> 2, csh = c & 3;
-  const uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2];
   const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
   const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
   const uint32_t f = (uint32_t)(__builtin_ffs((int)x1) - 1);  // 0xFFFFFFFF when bytes 4..7 are equal
   return x0 ? 0u : 4u + min(f >> 3, 4u);
+}
+__device__ __forceinline__ uint32_t rank8(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t c) {
+  const uint32_t cw = c >> 2;
+  uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2];
+  asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));
+  return rank_of(a0, a1, c0, c1, c2, c & 3);
+}
+__device__ __forceinline__ void rank8x2(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t ca, uint32_t cb,
+                                        uint32_t& la, uint32_t& lb) {
+  const uint32_t wa = ca >> 2, wb = cb >> 2;
+  uint32_t p0 = d32[wa], p1 = d32[wa + 1], p2 = d32[wa + 2], q0 = d32[wb], q1 = d32[wb + 1], q2 = d32[wb + 2];
+  asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(q0), "+v"(q1), "+v"(q2));
+  la = rank_of(a0, a1, p0, p1, p2, ca & 3);
+  lb = rank_of(a0, a1, q0, q1, q2, cb & 3);
 }
 
 // 16-bit step code -> position relative to the epoch's first step: (sc-1)*1024 + t with
@@ -308,8 +323,9 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 != 0 && ad - c1 <= kWindow;
         const uint32_t q0 = ok0 ? c0 : ad, q1 = ok1 ? c1 : ad;
         // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
-        const uint32_t l0 = rank8(s_data, a0, a1, q0);
-        const uint32_t l1 = DEPTH2 ? rank8(s_data, a0, a1, q1) : 0u;
+        uint32_t l0, l1 = 0;
+        if constexpr (DEPTH2) rank8x2(s_data, a0, a1, q0, q1, l0, l1);
+        else l0 = rank8(s_data, a0, a1, q0);
         const uint32_t lf0 = ok0 ? l0 : 0u, lf1 = ok1 ? l1 : 0u;
         __syncthreads();  // every far read of this step precedes every insertion of this step
         {
