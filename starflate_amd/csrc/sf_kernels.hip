@@ -1188,6 +1188,16 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
     uint64_t val[K4_IPT];
     uint32_t nb[K4_IPT], mine = 0;
     uint32_t starts = 0;  // bit k: item k starts a token and carries the region flag
+    // the two table reads that depend on the item alone (its code as a literal, its code + extra bits as a match
+    // length) for all eight items at once, pinned: sixteen LDS reads in flight instead of a chain of dependent ones
+    uint32_t lcv[K4_IPT], lev[K4_IPT];
+#pragma unroll
+    for (uint32_t k = 0; k < K4_IPT; ++k) {
+      lcv[k] = s_lcode[e[k + 1] & 0xFFu];
+      lev[k] = s_lenlut[e[k + 1] & 0xFFu];
+    }
+    asm volatile("" : "+v"(lcv[0]), "+v"(lcv[1]), "+v"(lcv[2]), "+v"(lcv[3]), "+v"(lcv[4]), "+v"(lcv[5]), "+v"(lcv[6]), "+v"(lcv[7]),
+                      "+v"(lev[0]), "+v"(lev[1]), "+v"(lev[2]), "+v"(lev[3]), "+v"(lev[4]), "+v"(lev[5]), "+v"(lev[6]), "+v"(lev[7]));
 #pragma unroll
     for (uint32_t k = 0; k < K4_IPT; ++k) {
       const uint32_t cur = e[k + 1];
@@ -1195,8 +1205,20 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
       val[k] = 0;
       nb[k] = 0;
       if (!cont && i0 + k < nit) {
-        if (cur & kItemMatch) match_bits(cur & 0xFFu, e[k + 2] & 0x7FFFu, s_lenlut, s_dcode, val[k], nb[k]);
-        else literal_bits(cur & 0xFFu, s_lcode, val[k], nb[k]);
+        if (cur & kItemMatch) {
+          uint32_t de, dv;
+          const uint32_t dc = s_dcode[dist_symbol(e[k + 2] & 0x7FFFu, de, dv)];
+          uint32_t p = lev[k] >> 24;
+          uint64_t v = lev[k] & 0xFFFFFFu;
+          v |= (uint64_t)(dc & 0xFFFF) << p;
+          p += dc >> 16;
+          v |= (uint64_t)dv << p;
+          val[k] = v;
+          nb[k] = p + de;
+        } else {
+          val[k] = lcv[k] & 0xFFFF;
+          nb[k] = lcv[k] >> 16;
+        }
         if (cur & kItemRegion) starts |= 1u << k;
       }
       mine += nb[k];
