@@ -112,6 +112,19 @@ def test_batches_give_the_stream_of_one_launch(monkeypatch):
         c.close()
 
 
+def test_largest_and_odd_strips(compressor):
+    """block_bytes at its maximum (16 MiB: the table's step codes are aged a thousand times, the decoder walks 512
+    segments per strip) and at a non-power-of-two multiple of 32 KiB: bit-exact, and decodable on the GPU."""
+    data = np.concatenate([synth.gen_text(20 << 20, seed=71), synth.gen_mixed(13 << 20, seed=72, stripe=1 << 18)[: (13 << 20) - 77]])
+    for bb in (16 << 20, 3 * CHUNK):
+        got = np.frombuffer(compressor.compress(data, block_bytes=bb), np.uint8)
+        assert np.array_equal(got, O.compress(data, O.default_params(strip_bytes=bb))), bb
+        back, st = compressor.decompress(got, compressor.last_index(), data.size, subindex=compressor.last_subindex(), block_bytes=bb)
+        assert st == 0 and back == data.tobytes(), bb
+    with pytest.raises(Exception):
+        compressor.compress(data[:CHUNK], block_bytes=(16 << 20) + CHUNK)  # beyond the maximum
+
+
 def test_default_block_bytes_rule(compressor):
     """block_bytes = 0 stands for a function of the input size alone (the oracle and the library share the rule)."""
     for n in (0, 1, CHUNK, 50 * CHUNK, (8 << 20) + 5, 16 << 20, (64 << 20) + 1):
