@@ -2,11 +2,12 @@
 //
 // Pipeline (one HIP stream, four launches per call):
 //   K1 k_lz77   one 1024-thread workgroup per STRIP (block_bytes of input, a whole number of 32 KiB
-//               chunks, coded independently of what precedes it): a 32 KiB window + the 4 KiB round in
+//               chunks, coded independently of what precedes it): a 32 KiB window + the 8 KiB round in
 //               flight + the hash table + per-position (len,dist) of the round in LDS; step-synchronous
-//               hash insertion, candidate compare, speculative lane-parallel greedy/lazy parse;
-//               16-bit token items + histogram out, one DEFLATE block per chunk
-//   K2 k_plan   one wave per chunk: length-limited Huffman lengths (ll, d, cl),
+//               hash insertion (two history levels per bucket), candidate compare, wave-local
+//               register-resident greedy/lazy parse; 16-bit token items + histogram out, one DEFLATE
+//               block per chunk
+//   K2 k_plan   one wave per chunk: raw length counts folded into symbols, length-limited Huffman lengths (ll, d, cl),
 //               canonical codes, dynamic header bits, block type, exact byte size
 //   K3 k_scan   exclusive scan of chunk byte sizes -> output offsets, total
 //   K4 k_emit   one workgroup per chunk: bit-pack tokens into LDS, flush to the
@@ -14,8 +15,10 @@
 // With a zlib / gzip container two more launches (sf_checksum.hip):
 //   K5 k_checksum  one workgroup per chunk: Adler-32 / CRC-32 partial of the chunk's input bytes
 //   K6 k_wrap      one workgroup: fold the partials, write wrapper header + trailer
+// A call on more than kBatchChunks chunks runs K1..K4 batch after batch (bounded scratch); the host-buffer entry
+// point pipelines smaller batches with their copies.
 // The decoder (sf_inflate.hip, sf_inflate_core.h) runs the other way: k_inflate_tokens[_sub] (Huffman codes ->
-// tokens), k_inflate_bytes (tokens -> bytes), k_inflate_status.
+// tokens, all segments at once), k_inflate_bytes (tokens -> bytes, strip by strip), k_inflate_status.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

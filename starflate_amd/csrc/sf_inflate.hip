@@ -1,9 +1,9 @@
 // sf_inflate.hip -- GPU decode of block-indexed DEFLATE streams: the reference's
-// decompress() (/root/reference/src/decompress.cpp:402-461) for streams whose independently decodable
-// segments are known -- every stream this library writes (one segment per 32 KiB chunk, byte-aligned, no
-// match reaching before the segment; the index is the chunk offset table k_scan already produces), and
-// e.g. zlib streams flushed with Z_FULL_FLUSH every 32 KiB.  Arbitrary DEFLATE is serial (README.md:5-6);
-// the index is what makes it parallel.
+// decompress() (/root/reference/src/decompress.cpp:402-461) for streams whose byte-aligned segments and
+// independently decodable strips are known -- every stream this library writes (one segment per 32 KiB chunk;
+// no match reaches before its strip of block_bytes; the index is the chunk offset table k_scan already
+// produces), and e.g. zlib streams with Z_SYNC_FLUSH every 32 KiB and Z_FULL_FLUSH at the strip boundaries.
+// Arbitrary DEFLATE is serial (README.md:5-6); the index is what makes it parallel.
 //
 //   k_inflate_tokens  the bit-serial half.  Huffman decoding cannot be split inside a segment, so the SIMT
 //                     mapping is one LANE per segment: 64 segments per wave, each lane running
@@ -11,7 +11,8 @@
 //                     of LDS (144 KiB per workgroup) and its own 64-bit bit buffer fed by dword loads one
 //                     refill ahead.  Output: the k_lz77 token format, four tokens per 16-byte store.
 //   k_inflate_bytes   the byte-copy half (src/decompress.cpp:157-187,388-398), one 512-thread workgroup per
-//                     segment, the 32 KiB output window in LDS, steps of <= 1024 tokens / 3968 bytes: a
+//                     strip, its segments in order, the output window a 36 KiB ring in LDS (the 32 KiB a match
+//                     may reach back + the step in flight), steps of <= 1024 tokens / 3968 bytes: a
 //                     workgroup prefix sum places the tokens, every thread then takes BYTES (token found by
 //                     bitmap + popcount): sources before the step are final and copied at once, sources
 //                     inside it become 16-bit pointers that pointer jumping resolves in a few barrier-

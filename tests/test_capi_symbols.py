@@ -37,6 +37,10 @@ def test_host_side_entry_points_without_gpu():
         assert lib.sfh_compress_bound(32768, bb) == 32768 + 4096 + 640
         assert lib.sfh_compress_bound(32769, bb) == 2 * (32768 + 4096 + 640)
     assert _capi.resolve_block_bytes(0, 1 << 30) == 262144 and _capi.resolve_block_bytes(0, 1 << 20) == 32768
+    import oracle_lib as O  # the specification's rule for strip_bytes = 0 is the library's for block_bytes = 0
+
+    for n in (0, 1, 32768, 8 << 20, (8 << 20) + 1, 16 << 20, 64 << 20, (64 << 20) - 1, 1 << 30, 5 << 30):
+        assert _capi.resolve_block_bytes(0, n) == O.resolve_strip_bytes(O.default_params(), n), n
     assert lib.sfh_stage_name(0) == b"k_lz77" and lib.sfh_stage_name(3) == b"k_emit" and lib.sfh_stage_name(9) == b""
     import zlib
     a, b = bytes(range(256)) * 300, b"starflate" * 5000  # host-side checksum combine rules against zlib
