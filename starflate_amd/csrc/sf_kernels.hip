@@ -122,25 +122,15 @@ static_assert(L_WTOT % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0 && L_LEN
 static_assert(kCap - 3 <= 15, "capped len-3 fits four bits");
 static_assert((kWindow + kLook) % 16 == 0 && kRound % 16 == 0, "window shift in 16-byte units");
 
-// first mismatching byte (0..16) between the 16 bytes in a0..a3 and those at LDS byte address c
-__device__ __forceinline__ uint32_t cmp16(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t a2,
-                                          uint32_t a3, uint32_t c) {
-  const uint32_t cw = c >> 2, csh = c & 3;
-  const uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2], c3 = d32[cw + 3], c4 = d32[cw + 4];
-  const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
-  const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
-  const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(c3, c2, csh);
-  const uint32_t x3 = a3 ^ __builtin_amdgcn_alignbyte(c4, c3, csh);
-  // first differing dword by a select chain, then ONE find-first-bit: v_ffbl_b32 of 0 is
-  // 0xFFFFFFFF, so sixteen equal bytes fall out as a huge value and the final min gives 16
-  uint32_t x = x2 ? x2 : x3, base = x2 ? 8u : 12u;
-  x = x1 ? x1 : x;
-  base = x1 ? 4u : base;
-  x = x0 ? x0 : x;
-  base = x0 ? 0u : base;
-  const uint32_t f = (uint32_t)(__builtin_ffs((int)x) - 1);
-  return min(base + (f >> 3), 16u);
+// v_ffbl_b32 as the hardware defines it: the lowest set bit, 0xFFFFFFFF for 0 (spelled out, because the C
+// builtins leave 0 undefined or make the compiler add a compare and a select to patch it)
+__device__ __forceinline__ uint32_t ffbl(uint32_t x) {
+  uint32_t r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
+// lowest set bit of x1:x0 (0..63), 0xFFFFFFFF when both are 0: the OR leaves the all-ones alone, the MIN skips it
+__device__ __forceinline__ uint32_t first_bit64(uint32_t x0, uint32_t x1) { return min(ffbl(x0), ffbl(x1) | 32u); }
 
 // first mismatching byte (0..8) between the 8 bytes in a0,a1 and those at LDS byte address c
 __device__ __forceinline__ uint32_t cmp8(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t c) {
@@ -148,9 +138,7 @@ __device__ __forceinline__ uint32_t cmp8(const uint32_t* d32, uint32_t a0, uint3
   const uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2];
   const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
   const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
-  const uint32_t x = x0 ? x0 : x1, base = x0 ? 0u : 4u;
-  const uint32_t f = (uint32_t)(__builtin_ffs((int)x) - 1);  // 0xFFFFFFFF when all eight bytes are equal
-  return min(base + (f >> 3), 8u);
+  return min(first_bit64(x0, x1) >> 3, 8u);
 }
 
 // The same for ranking candidates: a candidate whose first four bytes differ can never become a match
@@ -185,6 +173,14 @@ __device__ __forceinline__ void rank8x2(const uint32_t* d32, uint32_t a0, uint32
 // keeps the same winner (the first position of the latest step)
 static_assert(kStep == 1024, "entry encoding");
 __device__ __forceinline__ uint32_t entry_pos(uint32_t v) { return v - 1u - 2u * (v & 1023u); }
+// entry_pos(v) + k1 + 1 in three instructions (the multiply-add is spelled out: left to itself the compiler
+// expands the expression into twice as many shifts and masks)
+__device__ __forceinline__ uint32_t entry_addr(uint32_t v, uint32_t k1) {
+  const uint32_t lo = v & 1023u;
+  uint32_t c;
+  asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(c) : "v"(lo), "v"(v));
+  return c + k1;
+}
 
 // STAMPS: diagnostic build only (SFH_K1_STAMPS=1), s_memtime at phase boundaries into `stamps`
 // [strip][8] = cycles in {stage, match, take, walk, segpre, emit, flush}; never used for timing claims.
@@ -319,7 +315,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t farv = s_table[h];
         // the far candidates only need the (immutable) window: compare them ahead of the barriers
         const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
-        const uint32_t c0 = entry_pos(f0) + K, c1 = entry_pos(f1) + K;
+        const uint32_t c0 = entry_addr(f0, K - 1), c1 = entry_addr(f1, K - 1);
         const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 != 0 && ad - c1 <= kWindow;
         const uint32_t q0 = ok0 ? c0 : ad, q1 = ok1 ? c1 : ad;
         // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
@@ -336,7 +332,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         }
         __syncthreads();  // insertions complete before the near reads
         const uint32_t nv = s_table[h] >> 16;
-        const uint32_t nc = entry_pos(nv) + K;
+        const uint32_t nc = entry_addr(nv, K - 1);
         const bool okn = nv != 0 && nc < ad;
         const uint32_t qnr = okn ? nc : ad;
         const uint32_t ln = rank8(s_data, a0, a1, qnr);
