@@ -132,13 +132,15 @@ __device__ __forceinline__ uint32_t ffbl(uint32_t x) {
 // lowest set bit of x1:x0 (0..63), 0xFFFFFFFF when both are 0: the OR leaves the all-ones alone, the MIN skips it
 __device__ __forceinline__ uint32_t first_bit64(uint32_t x0, uint32_t x1) { return min(ffbl(x0), ffbl(x1) | 32u); }
 
-// first mismatching byte (0..8) between the 8 bytes in a0,a1 and those at LDS byte address c
+// first mismatching byte between the 8 bytes in a0,a1 and those at LDS byte address c + 4*WOFF (the word offset
+// rides in the loads' immediate field); some huge value when all eight are equal
+template <uint32_t WOFF>
 __device__ __forceinline__ uint32_t cmp8(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t c) {
   const uint32_t cw = c >> 2, csh = c & 3;
-  const uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2];
+  const uint32_t c0 = d32[cw + WOFF], c1 = d32[cw + WOFF + 1], c2 = d32[cw + WOFF + 2];
   const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
   const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
-  return min(first_bit64(x0, x1) >> 3, 8u);
+  return first_bit64(x0, x1) >> 3;
 }
 
 // The same for ranking candidates: a candidate whose first four bytes differ can never become a match
@@ -146,26 +148,32 @@ __device__ __forceinline__ uint32_t cmp8(const uint32_t* d32, uint32_t a0, uint3
 // All dwords are loaded up front and pinned there (empty asm): left alone, the compiler sinks the third load
 // of every candidate behind a branch on the first compare, which turns one LDS round trip per step into several
 // dependent ones.
-__device__ __forceinline__ uint32_t rank_of(uint32_t a0, uint32_t a1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t csh) {
-  static_assert(kMinMatch == 4, "rank8: the first dword decides whether a candidate counts");
+__device__ __forceinline__ uint32_t rank_of(uint32_t a0, uint32_t a1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t csh,
+                                            uint32_t maxlen) {
+  static_assert(kMinMatch == 4 && kRank == 8, "rank8: the first dword decides whether a candidate counts");
   const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(c1, c0, csh);
   const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(c2, c1, csh);
-  const uint32_t f = (uint32_t)(__builtin_ffs((int)x1) - 1);  // 0xFFFFFFFF when bytes 4..7 are equal
-  return x0 ? 0u : 4u + min(f >> 3, 4u);
+  // min(4 + equal bytes among 4..7, kRank, maxlen) as ONE three-way minimum (spelled out: the compiler rewrites
+  // min(4 + x, 8) into 4 + min(x, 4) and then needs a second minimum); ffbl: 0xFFFFFFFF when bytes 4..7 are equal
+  const uint32_t l = 4u + (ffbl(x1) >> 3);
+  uint32_t r;
+  asm("v_min3_u32 %0, %1, 8, %2" : "=v"(r) : "v"(l), "v"(maxlen));
+  return x0 ? 0u : r;
 }
-__device__ __forceinline__ uint32_t rank8(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t c) {
+// rank of the candidate at LDS byte address c, capped at maxlen
+__device__ __forceinline__ uint32_t rank8(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t c, uint32_t maxlen) {
   const uint32_t cw = c >> 2;
   uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2];
   asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));
-  return rank_of(a0, a1, c0, c1, c2, c & 3);
+  return rank_of(a0, a1, c0, c1, c2, c & 3, maxlen);
 }
 __device__ __forceinline__ void rank8x2(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t ca, uint32_t cb,
-                                        uint32_t& la, uint32_t& lb) {
+                                        uint32_t maxlen, uint32_t& la, uint32_t& lb) {
   const uint32_t wa = ca >> 2, wb = cb >> 2;
   uint32_t p0 = d32[wa], p1 = d32[wa + 1], p2 = d32[wa + 2], q0 = d32[wb], q1 = d32[wb + 1], q2 = d32[wb + 2];
   asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(q0), "+v"(q1), "+v"(q2));
-  la = rank_of(a0, a1, p0, p1, p2, ca & 3);
-  lb = rank_of(a0, a1, q0, q1, q2, cb & 3);
+  la = rank_of(a0, a1, p0, p1, p2, ca & 3, maxlen);
+  lb = rank_of(a0, a1, q0, q1, q2, cb & 3, maxlen);
 }
 
 // 16-bit step code -> position relative to the epoch's first step: (sc-1)*1024 + t with
@@ -318,11 +326,14 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t c0 = entry_addr(f0, K - 1), c1 = entry_addr(f1, K - 1);
         const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 != 0 && ad - c1 <= kWindow;
         const uint32_t q0 = ok0 ? c0 : ad, q1 = ok1 ? c1 : ad;
+        // bytes a match may take from here: inside the round's valid part, the parse region and kCap (0 beyond qn)
+        const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
+        const uint32_t maxlen = (uint32_t)max(min(min((int)(qn - rel), (int)(rend - rel)), (int)kCap), 0);
         // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
         uint32_t l0, l1 = 0;
-        if constexpr (DEPTH2) rank8x2(s_data, a0, a1, q0, q1, l0, l1);
-        else l0 = rank8(s_data, a0, a1, q0);
-        const uint32_t lf0 = ok0 ? l0 : 0u, lf1 = ok1 ? l1 : 0u;
+        if constexpr (DEPTH2) rank8x2(s_data, a0, a1, q0, q1, maxlen, l0, l1);
+        else l0 = rank8(s_data, a0, a1, q0, maxlen);
+        const uint32_t m0 = ok0 ? l0 : 0u, m1 = ok1 ? l1 : 0u;
         __syncthreads();  // every far read of this step precedes every insertion of this step
         {
           // positions without kMinMatch bytes left insert 0, which MAX ignores
@@ -331,34 +342,36 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           atomicMax(&s_table[h], v);
         }
         __syncthreads();  // insertions complete before the near reads
-        const uint32_t nv = s_table[h] >> 16;
-        const uint32_t nc = entry_addr(nv, K - 1);
-        const bool okn = nv != 0 && nc < ad;
+        // the step's first position with this hash: this one's own entry at the latest, so the bucket is not empty
+        // (a position without kMinMatch bytes left inserted nothing and may read an empty one: whatever that
+        // decodes to, maxlen < kMinMatch keeps it from becoming a match)
+        const uint32_t nc = entry_addr(s_table[h] >> 16, K - 1);
+        const bool okn = nc < ad;
         const uint32_t qnr = okn ? nc : ad;
-        const uint32_t ln = rank8(s_data, a0, a1, qnr);
-        const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
-        uint32_t maxlen = (rel < qn) ? (qn - rel < kCap ? qn - rel : kCap) : 0u;
-        maxlen = rend - rel < maxlen ? rend - rel : maxlen;
+        const uint32_t ln = rank8(s_data, a0, a1, qnr, maxlen);
         // longest wins; ties go to the smaller distance: near, then the newer far level
-        uint32_t best = okn ? (ln < maxlen ? ln : maxlen) : 0u;
+        uint32_t best = okn ? ln : 0u;
         uint32_t bq = qnr;
-        const uint32_t m0 = lf0 < maxlen ? lf0 : maxlen, m1 = lf1 < maxlen ? lf1 : maxlen;
         if (m0 > best) { best = m0; bq = q0; }
         if (m1 > best) { best = m1; bq = q1; }
         const uint32_t bd = ad - bq;
         {
           // the winner's next eight bytes (they only count when its first kRank all matched)
-          const uint32_t lx = kRank + cmp8(s_data, a2, a3, bq + kRank);
+          const uint32_t lx = kRank + cmp8<kRank / 4>(s_data, a2, a3, bq);  // maxlen <= kCap does the capping
           best = best == kRank ? (lx < maxlen ? lx : maxlen) : best;
         }
         // a 4-byte match farther than kFar4 costs more bits than four literals: drop it.  (maxlen <= n - p, so a
         // position without kMinMatch bytes left cannot reach kMinMatch.)
-        const bool ok = best >= kMinMatch && !(best == 4 && bd > kFar4);
+        const bool ok = best >= (bd > kFar4 ? kMinMatch + 1 : kMinMatch);
         s_dist[rel] = (uint16_t)bd;  // only read where the length says there is a match
         // two lanes' 4-bit lengths -> one byte (the odd lane's value comes over the DPP network)
         uint32_t v = ok ? best - 3 : 0u;
         v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
-        if ((t & 1) == 0) reinterpret_cast<uint8_t*>(s_len4)[rel >> 1] = (uint8_t)v;
+        // stored by the even lanes.  All 1024 threads are active here, so the execution mask is switched and
+        // restored by hand: two scalar moves instead of the save / branch / restore a divergent `if` compiles to
+        // (smem sits at LDS address 0: it is the kernel's only __shared__ object)
+        asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
+                     :: "v"(rel >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
       }
       __syncthreads();
       stamp(1);
