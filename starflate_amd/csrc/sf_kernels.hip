@@ -162,14 +162,14 @@ __device__ __forceinline__ uint32_t rank_of(uint32_t a0, uint32_t a1, uint32_t c
 }
 // rank of the candidate at LDS byte address c, capped at maxlen
 __device__ __forceinline__ uint32_t rank8(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t c, uint32_t maxlen) {
-  const uint32_t cw = c >> 2;
+  const uint32_t cw = (c & 0xFFFFu) >> 2;  // any c reads inside the LDS allocation (see the call site)
   uint32_t c0 = d32[cw], c1 = d32[cw + 1], c2 = d32[cw + 2];
   asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));
   return rank_of(a0, a1, c0, c1, c2, c & 3, maxlen);
 }
 __device__ __forceinline__ void rank8x2(const uint32_t* d32, uint32_t a0, uint32_t a1, uint32_t ca, uint32_t cb,
                                         uint32_t maxlen, uint32_t& la, uint32_t& lb) {
-  const uint32_t wa = ca >> 2, wb = cb >> 2;
+  const uint32_t wa = (ca & 0xFFFFu) >> 2, wb = (cb & 0xFFFFu) >> 2;  // any address reads inside the LDS allocation
   uint32_t p0 = d32[wa], p1 = d32[wa + 1], p2 = d32[wa + 2], q0 = d32[wb], q1 = d32[wb + 1], q2 = d32[wb + 2];
   asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(q0), "+v"(q1), "+v"(q2));
   la = rank_of(a0, a1, p0, p1, p2, ca & 3, maxlen);
@@ -311,9 +311,9 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // ---- match finding over this round ----
       const uint32_t nsteps = (qn + kStep - 1) / kStep;
       const uint32_t K = kWindow + ebase * kStep - rb;  // LDS byte address of a coded position = entry_pos(code) + K (mod 2^32)
+      uint32_t code = ((rb / kStep - ebase + 1) << 10) | (1023u - t);  // this thread's step code, step by step
       for (uint32_t s = 0; s < nsteps; ++s) {
         const uint32_t rel = s * kStep + t;
-        const uint32_t p = rb + rel;                       // strip position
         const uint32_t ad = kWindow + rel;                 // its LDS byte address
         const uint32_t dw = ad >> 2, sh0 = ad & 3;
         const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2], d3 = s_data[dw + 3], d4 = s_data[dw + 4];
@@ -325,7 +325,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
         const uint32_t c0 = entry_addr(f0, K - 1), c1 = entry_addr(f1, K - 1);
         const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 != 0 && ad - c1 <= kWindow;
-        const uint32_t q0 = ok0 ? c0 : ad, q1 = ok1 ? c1 : ad;
+        // an empty or outdated entry decodes to some address that is not a candidate: it is still read (kept inside
+        // the LDS allocation by a 16-bit mask that leaves real candidates alone), its rank is dropped
+        static_assert(kWindow + kRound + kLook <= 0x10000 && 0x10000 + 16 <= K1_LDS, "candidate reads stay in LDS");
+        const uint32_t q0 = c0, q1 = c1;
         // bytes a match may take from here: inside the round's valid part, the parse region and kCap (0 beyond qn)
         const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
         const uint32_t maxlen = (uint32_t)max(min(min((int)(qn - rel), (int)(rend - rel)), (int)kCap), 0);
@@ -336,16 +339,18 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t m0 = ok0 ? l0 : 0u, m1 = ok1 ? l1 : 0u;
         __syncthreads();  // every far read of this step precedes every insertion of this step
         {
-          // positions without kMinMatch bytes left insert 0, which MAX ignores
-          const uint32_t code = ((rb / kStep + s - ebase + 1) << 10) | (1023u - t);
-          const uint32_t v = (p + kMinMatch <= n) ? ((code << 16) | f0) : 0u;
-          atomicMax(&s_table[h], v);
+          // {code, old newest}: the upper half of code:farv.  The specification lets positions without kMinMatch
+          // bytes left insert nothing; here they insert like the rest, which nothing can observe: every position
+          // after them in the strip is such a position too and takes no match (maxlen < kMinMatch), the next
+          // strip starts from an empty table
+          atomicMax(&s_table[h], __builtin_amdgcn_alignbit(code, farv, 16));
+          code += 1u << 10;
         }
         __syncthreads();  // insertions complete before the near reads
         // the step's first position with this hash: this one's own entry at the latest, so the bucket is not empty
-        // (a position without kMinMatch bytes left inserted nothing and may read an empty one: whatever that
-        // decodes to, maxlen < kMinMatch keeps it from becoming a match)
-        const uint32_t nc = entry_addr(s_table[h] >> 16, K - 1);
+        // (and it is of this very step: only its thread index has to be decoded)
+        uint32_t nc;  // = address of the step's thread 1023 - the entry's low ten bits, the former kept scalar
+        asm("v_sub_u32 %0, %1, %2" : "=v"(nc) : "s"(kWindow + s * kStep + 1023u), "v"((s_table[h] >> 16) & 1023u));
         const bool okn = nc < ad;
         const uint32_t qnr = okn ? nc : ad;
         const uint32_t ln = rank8(s_data, a0, a1, qnr, maxlen);
