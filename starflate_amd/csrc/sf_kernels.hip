@@ -504,15 +504,16 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // ---- emit: the lane's chain positions -> items (compact, chunk order) + histogram ----
       if (marks) {
         const uint32_t before = wbase + incl - mine;
-        uint32_t idx = tot_items + (before & 0xFFFFu) + (before >> 16);
+        uint32_t ib = 2u * (tot_items + (before & 0xFFFFu) + (before >> 16));  // byte offset of the lane's next item
         const uint4 D = *reinterpret_cast<const uint4*>(&s_dist[pb]);
         const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + pb]);
         const uint32_t dd[4] = {D.x, D.y, D.z, D.w};
-        // first token of a sub-index region (its position is always a token start)
-        uint32_t flag = (t & (kSubBytes / 8 - 1)) == 0 ? (kItemRegion | ((rc * kRSubs + pb / kSubBytes) << 8)) : 0u;
-        // item `i` of the chunk: uniform base + a 32-bit byte offset (one shift per store, no 64-bit address arithmetic)
-        auto put_item = [&](uint32_t i, uint32_t v) {
-          *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(uint32_t)(2u * i)) = (uint16_t)v;
+        // first token of a sub-index region: its position is the region's first, which is always a token start,
+        // so the flag can only ever go onto the lane's slot 0
+        const uint32_t flag = (t & (kSubBytes / 8 - 1)) == 0 ? (kItemRegion | ((rc * kRSubs + pb / kSubBytes) << 8)) : 0u;
+        // an item of the chunk: uniform base + a 32-bit byte offset (no 64-bit address arithmetic)
+        auto put_item = [&](uint32_t byte_off, uint32_t v) {
+          *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)byte_off) = (uint16_t)v;
         };
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
@@ -524,15 +525,15 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             const uint32_t d1 = ((dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) - 1;
             const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
             const uint32_t sym = isM ? kHistLen + l3 : b;  // match lengths are counted raw: k_plan folds them into symbols
-            put_item(idx, (isM ? (kItemMatch | l3) : b) | flag);
+            const uint32_t item = isM ? (kItemMatch | l3) : b;
+            put_item(ib, k == 0 ? (item | flag) : item);
             atomicAdd(&s_hist[sym], 1u);
             if (isM) {
-              put_item(idx + 1, d1);
+              put_item(ib + 2, d1);
               uint32_t eb, ev;
               atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
             }
-            idx += isM ? 2u : 1u;
-            flag = 0;
+            ib += isM ? 4u : 2u;
           }
         }
       }
@@ -580,22 +581,26 @@ __device__ __forceinline__ void or_bits(uint32_t* stage, uint32_t bitpos, uint64
   if (v2) atomicOr(&stage[w + 2], v2);
 }
 
-// 6 KiB per workgroup (one wave): the CU holds as many chunks in flight as its wave slots allow, which is what a
+// 5 KiB per workgroup (one wave): the CU then holds a chunk in every one of its 32 wave slots, which is what a
 // latency-bound kernel wants.  Node weights fit 16 bits (a chunk has at most kChunk tokens + the end-of-block).
+// The tree arrays are only fully used by the literal/length tree; what comes after the two big trees (run-length
+// items, the code-length code's counts / codes / lengths) lives in their tails -- the code-length tree itself has
+// 19 leaves and touches w[0..36], parent[0..36] and key[0..18].
 struct PlanSmem {
   uint32_t freq[320];  // ll [0..285], d [288..317]
   uint32_t key[288];   // sorted (freq << 9 | symbol); entries 32.. double as the header bit image (see kHeaderAt)
-  uint16_t w[576];
-  uint16_t parent[576];
-  uint32_t cnt[16];
-  uint8_t lens[320];  // ll [0..287], d [288..319]
-  uint8_t cl_lens[32];
-  uint32_t cl_code[32];
-  uint32_t clfreq[32];
-  uint8_t rle_sym[320];
-  uint8_t rle_ext[320];
-  uint32_t misc[8];
+  union {
+    uint16_t w[576];
+    struct { uint16_t w_head[64]; uint8_t rle_sym[320]; uint8_t rle_ext[320]; };
+  };
+  union {
+    uint16_t parent[576];
+    struct { uint16_t parent_head[128]; uint32_t clfreq[32]; uint32_t cl_code[32]; uint8_t cl_lens[32]; };
+  };
+  uint32_t cnt[16];    // leaves per depth 1..15; [0] carries the header's bit count at the end
+  uint8_t lens[320];   // ll [0..287], d [288..319]
 };
+static_assert(sizeof(PlanSmem) == 5120, "k_plan: 32 workgroups per CU");
 // The header image is built after the literal/length and distance trees are done; the code-length tree that is
 // built in between only touches key[0..18].
 constexpr uint32_t kHeaderAt = 32;
@@ -954,12 +959,12 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
       if (nb) or_bits(s_header, bitbase + incl - nb, v);
       bitbase += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-    if (lane == 0) S.misc[3] = bitbase;  // includes the 3 block-header bits
+    if (lane == 0) S.cnt[0] = bitbase;  // includes the 3 block-header bits
   }
   __syncthreads();
 
   stamp();  // 5 header bits
-  const uint32_t dyn_hbits = S.misc[3];
+  const uint32_t dyn_hbits = S.cnt[0];
   const uint32_t dyn_bits = dyn_hbits + dyn_body;
   const uint32_t fix_bits = 3 + fix_body;
   const uint32_t dyn_bytes = fin ? (dyn_bits + 7) / 8 : (dyn_bits + 3 + 7) / 8 + 4;
