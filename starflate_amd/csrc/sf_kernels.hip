@@ -435,9 +435,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             const bool act = pos < nv;
             const uint32_t m = act ? (T >> (pos & 7)) : 0u;
             const bool hit = m != 0;
-            const uint32_t k = hit ? (uint32_t)__builtin_ctz(m) : 0u;
-            const uint32_t tail = ((1u << nv) - 1u) & ~((1u << (pos & 7)) - 1u);  // literals to the lane's end
-            mk |= hit ? (((2u << k) - 1u) << (pos & 7)) : (act ? tail : 0u);   // literals, then the match position
+            const uint32_t k = ffbl(m) & 7u;  // only used where hit (m has a bit among its low eight)
+            // literals from pos up to the match position (or the lane's last valid one): bits pos&7 .. hi
+            const uint32_t hi = hit ? (pos & 7) + k : nv - 1u;
+            mk |= act ? (2u << hi) - (1u << (pos & 7)) : 0u;
             const uint32_t mp = (pos + k) & 7;
             uint32_t len = ((N >> (4 * mp)) & 15u) + 3;
             if (hit && len == kCap) {                    // capped at match time: extend (once per position)
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           const uint32_t pm = wave_excl_max(exit_abs);
           const uint32_t ne = pm > lb ? pm - lb : 0u;  // where the chain enters this lane (>= nv: it jumps over it)
           const bool changed = ne != entry && nv != 0;
-          if (!__any(changed)) break;
+          if (__builtin_amdgcn_ballot_w64(changed) == 0) break;
           if constexpr (STAMPS) st_acc[7] += 1;  // diagnostic: reconcile rounds of wave 0
           if (changed) {
             entry = ne;
