@@ -30,6 +30,13 @@ __device__ __forceinline__ uint32_t dist_symbol(uint32_t d1, uint32_t& ebits, ui
   eval = d1 & ((1u << e) - 1);
   return 2 * hb + ((d1 >> e) & 1);
 }
+// the symbol alone, without a branch (0 and 1 are their own symbols; from 2 on the general rule holds)
+__device__ __forceinline__ uint32_t dist_symbol_of(uint32_t d1) {
+  const uint32_t x = d1 > 2u ? d1 : 2u;
+  const uint32_t hb = 31 - __builtin_clz(x);
+  const uint32_t s = 2 * hb + ((x >> (hb - 1)) & 1);
+  return d1 < 2u ? d1 : s;
+}
 __device__ __forceinline__ uint32_t len_extra_of_sym(uint32_t k /*sym-257*/) {
   return (k < 8 || k == 28) ? 0 : (k - 4) >> 2;
 }
@@ -1161,7 +1168,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
     for (uint32_t k = t; k < (nwords + 2 + 3) / 4 && k < K4_STAGE_WORDS / 4; k += K4_THREADS) z[k] = make_uint4(0, 0, 0, 0);
   }
   if (t < 288) s_lcode[t] = C.lcode[t];
-  if (t < 32) s_dcode[t] = C.dcode[t];
+  if (t < 32) s_dcode[t] = C.dcode[t] | (dist_extra_of_sym(t) << 24);  // code | length << 16 | extra bits << 24
   if (t < kSubRegions) {
     const uint32_t r0 = rtok[(uint64_t)chunk * kSubRegions + t];
     s_rtok[t] = r0;
@@ -1183,64 +1190,57 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
   uint32_t running = 8 * sh + P.header_bits;
   uint32_t buf = 0;
   // items in batches of K4_THREADS*8 (one 16-byte load per thread); the next batch is in flight while this
-  // one is packed.  A thread also needs the item before its eight (is my first one a match's distance?) and
-  // the one after them (the distance of a match head in my last slot): its neighbours' -- same cache lines.
+  // one is packed.  A thread also needs the item before its eight (is my first one a match's distance?): its
+  // neighbour's last -- over the DPP network, only a wave's first lane goes to memory.
   // (reads past nit stay inside the chunk's kChunk-slot item area; they are masked below)
-  auto load_batch = [&](uint32_t i0, uint4& q, uint32_t& before, uint32_t& after) {
+  auto load_batch = [&](uint32_t i0, uint4& q, uint32_t& before) {
     q = *reinterpret_cast<const uint4*>(it + i0);
-    // the neighbouring items sit in the neighbouring lanes' registers; only a wave's edge lanes go to memory
     before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q.w >> 16), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-    after = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q.x & 0xFFFFu), 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
     if (lane == 0) before = i0 ? it[i0 - 1] : 0u;
-    if (lane == 63) after = (i0 + K4_IPT < nit) ? it[i0 + K4_IPT] : 0u;
   };
   uint4 q_next = make_uint4(0, 0, 0, 0);
-  uint32_t before_next = 0, after_next = 0;
-  if (nit) load_batch(t * K4_IPT, q_next, before_next, after_next);
+  uint32_t before_next = 0;
+  if (nit) load_batch(t * K4_IPT, q_next, before_next);
   for (uint32_t b0 = 0; b0 < nit; b0 += K4_THREADS * K4_IPT, buf ^= 1) {
     const uint32_t i0 = b0 + t * K4_IPT;
     const uint4 q = q_next;
-    const uint32_t before = before_next, after = after_next;
-    if (b0 + K4_THREADS * K4_IPT < nit) load_batch(i0 + K4_THREADS * K4_IPT, q_next, before_next, after_next);
-    // e[0] = the item before mine, e[1..8] = mine, e[9] = the one after
-    const uint32_t e[K4_IPT + 2] = {before,        q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16,
-                                    q.z & 0xFFFFu, q.z >> 16,     q.w & 0xFFFFu, q.w >> 16, after};
-    uint64_t val[K4_IPT];
-    uint32_t nb[K4_IPT], mine = 0;
+    const uint32_t before = before_next;
+    if (b0 + K4_THREADS * K4_IPT < nit) load_batch(i0 + K4_THREADS * K4_IPT, q_next, before_next);
+    // e[0] = the item before mine, e[1..8] = mine
+    const uint32_t e[K4_IPT + 1] = {before,        q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16,
+                                    q.z & 0xFFFFu, q.z >> 16,     q.w & 0xFFFFu, q.w >> 16};
+    // Every item is ONE unit of at most 28 bits: a literal its code; a match head its length code + extra bits; the
+    // item behind a head the distance code + extra bits.  (A match is not priced as one 48-bit unit: that needs
+    // 64-bit shifts and a two-part flush, and the head's thread would have to look at the next thread's item.)
+    uint32_t val[K4_IPT], nb[K4_IPT], mine = 0;
     uint32_t starts = 0;  // bit k: item k starts a token and carries the region flag
-    // the two table reads that depend on the item alone (its code as a literal, its code + extra bits as a match
-    // length) for all eight items at once, pinned: sixteen LDS reads in flight instead of a chain of dependent ones
-    uint32_t lcv[K4_IPT], lev[K4_IPT];
+    // all table reads of the batch up front, pinned: twenty-four LDS reads in flight instead of chains of dependent
+    // ones.  Each item is looked up as all three kinds (any 15-bit value has a distance symbol, any low byte a
+    // literal and a length entry); what it really is picks one below
+    uint32_t lcv[K4_IPT], lev[K4_IPT], dcv[K4_IPT];
 #pragma unroll
     for (uint32_t k = 0; k < K4_IPT; ++k) {
       lcv[k] = s_lcode[e[k + 1] & 0xFFu];
       lev[k] = s_lenlut[e[k + 1] & 0xFFu];
+      dcv[k] = s_dcode[dist_symbol_of(e[k + 1] & 0x7FFFu)];
     }
     asm volatile("" : "+v"(lcv[0]), "+v"(lcv[1]), "+v"(lcv[2]), "+v"(lcv[3]), "+v"(lcv[4]), "+v"(lcv[5]), "+v"(lcv[6]), "+v"(lcv[7]),
-                      "+v"(lev[0]), "+v"(lev[1]), "+v"(lev[2]), "+v"(lev[3]), "+v"(lev[4]), "+v"(lev[5]), "+v"(lev[6]), "+v"(lev[7]));
+                      "+v"(lev[0]), "+v"(lev[1]), "+v"(lev[2]), "+v"(lev[3]), "+v"(lev[4]), "+v"(lev[5]), "+v"(lev[6]), "+v"(lev[7]),
+                      "+v"(dcv[0]), "+v"(dcv[1]), "+v"(dcv[2]), "+v"(dcv[3]), "+v"(dcv[4]), "+v"(dcv[5]), "+v"(dcv[6]), "+v"(dcv[7]));
 #pragma unroll
     for (uint32_t k = 0; k < K4_IPT; ++k) {
       const uint32_t cur = e[k + 1];
-      const bool cont = (e[k] & kItemMatch) != 0;      // the distance half of the match before
-      val[k] = 0;
-      nb[k] = 0;
-      if (!cont && i0 + k < nit) {
-        if (cur & kItemMatch) {
-          uint32_t de, dv;
-          const uint32_t dc = s_dcode[dist_symbol(e[k + 2] & 0x7FFFu, de, dv)];
-          uint32_t p = lev[k] >> 24;
-          uint64_t v = lev[k] & 0xFFFFFFu;
-          v |= (uint64_t)(dc & 0xFFFF) << p;
-          p += dc >> 16;
-          v |= (uint64_t)dv << p;
-          val[k] = v;
-          nb[k] = p + de;
-        } else {
-          val[k] = lcv[k] & 0xFFFF;
-          nb[k] = lcv[k] >> 16;
-        }
-        if (cur & kItemRegion) starts |= 1u << k;
-      }
+      const bool dist = (e[k] & kItemMatch) != 0;      // the item behind a match head: dist - 1
+      const bool head = (cur & kItemMatch) != 0;
+      const bool live = i0 + k < nit;
+      const uint32_t dc = dcv[k];                       // code | length << 16 | extra bits << 24
+      const uint32_t dl = (dc >> 16) & 0xFFu, de = dc >> 24;
+      const uint32_t vd = (dc & 0xFFFFu) | (__builtin_amdgcn_ubfe(cur, 0, de) << dl);
+      const uint32_t v = dist ? vd : head ? (lev[k] & 0xFFFFFFu) : (lcv[k] & 0xFFFFu);
+      const uint32_t n = dist ? dl + de : head ? lev[k] >> 24 : lcv[k] >> 16;
+      val[k] = live ? v : 0u;
+      nb[k] = live ? n : 0u;
+      starts |= (live && !dist && (cur & kItemRegion)) ? 1u << k : 0u;
       mine += nb[k];
     }
     const uint32_t incl = wave_incl_scan(mine, lane);
@@ -1278,14 +1278,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__
       }
     };
 #pragma unroll
-    for (uint32_t k = 0; k < K4_IPT; ++k) {
-      if (nb[k] <= 32) {
-        put((uint32_t)val[k], nb[k]);
-      } else {
-        put((uint32_t)val[k], 32);
-        put((uint32_t)(val[k] >> 32), nb[k] - 32);
-      }
-    }
+    for (uint32_t k = 0; k < K4_IPT; ++k) put(val[k], nb[k]);
     if (ab) atomicOr(&s_stage[wi], (uint32_t)acc);
     running += all;
   }
