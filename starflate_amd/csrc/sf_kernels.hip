@@ -1067,7 +1067,11 @@ __global__ __launch_bounds__(K3_THREADS) void k_scan(uint32_t nchunks, const Chu
 constexpr uint32_t K4_THREADS = 512;
 constexpr uint32_t K4_WAVES = K4_THREADS / 64;
 constexpr uint32_t K4_IPT = 8;  // items per thread per batch (one 16-byte load)
-constexpr uint32_t K4_STAGE_WORDS = 10240;  // 40 KiB: fixed-Huffman worst case of a 32 KiB chunk + align
+// the image of one chunk's output: sfh_compress_bound's per-chunk share (fixed-Huffman worst case: nine bits per
+// literal, + the largest dynamic header) + alignment and the bit writers' slack; four workgroups fit a CU's LDS
+constexpr uint32_t K4_STAGE_WORDS = 9392;
+static_assert(4 * K4_STAGE_WORDS >= kChunk + kChunk / 8 + 640 + 16 + 8, "k_emit: stage holds the largest chunk");
+static_assert(4 * (4 * K4_STAGE_WORDS + 4 * (288 + 32 + 256 + 2 * 8 + kSubRegions)) <= 160 * 1024, "k_emit: four workgroups per CU");
 
 // code bits of one token: literal byte, or match (l3 = len-3, d1 = dist-1)
 __device__ __forceinline__ void literal_bits(uint32_t byte, const uint32_t* lcode, uint64_t& value, uint32_t& nb) {
@@ -1098,7 +1102,7 @@ __device__ __forceinline__ void match_bits(uint32_t l3, uint32_t d1, const uint3
   nb = p;
 }
 
-__global__ __launch_bounds__(K4_THREADS) void k_emit(const uint8_t* __restrict__ src, uint64_t n_total,
+__global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restrict__ src, uint64_t n_total,
                                                      uint32_t /*nchunks*/, const uint16_t* __restrict__ items,
                                                      const uint32_t* __restrict__ nitems_in,
                                                      const uint32_t* __restrict__ ntok_in,
