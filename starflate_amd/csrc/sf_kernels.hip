@@ -512,10 +512,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // ---- emit: the lane's chain positions -> items (compact, chunk order) + histogram ----
       if (marks) {
         const uint32_t before = wbase + incl - mine;
-        uint32_t ib = 2u * (tot_items + (before & 0xFFFFu) + (before >> 16));  // byte offset of the lane's next item
+        const uint32_t ib0 = 2u * (tot_items + (before & 0xFFFFu) + (before >> 16));  // byte offset of the lane's first item
+        uint32_t ib = ib0;
         const uint4 D = *reinterpret_cast<const uint4*>(&s_dist[pb]);
         const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + pb]);
-        const uint32_t dd[4] = {D.x, D.y, D.z, D.w};
         // first token of a sub-index region: its position is the region's first, which is always a token start,
         // so the flag can only ever go onto the lane's slot 0
         const uint32_t flag = (t & (kSubBytes / 8 - 1)) == 0 ? (kItemRegion | ((rc * kRSubs + pb / kSubBytes) << 8)) : 0u;
@@ -523,25 +523,38 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         auto put_item = [&](uint32_t byte_off, uint32_t v) {
           *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)byte_off) = (uint16_t)v;
         };
+        // the token's first item, slot by slot: one store and one histogram update serve literal and match head alike
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
           if ((marks >> k) & 1) {
-            // one store and one histogram update serve both kinds of token; a match adds its distance half
             const bool isM = (cm >> k) & 1;
             uint32_t l3 = (N >> (4 * k)) & 15u;      // capped len-3 from the match phase
             if (l3 == kCap - 3) l3 = cap_len - 3;    // capped match: the walk extended it
-            const uint32_t d1 = ((dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) - 1;
             const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
             const uint32_t sym = isM ? kHistLen + l3 : b;  // match lengths are counted raw: k_plan folds them into symbols
             const uint32_t item = isM ? (kItemMatch | l3) : b;
             put_item(ib, k == 0 ? (item | flag) : item);
             atomicAdd(&s_hist[sym], 1u);
-            if (isM) {
-              put_item(ib + 2, d1);
-              uint32_t eb, ev;
-              atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
-            }
             ib += isM ? 4u : 2u;
+          }
+        }
+        // the distance items: a lane's eight positions hold at most two taken matches (kMinMatch = 4), so two
+        // rounds over the match bits cost less than a distance path in each of the eight slots
+        static_assert(kMinMatch >= 4, "at most two matches start in eight positions");
+        uint32_t rest = cm;
+#pragma unroll
+        for (uint32_t it = 0; it < 2; ++it) {
+          if (rest) {
+            const uint32_t k = (uint32_t)__builtin_ctz(rest);
+            rest &= rest - 1u;
+            const uint32_t below = (1u << k) - 1u;
+            // items of the lane before this match's distance: tokens before it, matches before it, its own head
+            const uint32_t off = 2u * ((uint32_t)__popc(marks & below) + (uint32_t)__popc(cm & below) + 1u);
+            const uint32_t w = k < 4 ? (k < 2 ? D.x : D.y) : (k < 6 ? D.z : D.w);
+            const uint32_t d1 = ((w >> (16 * (k & 1))) & 0xFFFFu) - 1u;
+            put_item(ib0 + off, d1);
+            uint32_t eb, ev;
+            atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
           }
         }
       }
