@@ -523,23 +523,20 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         auto put_item = [&](uint32_t byte_off, uint32_t v) {
           *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)byte_off) = (uint16_t)v;
         };
-        // the token's first item, slot by slot: one store and one histogram update serve literal and match head alike
+        // the literals, slot by slot (a match head only moves the item offset on)
+        const uint32_t lits = marks & ~cm;
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
-          if ((marks >> k) & 1) {
-            const bool isM = (cm >> k) & 1;
-            uint32_t l3 = (N >> (4 * k)) & 15u;      // capped len-3 from the match phase
-            if (l3 == kCap - 3) l3 = cap_len - 3;    // capped match: the walk extended it
+          if ((lits >> k) & 1) {
             const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
-            const uint32_t sym = isM ? kHistLen + l3 : b;  // match lengths are counted raw: k_plan folds them into symbols
-            const uint32_t item = isM ? (kItemMatch | l3) : b;
-            put_item(ib, k == 0 ? (item | flag) : item);
-            atomicAdd(&s_hist[sym], 1u);
-            ib += isM ? 4u : 2u;
+            put_item(ib, k == 0 ? (b | flag) : b);
+            atomicAdd(&s_hist[b], 1u);
           }
+          ib += 2u * ((marks >> k) & 1u) + 2u * ((cm >> k) & 1u);
         }
-        // the distance items: a lane's eight positions hold at most two taken matches (kMinMatch = 4), so two
-        // rounds over the match bits cost less than a distance path in each of the eight slots
+        // the matches: a lane's eight positions hold at most two taken ones (kMinMatch = 4), so two rounds over
+        // the match bits cost less than a match path in each of the eight slots.  Lengths are counted raw (k_plan
+        // folds them into symbols)
         static_assert(kMinMatch >= 4, "at most two matches start in eight positions");
         uint32_t rest = cm;
 #pragma unroll
@@ -548,11 +545,15 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             const uint32_t k = (uint32_t)__builtin_ctz(rest);
             rest &= rest - 1u;
             const uint32_t below = (1u << k) - 1u;
-            // items of the lane before this match's distance: tokens before it, matches before it, its own head
-            const uint32_t off = 2u * ((uint32_t)__popc(marks & below) + (uint32_t)__popc(cm & below) + 1u);
+            // items of the lane before this match: one per token before it, one more per match before it
+            const uint32_t at = ib0 + 2u * ((uint32_t)__popc(marks & below) + (uint32_t)__popc(cm & below));
+            uint32_t l3 = (N >> (4 * k)) & 15u;      // capped len-3 from the match phase
+            if (l3 == kCap - 3) l3 = cap_len - 3;    // capped match: the walk extended it
             const uint32_t w = k < 4 ? (k < 2 ? D.x : D.y) : (k < 6 ? D.z : D.w);
             const uint32_t d1 = ((w >> (16 * (k & 1))) & 0xFFFFu) - 1u;
-            put_item(ib0 + off, d1);
+            put_item(at, (kItemMatch | l3) | (k == 0 ? flag : 0u));
+            put_item(at + 2, d1);
+            atomicAdd(&s_hist[kHistLen + l3], 1u);
             uint32_t eb, ev;
             atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
           }
