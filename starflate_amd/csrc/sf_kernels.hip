@@ -513,7 +513,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       if (marks) {
         const uint32_t before = wbase + incl - mine;
         const uint32_t ib0 = 2u * (tot_items + (before & 0xFFFFu) + (before >> 16));  // byte offset of the lane's first item
-        uint32_t ib = ib0;
+        // items of the lane before position k: one per token before it, one more per match before it -- one
+        // population count over both masks side by side
+        const uint32_t both = marks | (cm << 8);
+        auto item_at = [&](uint32_t below) { return ib0 + 2u * (uint32_t)__popc(both & (below | (below << 8))); };
         const uint4 D = *reinterpret_cast<const uint4*>(&s_dist[pb]);
         const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + pb]);
         // first token of a sub-index region: its position is the region's first, which is always a token start,
@@ -529,10 +532,9 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         for (uint32_t k = 0; k < 8; ++k) {
           if ((lits >> k) & 1) {
             const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
-            put_item(ib, k == 0 ? (b | flag) : b);
+            put_item(item_at((1u << k) - 1u), k == 0 ? (b | flag) : b);
             atomicAdd(&s_hist[b], 1u);
           }
-          ib += 2u * ((marks >> k) & 1u) + 2u * ((cm >> k) & 1u);
         }
         // the matches: a lane's eight positions hold at most two taken ones (kMinMatch = 4), so two rounds over
         // the match bits cost less than a match path in each of the eight slots.  Lengths are counted raw (k_plan
@@ -544,9 +546,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           if (rest) {
             const uint32_t k = (uint32_t)__builtin_ctz(rest);
             rest &= rest - 1u;
-            const uint32_t below = (1u << k) - 1u;
-            // items of the lane before this match: one per token before it, one more per match before it
-            const uint32_t at = ib0 + 2u * ((uint32_t)__popc(marks & below) + (uint32_t)__popc(cm & below));
+            const uint32_t at = item_at((1u << k) - 1u);
             uint32_t l3 = (N >> (4 * k)) & 15u;      // capped len-3 from the match phase
             if (l3 == kCap - 3) l3 = cap_len - 3;    // capped match: the walk extended it
             const uint32_t w = k < 4 ? (k < 2 ? D.x : D.y) : (k < 6 ? D.z : D.w);
