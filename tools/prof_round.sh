@@ -17,5 +17,5 @@ python tools/pmc_summary.py $out/kt $out/pmc_fetch $out/pmc_write $out/pmc1 $out
 f=$(find $out/kt -name '*kernel_stats.csv' | head -1)
 (head -1 $f; grep 'sf::' $f) > $out/${tag}_kernel_stats.csv
 cat $out/${tag}_kernel_stats.csv
-tail -1 $out/kt.log > $out/${tag}_bench_under_rocprof.json
+grep '^{"metric"' $out/kt.log | tail -1 > $out/${tag}_bench_under_rocprof.json
 python tools/pmc_traffic.py $out/${tag}_pmc_summary.json $out/pmc_traffic.json > /dev/null
