@@ -323,9 +323,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t rel = s * kStep + t;
         const uint32_t ad = kWindow + rel;                 // its LDS byte address
         const uint32_t dw = ad >> 2, sh0 = ad & 3;
-        const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2], d3 = s_data[dw + 3], d4 = s_data[dw + 4];
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0),
-                       a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0), a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
+        const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2];
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
         const uint32_t h = (a0 * 2654435761u) >> (32 - kHashBits);
         const uint32_t farv = s_table[h];
         // the far candidates only need the (immutable) window: compare them ahead of the barriers
@@ -367,10 +366,13 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         if (m0 > best) { best = m0; bq = q0; }
         if (m1 > best) { best = m1; bq = q1; }
         const uint32_t bd = ad - bq;
-        {
-          // the winner's next eight bytes (they only count when its first kRank all matched)
+        if (best == kRank) {
+          // the winner's next eight bytes, only where its first kRank all matched: the kernel is bound by the LDS,
+          // and a gather's cost follows the number of lanes that take part in it
+          const uint32_t d3 = s_data[dw + 3], d4 = s_data[dw + 4];
+          const uint32_t a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0), a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
           const uint32_t lx = kRank + cmp8<kRank / 4>(s_data, a2, a3, bq);  // maxlen <= kCap does the capping
-          best = best == kRank ? (lx < maxlen ? lx : maxlen) : best;
+          best = lx < maxlen ? lx : maxlen;
         }
         // a 4-byte match farther than kFar4 costs more bits than four literals: drop it.  (maxlen <= n - p, so a
         // position without kMinMatch bytes left cannot reach kMinMatch.)
