@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=1 << 30, help="input bytes per GPU")
     ap.add_argument("--workload", default="text", choices=["text", "random", "mixed"])
-    ap.add_argument("--effort", default="default", choices=["default", "fast"], help="sfh_options.effort of the timed steps")
+    ap.add_argument("--effort", default="default", choices=["default", "fast", "fastest"], help="sfh_options.effort of the timed steps")
     ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default, 256 KiB at this size)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -361,6 +361,8 @@ def main():
         others = {w: secondary_workload(comp, w, args.secondary_bytes, dev, 0) for w in ("text", "mixed", "random") if w != args.workload}
         # the same bytes at sfh_options.effort = SFH_EFFORT_FAST (one history level per hash bucket)
         others["effort_fast"] = secondary_workload(comp, args.workload, n, dev, bb, effort="fast", data=data, wl=wl)
+        # and at SFH_EFFORT_FASTEST (that, and no step-local candidate)
+        others["effort_fastest"] = secondary_workload(comp, args.workload, n, dev, bb, effort="fastest", data=data, wl=wl)
 
     # ---- CPU baseline: oracle restatement of the reference decompress(), 1 thread ----
     cpu = None

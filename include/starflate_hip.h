@@ -73,11 +73,12 @@ typedef struct sfh_options {
                             larger strips compress better; 32768 makes every DEFLATE block independent */
   uint32_t effort;       /* enum sfh_effort: SFH_EFFORT_DEFAULT tries both history levels of a hash bucket plus the
                             step-local candidate; SFH_EFFORT_FAST only the newer level (a third fewer compares,
-                            about 3 % more output) */
+                            about 3 % more output); SFH_EFFORT_FASTEST drops the step-local candidate as well
+                            (about 5 % more output than the default on text, more on very repetitive data) */
   uint32_t reserved;     /* must be 0 */
 } sfh_options;
 
-enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1 };
+enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1, SFH_EFFORT_FASTEST = 2 };
 
 #define SFH_DEFAULT_BLOCK_BYTES 262144u
 

@@ -200,8 +200,9 @@ __device__ __forceinline__ uint32_t entry_addr(uint32_t v, uint32_t k1) {
 // STAMPS: diagnostic build only (SFH_K1_STAMPS=1), s_memtime at phase boundaries into `stamps`
 // [strip][8] = cycles in {stage, match, take, walk, segpre, emit, flush}; never used for timing claims.
 // DEPTH2: both history levels of a bucket are tried (effort 0); otherwise only the newer one (effort 1: a third
-// fewer compares, about 3 % more output)
-template <bool STAMPS, bool DEPTH2>
+// fewer compares, about 3 % more output).  NEAR: the step-local candidate is tried too (efforts 0 and 1; effort 2
+// leaves it out: one table read and one candidate fewer, another 2 % of output on text, more on repetitive data)
+template <bool STAMPS, bool DEPTH2, bool NEAR>
 __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     const uint8_t* __restrict__ src, uint64_t n_total, uint32_t strip_bytes, uint16_t* __restrict__ items,
     uint32_t* __restrict__ nitems_out, uint32_t* __restrict__ ntok_out, uint32_t* __restrict__ hist_out,
@@ -353,16 +354,19 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           code += 1u << 10;
         }
         __syncthreads();  // insertions complete before the near reads
-        // the step's first position with this hash: this one's own entry at the latest, so the bucket is not empty
-        // (and it is of this very step: only its thread index has to be decoded)
-        uint32_t nc;  // = address of the step's thread 1023 - the entry's low ten bits, the former kept scalar
-        asm("v_sub_u32 %0, %1, %2" : "=v"(nc) : "s"(kWindow + s * kStep + 1023u), "v"((s_table[h] >> 16) & 1023u));
-        const bool okn = nc < ad;
-        const uint32_t qnr = okn ? nc : ad;
-        const uint32_t ln = rank8(s_data, a0, a1, qnr, maxlen);
         // longest wins; ties go to the smaller distance: near, then the newer far level
-        uint32_t best = okn ? ln : 0u;
-        uint32_t bq = qnr;
+        uint32_t best = 0, bq = ad;
+        if constexpr (NEAR) {
+          // the step's first position with this hash: this one's own entry at the latest, so the bucket is not empty
+          // (and it is of this very step: only its thread index has to be decoded)
+          uint32_t nc;  // = address of the step's thread 1023 - the entry's low ten bits, the former kept scalar
+          asm("v_sub_u32 %0, %1, %2" : "=v"(nc) : "s"(kWindow + s * kStep + 1023u), "v"((s_table[h] >> 16) & 1023u));
+          const bool okn = nc < ad;
+          const uint32_t qnr = okn ? nc : ad;
+          const uint32_t ln = rank8(s_data, a0, a1, qnr, maxlen);
+          best = okn ? ln : 0u;
+          bq = qnr;
+        }
         if (m0 > best) { best = m0; bq = q0; }
         if (m1 > best) { best = m1; bq = q1; }
         const uint32_t bd = ad - bq;
@@ -1350,10 +1354,16 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
     hipLaunchKernelGGL(kernel, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items, ws.nitems, ws.ntok,
                        ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps);
   };
+  // effort: {both levels + near, newer level + near, newer level only}
+  const uint32_t kind = opt.depth2 ? 0u : (opt.near ? 1u : 2u);
   if (ws.stamps) {
-    if (opt.depth2) launch(k_lz77<true, true>, ws.stamps); else launch(k_lz77<true, false>, ws.stamps);
+    if (kind == 0) launch(k_lz77<true, true, true>, ws.stamps);
+    else if (kind == 1) launch(k_lz77<true, false, true>, ws.stamps);
+    else launch(k_lz77<true, false, false>, ws.stamps);
   } else {
-    if (opt.depth2) launch(k_lz77<false, true>, (uint64_t*)nullptr); else launch(k_lz77<false, false>, (uint64_t*)nullptr);
+    if (kind == 0) launch(k_lz77<false, true, true>, (uint64_t*)nullptr);
+    else if (kind == 1) launch(k_lz77<false, false, true>, (uint64_t*)nullptr);
+    else launch(k_lz77<false, false, false>, (uint64_t*)nullptr);
   }
   return hipGetLastError();
 }

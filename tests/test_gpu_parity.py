@@ -91,6 +91,12 @@ def test_effort_fast_bit_exact_vs_oracle(compressor, starfleet):
             assert np.array_equal(got, want)
             _roundtrip(got, data)
             assert got.size >= len(compressor.compress(data, block_bytes=bb))
+            # SFH_EFFORT_FASTEST: that, and no step-local candidate (the specification's use_near = 0)
+            got2 = np.frombuffer(compressor.compress(data, effort="fastest", block_bytes=bb), np.uint8)
+            want2 = O.compress(data, O.default_params(depth=1, use_near=0, strip_bytes=bb))
+            assert np.array_equal(got2, want2)
+            _roundtrip(got2, data)
+            assert got2.size >= got.size
 
 
 def test_batches_give_the_stream_of_one_launch(monkeypatch):
