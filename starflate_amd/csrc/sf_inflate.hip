@@ -109,13 +109,242 @@ __device__ __forceinline__ void build_tables_wave(uint8_t* m, uint32_t lane) {
   if (lane == 0) inflate::st16(m, off_cnt, 0);
 }
 
+// ---- the token loop of k_inflate_tokens_sub ----
+// The 64 region lanes of a wave in lockstep, one token per lane and iteration, written for what bounds this kernel:
+// instruction issue (vector and, with one scalar unit per CU, scalar) and vmcnt, the one counter loads and stores share.
+//   * straight-line: literal, length and distance are decoded by every lane in every iteration and selected
+//     afterwards; base / extra-bit pairs come from a 64-entry table in LDS (RFC 1951 3.2.5).  A code longer than the
+//     one-read tables is not walked bit by bit (some lane of 64 has one in most iterations): canonical codes of
+//     length l, left-justified to 15 bits, lie below limit[l] = (first[l] + count[l]) << (15 - l), the limits never
+//     decrease, so the length is 1 + the number of limits the next 15 bits reach -- a handful of compares.
+//   * no bit buffer: a lane keeps its bit position; the next 32 bits are two dwords of its STREAM WINDOW in LDS and
+//     one v_alignbit.  The window (kWinDwords dwords from the lane's position) is loaded once per PERIOD of kPeriod
+//     iterations into registers and moved to LDS at the next period's start, so the load has a whole period to
+//     arrive.  (A dword load per lane "one refill ahead" sounds the same, but lanes refill in different iterations:
+//     the wave then waits in nearly every iteration for a load issued one iteration earlier.)  A lane that outruns
+//     its window reads those dwords from memory.
+//   * the period's tokens stay in registers and leave as one 16-byte store per lane, issued in the same burst as the
+//     window loads and, like them, waited for a period later.
+constexpr uint32_t kPeriod = 4, kWinDwords = 8;
+constexpr uint32_t kWinRow = kWinDwords + 1;  // an odd row length spreads the lanes' rows over the LDS banks
+struct RegionLds {
+  uint32_t win[64][kWinRow];  // a lane's window: consecutive dwords, so that two of them are one ds_read2
+  uint32_t lut[64];           // [k]: length symbol 257+k, [32+s]: distance symbol s -- base | extra bits << 16
+  uint32_t lim[2][2][16];     // [segment of the wave][0: literal/length, 1: distance][code length]: see above
+  int32_t base[2][2][16];     // sorted-symbol index of the first code of a length - that code
+};
+struct alignas(4) Dwords4 {  // four dwords at a dword-aligned address: the compiler picks the widest legal access
+  uint32_t a, b, c, d;
+};
+
+// limit[] / base[] of one code from its per-length counts (lane l < 16 writes entry l; count[0] is 0)
+template <bool WIDE>
+__device__ void build_limits(const uint8_t* m, uint32_t* lim, int32_t* base, uint32_t lane) {
+  using L = inflate::SharedLayout;
+  constexpr uint32_t off_cnt = WIDE ? L::kOffCntL : L::kOffCntD;
+  if (lane < 16) {
+    uint32_t first = 0, index = 0, c = 0;
+    for (uint32_t l = 1; l <= lane; ++l) {  // first code and first sorted slot of length `lane`
+      first = (first + c) << 1;
+      index += c;
+      c = inflate::ld16(m, off_cnt + 2 * l);
+    }
+    lim[lane] = lane ? (first + c) << (15 - lane) : 0u;
+    base[lane] = (int32_t)index - (int32_t)first;
+  }
+}
+
+// a code longer than the one-read table: its length and symbol from the next 32 stream bits (0: no code matches)
+template <bool WIDE>
+__device__ __forceinline__ uint32_t long_code(const uint8_t* m, const uint32_t* lim, const int32_t* base, uint32_t bits,
+                                              uint32_t& sym) {
+  using L = inflate::SharedLayout;
+  constexpr uint32_t fast_bits = WIDE ? L::kFastL : L::kFastD, off_sym = WIDE ? L::kOffSymL : L::kOffSymD;
+  const uint32_t c15 = __builtin_bitreverse32(bits) >> 17;  // the first stream bit is the code's most significant
+  uint32_t l = fast_bits + 1;
+#pragma unroll
+  for (uint32_t k = fast_bits + 1; k < 15; ++k) l += c15 >= lim[k] ? 1u : 0u;
+  const bool hit = c15 < lim[15];
+  const uint32_t idx = (uint32_t)(base[l] + (int32_t)(c15 >> (15 - l)));
+  sym = inflate::ld16(m, off_sym + 2 * (hit ? idx : 0u));
+  return hit ? l : 0u;
+}
+
+template <class L>
+__device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end,
+                                        uint32_t bit_begin, uint32_t bit_end, bool until_eob, uint32_t out_begin,
+                                        uint32_t out_end, uint32_t* tokens, const uint8_t* m, uint32_t half, uint32_t hist,
+                                        bool decode, uint32_t lane, RegionLds& R, uint32_t& st_out, uint32_t& ntok_out) {
+  using namespace inflate;
+  uint32_t st = kOk;
+  bool active = decode;
+  // the segment's dwords: seg32[0] holds its first byte; nothing past seg32[last] is read (BitReader::open)
+  const uint32_t* seg32 = reinterpret_cast<const uint32_t*>(src);
+  uint32_t last = 0, bias = 0, nbits = 0;  // bias: bits of seg32[0] before the segment's first byte
+  if (active) {
+    if (seg_begin >= seg_end || seg_end > src_n) {
+      st = kError;
+      active = false;
+    } else {
+      const uint64_t w0 = seg_begin >> 2, wl = (src_n - 1) >> 2;
+      seg32 += w0;
+      last = wl - w0 < 0xFFFFFFF0ull ? (uint32_t)(wl - w0) : 0xFFFFFFF0u;
+      bias = 8 * (uint32_t)(seg_begin & 3);
+      const uint64_t nb = 8 * (seg_end - seg_begin);
+      nbits = nb < 0x80000000ull ? (uint32_t)nb : 0x80000000u;
+      if (bit_begin > nbits || (!until_eob && (bit_end < bit_begin || bit_end > nbits))) {
+        st = kError;
+        active = false;
+      }
+    }
+  }
+  // positions below are bit indices from bit 0 of seg32[0]
+  uint32_t ab = bias + bit_begin;
+  const uint32_t end_ab = until_eob ? ~0u : bias + bit_end, lim_ab = bias + nbits;
+  if (active && ab >= end_ab) active = false;  // an empty region: no token
+  const bool started = active;
+  uint32_t out_pos = out_begin, n = 0;
+  bool eob = false;
+  const uint32_t* limL = R.lim[half][0];
+  const uint32_t* limD = R.lim[half][1];
+  const int32_t* baseL = R.base[half][0];
+  const int32_t* baseD = R.base[half][1];
+
+  uint32_t wbase = 0, wvalid = 0;  // the window in LDS: first dword index, dwords it holds
+  uint32_t pbase = 0, pvalid = 0;  // the one on its way
+  Dwords4 p0{0, 0, 0, 0}, p1{0, 0, 0, 0};
+  auto load_window = [&]() {
+    pbase = ab >> 5;
+    const uint32_t avail = (active && last >= pbase) ? last - pbase + 1u : 0u;  // dwords readable from there
+    pvalid = avail < kWinDwords ? (avail & ~3u) : kWinDwords;                   // whole 16-byte chunks
+    if (pvalid > 0) p0 = *reinterpret_cast<const Dwords4*>(seg32 + pbase);
+    if (pvalid > 4) p1 = *reinterpret_cast<const Dwords4*>(seg32 + pbase + 4);
+  };
+  auto window_to_lds = [&]() {
+    uint32_t* row = R.win[lane];
+    row[0] = p0.a; row[1] = p0.b; row[2] = p0.c; row[3] = p0.d;
+    row[4] = p1.a; row[5] = p1.b; row[6] = p1.c; row[7] = p1.d;
+    wbase = pbase;
+    wvalid = pvalid;
+  };
+  // the 32 stream bits from bit position a on
+  auto peek = [&](uint32_t a) -> uint32_t {
+    const uint32_t w = a >> 5, i = w - wbase;
+    // the window is read in any case (index clamped) and overridden in the rare other case: written as an if / else
+    // the two loads are merged into one FLAT load of a selected pointer, slow and counted by vmcnt
+    const bool inside = i + 1 < wvalid;
+    const uint32_t i0 = inside ? i : 0u;
+    uint32_t d0 = R.win[lane][i0], d1 = R.win[lane][i0 + 1];
+    asm volatile("" : "+v"(d0), "+v"(d1));  // pinned: the LDS reads happen here, as LDS reads
+    if (!inside) {  // from memory, the last dword repeating past the end (BitReader::load_word)
+      d0 = seg32[w < last ? w : last];
+      d1 = seg32[w + 1 < last ? w + 1 : last];
+      // consumed inside the branch: the wait for these two loads stays in here, instead of a wait at the join that
+      // every lane pays in every iteration (and that would also wait for the period's window loads and token store)
+      asm volatile("" : "+v"(d0), "+v"(d1));
+    }
+    return __builtin_amdgcn_alignbit(d1, d0, a & 31);
+  };
+
+  uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, made = 0;  // the period's tokens
+  uint32_t nflushed = 0;
+  auto flush = [&]() {
+    if (made == kPeriod) {
+      *reinterpret_cast<Dwords4*>(tokens + nflushed) = Dwords4{t0, t1, t2, t3};
+    } else if (made) {  // the lane stopped inside the period (once per lane)
+      tokens[nflushed] = t0;
+      if (made > 1) tokens[nflushed + 1] = t1;
+      if (made > 2) tokens[nflushed + 2] = t2;
+    }
+    nflushed += made;
+    made = 0;
+  };
+
+  // one token (src/decompress.cpp:122-187; the order of the checks is inflate::decode_symbols')
+  auto step = [&](uint32_t& tok) {
+    const uint32_t P = peek(ab);
+    uint32_t e = ld16(m, L::kOffFastL + 2 * (P & ((1u << L::kFastL) - 1u)));
+    if (e == 0) {  // a longer code, or none
+      uint32_t sy = 0;
+      const uint32_t l = long_code<true>(m, limL, baseL, P, sy);
+      e = l ? (sy << 4) | l : 0u;
+    }
+    const uint32_t l = e & 15u, sym = e >> 4;
+    const bool is_lit = sym < 256, is_eob = sym == 256, is_len = sym - 257u < 29u;
+    const uint32_t lrec = R.lut[is_len ? sym - 257u : 31u];
+    const uint32_t lx = lrec >> 16;
+    const uint32_t len = (lrec & 0xFFFFu) + __builtin_amdgcn_ubfe(P, l, lx);
+    const uint32_t ab2 = ab + l + lx;
+    // the distance, decoded by every lane (only a length symbol's lane keeps it)
+    const uint32_t Q = peek(ab2);
+    uint32_t de = ld16(m, L::kOffFastD + 2 * (Q & ((1u << L::kFastD) - 1u)));
+    if (is_len && de == 0) {
+      uint32_t sy = 0;
+      const uint32_t dl2 = long_code<false>(m, limD, baseD, Q, sy);
+      de = dl2 ? (sy << 4) | dl2 : 0u;
+    }
+    const uint32_t dl = de & 15u, dsym = de >> 4;
+    const uint32_t drec = R.lut[32u + (dsym < 31u ? dsym : 31u)];
+    const uint32_t dx = drec >> 16;
+    const uint32_t dist = (drec & 0xFFFFu) + __builtin_amdgcn_ubfe(Q, dl, dx);
+    const uint32_t ab3 = ab2 + dl + dx;
+    // what the serial decoder would report, in its order (selects from the last check to the first, so that the
+    // first one that fails wins)
+    uint32_t em = ab3 > lim_ab ? (uint32_t)kSrcTooSmall : (uint32_t)kOk;
+    em = len > out_end - out_pos ? (uint32_t)kDstTooSmall : em;
+    em = (dl == 0 || dsym > 29 || dist > out_pos + hist) ? (uint32_t)kInvalidDistance : em;  // src/decompress.cpp:178
+    const uint32_t el = out_pos >= out_end ? (uint32_t)kDstTooSmall : (uint32_t)kOk;
+    uint32_t err = is_len ? em : (uint32_t)kInvalidLitOrLen;  // neither literal, end-of-block nor length: sym > 285
+    err = is_eob ? (uint32_t)kOk : err;
+    err = is_lit ? el : err;
+    err = l == 0 ? (uint32_t)kInvalidLitOrLen : err;
+    const bool ok = err == kOk;
+    const bool emits = ok && !is_eob;
+    tok = is_lit ? sym : (kTokMatchBit | ((len - 3) << 16) | (dist - 1));
+    out_pos += emits ? (is_lit ? 1u : len) : 0u;
+    ab = ok ? (is_len ? ab3 : ab + l) : ab;
+    n += emits ? 1u : 0u;
+    made += emits ? 1u : 0u;
+    eob = eob || (ok && is_eob);
+    st = ok ? st : err;
+    active = ok && !is_eob && ab < end_ab;
+  };
+
+  // the first window: loaded and waited for on the spot
+  load_window();
+  while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    // period start: last period's window (arrived meanwhile) into LDS, last period's tokens out, next window's loads
+    window_to_lds();
+    flush();
+    load_window();
+    uint32_t tk;
+    if (active) { step(tk); t0 = tk; }
+    if (active) { step(tk); t1 = tk; }
+    if (active) { step(tk); t2 = tk; }
+    if (active) { step(tk); t3 = tk; }
+  }
+  flush();
+  if (started) {
+    if (st == kOk) {
+      if (ab > lim_ab) st = kSrcTooSmall;
+      else if (out_pos != out_end) st = kError;  // the sub-index and the stream disagree
+      else if (until_eob ? !eob : (eob || ab != end_ab)) st = kError;
+    }
+  } else if (decode && st == kOk) {
+    // no token at all: the region must be empty in both views (inflate::decode_region on such a region)
+    if (out_pos != out_end || until_eob) st = kError;
+  }
+  st_out = st;
+  ntok_out = n;
+}
+
 // Streams of this library: one block per segment and a sub-index naming, for each of the 32 parse regions
 // (1024 bytes of output; k_lz77 never lets a match cross them), the bit offset of the region's first token
 // code and the number of tokens before it (k_emit writes both).  One wave takes TWO segments, 32 lanes each:
 // lanes 0 and 32 read the two block headers side by side, all 64 lanes build each segment's code tables
 // (10-bit literal/length and 8-bit distance one-read tables: a longer code is a rarity), then every lane
-// decodes one region, 64 bit streams side by side, writing tokens at their compact positions.  The kernel is
-// bound by instruction issue (a few hundred VALU instructions per token), so full waves matter more than
+// decodes one region, 64 bit streams side by side in lockstep (decode_regions_lockstep above), writing tokens at
+// their compact positions.  The kernel is bound by instruction issue, so full waves matter more than
 // occupancy.  The sub-index is checked against the stream (first code right after the header, every lane ends
 // exactly where the next begins, exact byte and token counts): a wrong sub-index is an error, never wrong output.
 __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __restrict__ src, uint64_t src_n,
@@ -125,7 +354,7 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __r
                                                              SegInfo* __restrict__ info, uint32_t sps) {
   using L = inflate::SharedLayout;
   __shared__ __align__(16) uint8_t s_tab[2][L::kBytes];
-  __shared__ uint32_t s_tokbuf[64][9];  // 8 waiting tokens per region lane (+1: bank spread)
+  __shared__ __align__(16) RegionLds s_reg;
   __shared__ uint32_t s_open[2][2];
   __shared__ uint64_t s_open64[2][2];
   const uint32_t lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
@@ -134,6 +363,13 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __r
   const uint64_t lo = live ? index[seg] : 0, hi = live ? index[seg + 1] : 0;
   const uint64_t obase = (uint64_t)seg * kChunk;
   const uint32_t out_n = (live && dst_n > obase) ? (uint32_t)(dst_n - obase < kChunk ? dst_n - obase : kChunk) : 0u;
+  {
+    // RFC 1951 3.2.5 as a table: base | extra bits << 16
+    uint32_t base = 0, extra = 0;
+    if (lane < 29) inflate::length_info(257 + lane, base, extra);
+    else if (lane >= 32 && lane < 62) inflate::distance_info(lane - 32, base, extra);
+    s_reg.lut[lane] = base | (extra << 16);
+  }
   if (hl == 0) {
     uint32_t raw = 0;
     uint64_t raw_off = 0, hdr_end = 0;
@@ -152,24 +388,39 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __r
     }
   }
   __syncthreads();
+#pragma unroll
+  for (uint32_t h = 0; h < 2; ++h) {
+    if (s_open[h][0] == inflate::kOk && !s_open[h][1]) {  // uniform
+      build_limits<true>(s_tab[h], s_reg.lim[h][0], s_reg.base[h][0], lane);
+      build_limits<false>(s_tab[h], s_reg.lim[h][1], s_reg.base[h][1], lane);
+    }
+  }
+  __syncthreads();
   uint32_t status = s_open[half][0];
   const uint32_t raw = s_open[half][1];
   uint32_t st = inflate::kOk, n = 0, tok0 = 0;
   const bool decode = live && status == inflate::kOk && !raw;
+  uint32_t bit0 = 0, bit1 = 0, tok1 = 0, ob = 0, oe = 0;
+  bool go = false;
   if (decode) {
     const uint32_t* sub = subidx + (uint64_t)seg * 2 * kSubRegions;
-    const uint32_t bit0 = sub[2 * hl];
+    bit0 = sub[2 * hl];
     tok0 = sub[2 * hl + 1];
-    const uint32_t bit1 = hl + 1 < kSubRegions ? sub[2 * hl + 2] : 0u;
-    const uint32_t tok1 = hl + 1 < kSubRegions ? sub[2 * hl + 3] : 0u;
-    const uint32_t ob = hl * kSubBytes < out_n ? hl * kSubBytes : out_n;
-    const uint32_t oe = (hl + 1) * kSubBytes < out_n ? (hl + 1) * kSubBytes : out_n;
-    if ((hl == 0 && bit0 != s_open64[half][1]) || tok0 > ob) {
-      st = inflate::kError;  // (tokens before a region) <= (bytes before it) also bounds the token stores
-    } else {
-      st = inflate::decode_region<L>(src, src_n, lo, hi, bit0, bit1, hl + 1 == kSubRegions, ob, oe,
-                                     tokens + (uint64_t)seg * kChunk + tok0, s_tab[half], n, s_tokbuf[lane],
-                                     (seg % sps) * kChunk);
+    bit1 = hl + 1 < kSubRegions ? sub[2 * hl + 2] : 0u;
+    tok1 = hl + 1 < kSubRegions ? sub[2 * hl + 3] : 0u;
+    ob = hl * kSubBytes < out_n ? hl * kSubBytes : out_n;
+    oe = (hl + 1) * kSubBytes < out_n ? (hl + 1) * kSubBytes : out_n;
+    // (tokens before a region) <= (bytes before it) also bounds the token stores
+    if ((hl == 0 && bit0 != s_open64[half][1]) || tok0 > ob) st = inflate::kError;
+    else go = true;
+  }
+  {
+    uint32_t rst = inflate::kOk;
+    decode_regions_lockstep<L>(src, src_n, lo, hi, bit0, bit1, hl + 1 == kSubRegions, ob, oe,
+                               tokens + (uint64_t)seg * kChunk + tok0, s_tab[half], half, (seg % sps) * kChunk, go, lane,
+                               s_reg, rst, n);
+    if (go) {
+      st = rst;
       if (st == inflate::kOk && hl + 1 < kSubRegions && tok0 + n != tok1) st = inflate::kError;
     }
   }
