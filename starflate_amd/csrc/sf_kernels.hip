@@ -86,19 +86,21 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/
 // into earlier blocks of the strip (legal: /root/reference/src/decompress.cpp:178 only requires
 // distance <= bytes written).  The CU has ONE scalar unit for all its waves, so the hot loops are
 // straight-line vector code.  Per round:
-//   stage : shift the window, store the prefetched 4 KiB, age the table's step codes if due
-//   match : 4 steps of step-synchronous hash insertion (kStep positions, one per thread, between
+//   stage : shift the window, store the prefetched 8 KiB, age the table's step codes if due
+//   match : 8 steps of step-synchronous hash insertion (kStep positions, one per thread, between
 //           two barriers).  A bucket is one dword = two 16-bit history levels {newest, the one
 //           before}; ONE ds_max_u32 of (code << 16 | old newest) inserts: every thread of a step
 //           carries the same low half, so the result is independent of thread order.  Branch-free
-//           compare of kCap bytes against both far levels (read before the insertion) and the near
-//           candidate (the step's first same-hash position, read after it)
-//   take  : one ballot per 64-position segment flags the positions whose match the greedy /
-//           lazy rule would take
-//   walk  : 32 LANES per kRegion-byte region follow the chain speculatively from 32 sub-region
-//           starts and reconcile with their predecessors' exits (regions are independent:
-//           matches never cross them); sets chain / match bit masks, extends capped matches
-//   emit  : position-parallel: chain positions -> compact 16-bit items + LDS histogram
+//           ranking by kRank bytes of both far levels (read before the insertion) and the near
+//           candidate (the step's first same-hash position, read after it); the winner's next
+//           kCap - kRank bytes only where its rank is full.  4-bit capped lengths + 16-bit distances
+//   parse : wave-local, in registers: thread t owns the eight positions [8t, 8t + 8) of the round, a
+//           wave one kRegion-byte parse region (matches never cross it).  take: the positions whose
+//           match the greedy / lazy rule would take; walk: every lane follows the chain through its
+//           positions from a speculative entry, the true entry is the exclusive prefix maximum of
+//           the exits before it (DPP scan), lanes whose entry changed walk again
+//   emit  : the lane's tokens -> compact 16-bit items (literals slot by slot, its at most two matches
+//           in two compact rounds) + LDS histogram
 // ---------------------------------------------------------------------------
 constexpr uint32_t K1_THREADS = kStep;
 constexpr uint32_t K1_WAVES = K1_THREADS / 64;
