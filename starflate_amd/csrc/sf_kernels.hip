@@ -442,9 +442,14 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t rend = (pb & ~(kRegion - 1)) + kRegion < qn ? (pb & ~(kRegion - 1)) + kRegion : qn;  // region end, round-relative
         // follow the chain from local offset e (< nv): at most two matches fit into eight positions, so two
         // predicated passes (literals up to a taken match, the match) cover the lane; straight-line code but for
-        // the rare extension of a capped match
+        // the extension of a match that was capped at match time (kCap bytes or more: it leaves the lane whatever
+        // its length).  The lane itself looks at the next kLaneExt bytes, which settles nearly every such match of
+        // ordinary data; one that is still going then (a run, a repeated record) is noted for the wave
+        constexpr uint32_t kLaneExt = 16;
+        // cap_mp: 0..7 the position whose extended length cap_len holds, 8 none, 16 + p: position p waits for the wave
         auto walk = [&](uint32_t e) {
           uint32_t pos = e, mk = 0;
+          cap_mp = cap_mp >= 16 ? 8u : cap_mp;           // a request of an earlier walk is void
 #pragma unroll
           for (uint32_t it = 0; it < 2; ++it) {
             const bool act = pos < nv;
@@ -460,39 +465,84 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               if (cap_mp != mp) {
                 const uint32_t xpa = kWindow + pb + mp, xca = xpa - s_dist[pb + mp];
                 const uint32_t xmax = rend - (pb + mp) < 258u ? rend - (pb + mp) : 258u;
-                uint32_t l = kCap;
-                while (l < xmax) {
-                  const uint32_t ia = xpa + l, ja = xca + l;
-                  const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1], i2 = s_data[(ia >> 2) + 2];
-                  const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1], j2 = s_data[(ja >> 2) + 2];
-                  const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, ia & 3) ^ __builtin_amdgcn_alignbyte(j1, j0, ja & 3);
-                  const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, ia & 3) ^ __builtin_amdgcn_alignbyte(j2, j1, ja & 3);
-                  if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; break; }
-                  if (x1) { l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3); break; }
-                  l += 8;
+                // the next kLaneExt bytes of both strings, straight-line (bytes past xmax are cut off below)
+                static_assert(kLaneExt == 16, "four dwords per string");
+                const uint32_t ia = xpa + kCap, ja = xca + kCap;
+                const uint32_t* ip = s_data + (ia >> 2);
+                const uint32_t* jp = s_data + (ja >> 2);
+                const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3], i4 = ip[4];
+                const uint32_t j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4];
+                const uint32_t si = ia & 3, sj = ja & 3;
+                const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, si) ^ __builtin_amdgcn_alignbyte(j1, j0, sj);
+                const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, si) ^ __builtin_amdgcn_alignbyte(j2, j1, sj);
+                const uint32_t x2 = __builtin_amdgcn_alignbyte(i3, i2, si) ^ __builtin_amdgcn_alignbyte(j3, j2, sj);
+                const uint32_t x3 = __builtin_amdgcn_alignbyte(i4, i3, si) ^ __builtin_amdgcn_alignbyte(j4, j3, sj);
+                // first differing bit of x3:x2:x1:x0 (all ones when there is none: ffbl(0) = 0xFFFFFFFF survives the ORs)
+                const uint32_t fb = min(min(ffbl(x0), ffbl(x1) | 32u), min(ffbl(x2) | 64u, ffbl(x3) | 96u));
+                const bool open = fb >= 8 * kLaneExt;      // all kLaneExt bytes equal
+                uint32_t l = kCap + (open ? kLaneExt : fb >> 3);
+                l = l < xmax ? l : xmax;
+                if (open && l < xmax) {
+                  cap_mp = 16 + mp;                      // still equal after kLaneExt more bytes: the wave's turn
+                  len = kCap + kLaneExt;                 // provisional (the chain has left the lane anyway)
+                } else {
+                  cap_mp = mp;
+                  cap_len = l;
+                  len = l;
                 }
-                cap_mp = mp;
-                cap_len = l < xmax ? l : xmax;
+              } else {
+                len = cap_len;
               }
-              len = cap_len;
             }
             pos = hit ? mp + len : (act ? 8u : pos);
           }
           marks = mk;
           exit_abs = lb + (pos > 8 ? pos : 8u);
         };
+        // A long capped match, by the whole wave: lane l compares the four bytes at offset kCap + kLaneExt + 4 l of
+        // the two strings, so one pass covers the 258 bytes a match can have.  Only the FIRST waiting lane is served
+        // per reconcile round: the match usually jumps over the lanes behind it, whose speculative requests then
+        // never have to be looked at (on a run of zeros every lane has one)
+        static_assert(kCap + kLaneExt + 4 * 64 >= 258, "one pass of the wave covers the longest match");
+        auto extend_first = [&]() {
+          const uint64_t need = __builtin_amdgcn_ballot_w64(cap_mp >= 16);
+          if (need == 0) return false;
+          const uint32_t src_lane = (uint32_t)__builtin_ctzll(need);
+          const uint32_t xat = (uint32_t)__builtin_amdgcn_readlane((int)(pb + cap_mp - 16), (int)src_lane);  // round-relative position
+          const uint32_t xd = s_dist[xat];             // uniform address: one broadcast read
+          const uint32_t xmax = rend - xat < 258u ? rend - xat : 258u;  // (rend is the same for the whole wave)
+          const uint32_t ia = kWindow + xat + kCap + kLaneExt + 4 * lane, ja = ia - xd;
+          const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1];
+          const uint32_t j0 = s_data[ja >> 2], j1 = s_data[(ja >> 2) + 1];
+          const uint32_t x = __builtin_amdgcn_alignbyte(i1, i0, ia & 3) ^ __builtin_amdgcn_alignbyte(j1, j0, ja & 3);
+          const uint64_t diff = __builtin_amdgcn_ballot_w64(x != 0);
+          uint32_t l = kCap + kLaneExt + 4 * 64;       // no difference within reach
+          if (diff) {
+            const uint32_t dl = (uint32_t)__builtin_ctzll(diff);
+            const uint32_t xx = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)dl);
+            l = kCap + kLaneExt + 4 * dl + ((uint32_t)__builtin_ctz(xx) >> 3);
+          }
+          l = l < xmax ? l : xmax;
+          if (lane == src_lane) {
+            cap_mp -= 16;
+            cap_len = l;
+            exit_abs = lb + cap_mp + l;                // the walk had left the lane at this match
+          }
+          return true;
+        };
         uint32_t entry = 0;
         if (nv) walk(0);
 #pragma unroll 1
-        for (uint32_t round = 0; round < 64; ++round) {
+        for (uint32_t round = 0; round < 128; ++round) {
+          const bool served = extend_first();
           const uint32_t pm = wave_excl_max(exit_abs);
           const uint32_t ne = pm > lb ? pm - lb : 0u;  // where the chain enters this lane (>= nv: it jumps over it)
           const bool changed = ne != entry && nv != 0;
-          if (__builtin_amdgcn_ballot_w64(changed) == 0) break;
+          if (__builtin_amdgcn_ballot_w64(changed) == 0 && !served) break;
           if constexpr (STAMPS) st_acc[7] += 1;  // diagnostic: reconcile rounds of wave 0
           if (changed) {
             entry = ne;
-            if (ne >= nv) { marks = 0; exit_abs = 0; }
+            if (ne >= nv) { marks = 0; exit_abs = 0; cap_mp = cap_mp >= 16 ? 8u : cap_mp; }
             else walk(ne);
           }
         }
