@@ -352,7 +352,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           // bytes left insert nothing; here they insert like the rest, which nothing can observe: every position
           // after them in the strip is such a position too and takes no match (maxlen < kMinMatch), the next
           // strip starts from an empty table
-          atomicMax(&s_table[h], __builtin_amdgcn_alignbit(code, farv, 16));
+          // a lane whose predecessor in the wave has the same bucket need not insert: that one's code is larger (a
+          // run of equal bytes would otherwise serialise sixty-four atomics on one address)
+          const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)~h, (int)h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+          if (hp != h) atomicMax(&s_table[h], __builtin_amdgcn_alignbit(code, farv, 16));
           code += 1u << 10;
         }
         __syncthreads();  // insertions complete before the near reads
