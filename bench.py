@@ -44,6 +44,14 @@ def make_input(workload, n, rank, dev):
         g.manual_seed(5 + rank)
         return (torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=g),
                 f"{n / 2**30:g} GiB high-entropy bytes per GPU (stored-block path)")
+    if workload == "runs":
+        # degenerate but common (sparse files, zero pages, repeated records): half zeros, half one 61-byte line repeated
+        g = torch.Generator(device=dev)
+        g.manual_seed(9 + rank)
+        line = torch.randint(32, 127, (61,), dtype=torch.uint8, device=dev, generator=g)
+        d = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d[n // 2:] = line.repeat((n - n // 2) // 61 + 1)[: n - n // 2]
+        return d, f"{n / 2**30:g} GiB per GPU: half zeros, half one 61-byte line repeated"
     return torch.from_numpy(synth.gen_mixed(n, seed=4 + rank)).to(dev), f"{n / 2**30:g} GiB mixed Silesia-like stripes per GPU"
 
 
@@ -139,7 +147,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=1 << 30, help="input bytes per GPU")
-    ap.add_argument("--workload", default="text", choices=["text", "random", "mixed"])
+    ap.add_argument("--workload", default="text", choices=["text", "random", "mixed", "runs"])
     ap.add_argument("--effort", default="default", choices=["default", "fast", "fastest"], help="sfh_options.effort of the timed steps")
     ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default, 256 KiB at this size)")
     ap.add_argument("--no-verify", action="store_true")
@@ -358,7 +366,7 @@ def main():
                "note": "sfh_compress from/to pinned host buffers, the call as a whole (synchronous): inside it 64 MiB batches are pipelined -- "
                        "H2D of batch b beside the kernels of batch b-1 beside the D2H of batch b-2's stream bytes"}
         del hin, hout
-        others = {w: secondary_workload(comp, w, args.secondary_bytes, dev, 0) for w in ("text", "mixed", "random") if w != args.workload}
+        others = {w: secondary_workload(comp, w, args.secondary_bytes, dev, 0) for w in ("text", "mixed", "random", "runs") if w != args.workload}
         # the same bytes at sfh_options.effort = SFH_EFFORT_FAST (one history level per hash bucket)
         others["effort_fast"] = secondary_workload(comp, args.workload, n, dev, bb, effort="fast", data=data, wl=wl)
         # and at SFH_EFFORT_FASTEST (that, and no step-local candidate)

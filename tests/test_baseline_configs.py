@@ -83,7 +83,7 @@ def test_config4_high_entropy_stored_fast_path(compressor):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["text", "mixed", "random"])
+@pytest.mark.parametrize("workload", ["text", "mixed", "random", "runs"])
 def test_bench_generators_under_stage_parity(compressor, workload):
     """The bytes bench.py times come from its own generators (gen_text_torch on the GPU, gen_mixed, torch.randint):
     their first 4 MiB, strips of 256 KiB as in the 1 GiB run, must give the specification's stream bit for bit and
@@ -95,6 +95,10 @@ def test_bench_generators_under_stage_parity(compressor, workload):
         data = synth.gen_text_torch(n, seed=3, device="cuda").cpu().numpy()
     elif workload == "mixed":
         data = synth.gen_mixed(n, seed=4)
+    elif workload == "runs":  # bench.py's degenerate workload: half zeros, half one 61-byte line repeated
+        import bench
+
+        data = bench.make_input("runs", n, 0, torch.device("cuda"))[0].cpu().numpy()
     else:
         g = torch.Generator(device="cuda")
         g.manual_seed(5)
