@@ -322,6 +322,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       const uint32_t nsteps = (qn + kStep - 1) / kStep;
       const uint32_t K = kWindow + ebase * kStep - rb;  // LDS byte address of a coded position = entry_pos(code) + K (mod 2^32)
       uint32_t code = ((rb / kStep - ebase + 1) << 10) | (1023u - t);  // this thread's step code, step by step
+      // The CU's two workgroups are in different phases most of the time.  The match phase is the long one and the one
+      // that keeps the LDS and the vector units busy, so its waves go first when both workgroups have instructions ready
+      // (measured: match 2 > walk 1 > stage = emit 0 takes 4 % off the kernel; walk at or above match gives it all back)
+      __builtin_amdgcn_s_setprio(2);
       for (uint32_t s = 0; s < nsteps; ++s) {
         const uint32_t rel = s * kStep + t;
         const uint32_t ad = kWindow + rel;                 // its LDS byte address
@@ -396,6 +400,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
                      :: "v"(rel >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
       }
+      __builtin_amdgcn_s_setprio(1);  // the parse: behind the other workgroup's match, ahead of its emit
       __syncthreads();
       stamp(1);
 
@@ -569,6 +574,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       if ((wave & (kSubBytes / kRegion - 1)) == 0 && lane == 0)
         rtok_out[chunk * kSubRegions + rc * kRSubs + wave / (kSubBytes / kRegion)] = tot_tok + (wbase & 0xFFFFu);
       stamp(4);
+      __builtin_amdgcn_s_setprio(0);  // emit, flush and the next round's stage: nothing waits for them
 
       // ---- emit: the lane's chain positions -> items (compact, chunk order) + histogram ----
       if (marks) {
