@@ -1208,6 +1208,12 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
   const uint64_t cbase = (uint64_t)chunk * kChunk;
   const uint32_t n_raw = (uint32_t)((n_total - cbase) < (uint64_t)kChunk ? (n_total - cbase) : kChunk);
   const ChunkCodes& C = codes[chunk];
+  // what a coded chunk needs next, requested before the plan has arrived (a stored chunk does not use it): one memory
+  // round trip for the plan and the tables together instead of two in a row
+  uint32_t pre_code = t < 288 ? C.lcode[t] : (t < 320 ? C.dcode[t - 288] : 0u);
+  uint32_t pre_rtok = t < kSubRegions ? rtok[(uint64_t)chunk * kSubRegions + t] : 0u;
+  const uint32_t pre_ntok = ntok_in[chunk], pre_nit = nitems_in[chunk];
+  asm volatile("" : "+v"(pre_code), "+v"(pre_rtok));
 
   uint32_t* const sub = subidx + (uint64_t)chunk * 2 * kSubRegions;  // {bit offset, tokens before} per region
   if (P.btype == 0) {
@@ -1252,12 +1258,11 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
     uint4* z = reinterpret_cast<uint4*>(s_stage);
     for (uint32_t k = t; k < (nwords + 2 + 3) / 4 && k < K4_STAGE_WORDS / 4; k += K4_THREADS) z[k] = make_uint4(0, 0, 0, 0);
   }
-  if (t < 288) s_lcode[t] = C.lcode[t];
-  if (t < 32) s_dcode[t] = C.dcode[t] | (dist_extra_of_sym(t) << 24);  // code | length << 16 | extra bits << 24
+  if (t < 288) s_lcode[t] = pre_code;
+  else if (t < 320) s_dcode[t - 288] = pre_code | (dist_extra_of_sym(t - 288) << 24);  // code | length << 16 | extra bits << 24
   if (t < kSubRegions) {
-    const uint32_t r0 = rtok[(uint64_t)chunk * kSubRegions + t];
-    s_rtok[t] = r0;
-    sub[2 * t + 1] = r0;
+    s_rtok[t] = pre_rtok;
+    sub[2 * t + 1] = pre_rtok;
   }
   __syncthreads();
   if (t < 256) s_lenlut[t] = lenlut_entry(t, s_lcode);
@@ -1269,8 +1274,8 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
   }
   __syncthreads();
 
-  const uint32_t ntok = ntok_in[chunk];
-  const uint32_t nit = nitems_in[chunk];
+  const uint32_t ntok = pre_ntok;
+  const uint32_t nit = pre_nit;
   const uint16_t* it = items + (uint64_t)chunk * kChunk;
   uint32_t running = 8 * sh + P.header_bits;
   uint32_t buf = 0;
