@@ -961,14 +961,18 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   const uint32_t n_raw = (uint32_t)((n_total - cbase) < (uint64_t)kChunk ? (n_total - cbase) : kChunk);
   const bool fin = (chunk + 1 == nchunks) && final_stream;
 
+  // both halves of the chunk's histogram are requested at once (one memory round trip, not two in a row)
+  uint32_t rawf[4];
+#pragma unroll
+  for (uint32_t q = 0; q < 4; ++q) rawf[q] = hist[(uint64_t)chunk * kHistStride + kHistLen + lane + 64 * q];
   for (uint32_t s = lane; s < 320; s += 64) S.freq[s] = hist[(uint64_t)chunk * kHistStride + s];
   for (uint32_t s = lane; s < 320; s += 64) S.lens[s] = 0;
   __syncthreads();
   // k_lz77 counted match lengths raw (len-3 at kHistLen + 0..255): fold them into the length symbols 257..285
-  for (uint32_t l3 = lane; l3 < 256; l3 += 64) {
-    const uint32_t f = hist[(uint64_t)chunk * kHistStride + kHistLen + l3];
+#pragma unroll
+  for (uint32_t q = 0; q < 4; ++q) {
     uint32_t eb, ev;
-    if (f) atomicAdd(&S.freq[len_symbol(l3, eb, ev)], f);
+    if (rawf[q]) atomicAdd(&S.freq[len_symbol(lane + 64 * q, eb, ev)], rawf[q]);
   }
   __syncthreads();
   if (lane < 29) hist[(uint64_t)chunk * kHistStride + 257 + lane] = S.freq[257 + lane];  // the folded counts, for parity tests
