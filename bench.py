@@ -67,11 +67,13 @@ def run_steps(step, fence, steps, warmup):
     return time.perf_counter() - t0
 
 
-def pipelined_step(compress_fn, pieces, gathered, container="raw", checksum_fn=None, group=None):
-    """One N > 1 step: block-cyclic rounds with the gather overlapped (what the driver's --gpus N runs)."""
+def pipelined_step(compress_fn, pieces, gathered, container="raw", checksum_fn=None, group=None, validate=True):
+    """One N > 1 step: block-cyclic rounds with the gather overlapped (what the driver's --gpus N runs).  validate: the
+    argument checks of compress_pipelined (two small collectives); a repeated step passes False after the first."""
     from starflate_amd import multigpu
 
-    return multigpu.compress_pipelined(compress_fn, pieces, out=gathered, container=container, checksum_fn=checksum_fn, group=group)
+    return multigpu.compress_pipelined(compress_fn, pieces, out=gathered, container=container, checksum_fn=checksum_fn, group=group,
+                                       validate=validate)
 
 
 def verify_pieces(pieces, streams, sizes, wbits):
@@ -235,9 +237,12 @@ def main():
                 comp.compress_tensor_async(piece, scratch[k], size_dev[k], final_stream=final, block_bytes=bb, effort=args.effort)
                 return scratch[k], size_dev[k]
 
+            # the arguments are the same in every step: the first one has them judged (by all ranks alike), the rest skip that
             out, total = pipelined_step(
                 compress_fn, pieces, gathered, container=args.container,
-                checksum_fn=(lambda piece, k: comp.checksum_tensor(piece, args.container)) if args.container != "raw" else None)
+                checksum_fn=(lambda piece, k: comp.checksum_tensor(piece, args.container)) if args.container != "raw" else None,
+                validate=not result.get("validated", False))
+            result["validated"] = True
             result["sizes"] = [int(s.item()) for s in size_dev]
         result["local_n"] = sum(result["sizes"])
         result["out"], result["total"] = out, total

@@ -61,7 +61,11 @@ def _agree(ok, msg, dev, group):
         raise ValueError(msg if not ok else "compress_pipelined: another rank rejected its arguments")
 
 
-def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw", checksum_fn=None, bound_fn=None):
+_SIDE_STREAMS = {}  # device index -> the two side streams of compress_pipelined (made once: creating a stream is not free)
+
+
+def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw", checksum_fn=None, bound_fn=None,
+                       validate=True):
     """Block-cyclic sharding with overlap.  BYTE ORDER CONTRACT: the global input is K*world pieces in the order
     g = k*world + rank; this rank holds `pieces[k]` for rounds k = 0..K-1 (a file of N bytes is dealt in pieces of
     N / (K*world) bytes, a multiple of the strip size: piece g goes to rank g % world as its round g // world).
@@ -80,7 +84,11 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
     container "zlib" / "gzip": the raw piece streams are wrapped once, on rank 0.  checksum_fn(piece, k)
     -> this rank's Adler-32 / CRC-32 of pieces[k] (Compressor.checksum_tensor on the GPU); the values ride
     the same small all_gather as the sizes and are folded in the global piece order with the combine
-    rules of the C-ABI (sfh_adler32_combine / sfh_crc32_combine) -- no extra collective."""
+    rules of the C-ABI (sfh_adler32_combine / sfh_crc32_combine) -- no extra collective.
+
+    validate=False skips the argument checks, which cost two small collectives and two host round trips per call: for
+    a caller that repeats a call whose arguments (piece sizes, `out`, container) a first call has already judged --
+    every rank must pass the same value."""
     from .compressor import checksum_combine, wrapper_bytes
 
     world = dist.get_world_size(group)
@@ -97,20 +105,23 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
         ok, msg = False, f"compress_pipelined: unknown container {container!r}"
     elif wrapped and checksum_fn is None:
         ok, msg = False, "compress_pipelined: a container needs checksum_fn"
-    lens = torch.tensor([int(p.numel()) for p in pieces] + [K], dtype=torch.int64, device=dev)
-    all_lens = [torch.zeros_like(lens) for _ in range(world)]
-    dist.all_gather(all_lens, lens, group=group)
-    all_lens = [[int(v) for v in x.tolist()] for x in all_lens]
-    if ok and any(r[-1] != K for r in all_lens):
-        ok, msg = False, "compress_pipelined: ranks disagree on the number of rounds"
-    if ok and rank == 0 and out is not None:
-        if bound_fn is None:
-            from ._capi import lib
-            bound_fn = lambda n: lib().sfh_compress_bound(int(n), 0)  # noqa: E731
-        need = len(header) + 8 + sum(bound_fn(n) for r in all_lens for n in r[:K])
-        if out.numel() < need:
-            ok, msg = False, f"compress_pipelined: `out` holds {out.numel()} bytes, the bound is {need}"
-    _agree(ok, msg, dev, group)
+    if validate:
+        lens = torch.tensor([int(p.numel()) for p in pieces] + [K], dtype=torch.int64, device=dev)
+        all_lens = [torch.zeros_like(lens) for _ in range(world)]
+        dist.all_gather(all_lens, lens, group=group)
+        all_lens = torch.stack(all_lens).tolist()  # one read-back for all ranks' rows
+        if ok and any(r[-1] != K for r in all_lens):
+            ok, msg = False, "compress_pipelined: ranks disagree on the number of rounds"
+        if ok and rank == 0 and out is not None:
+            if bound_fn is None:
+                from ._capi import lib
+                bound_fn = lambda n: lib().sfh_compress_bound(int(n), 0)  # noqa: E731
+            need = len(header) + 8 + sum(bound_fn(n) for r in all_lens for n in r[:K])
+            if out.numel() < need:
+                ok, msg = False, f"compress_pipelined: `out` holds {out.numel()} bytes, the bound is {need}"
+        _agree(ok, msg, dev, group)
+    elif not ok:
+        raise ValueError(msg)
 
     works, keep, parts = [], [], []
     base = len(header)
@@ -122,7 +133,9 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
     side = None
     if dev.type == "cuda":
         cur = torch.cuda.current_stream(dev)
-        side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        side = _SIDE_STREAMS.get(dev.index)
+        if side is None:
+            side = _SIDE_STREAMS[dev.index] = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
         for st in side:
             st.wait_stream(cur)
 
@@ -137,8 +150,8 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
         local, n = compress_fn(pieces[k], k == K - 1 and rank == world - 1, k)
         cs = int(checksum_fn(pieces[k], k)) if wrapped else 0
         if torch.is_tensor(n):
-            mine = torch.stack([n.reshape(()).to(torch.int64), torch.tensor(cs, dtype=torch.int64, device=n.device),
-                                torch.tensor(int(pieces[k].numel()), dtype=torch.int64, device=n.device)])
+            mine = torch.cat([n.reshape(1).to(torch.int64),
+                              torch.tensor([cs, int(pieces[k].numel())], dtype=torch.int64, device=n.device)])
         else:
             mine = torch.tensor([int(n), cs, int(pieces[k].numel())], dtype=torch.int64, device=local.device)
         enq[k] = (local, mine)
@@ -152,7 +165,7 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
         ctx.__enter__()
         rows = [torch.zeros(3, dtype=torch.int64, device=mine.device) for _ in range(world)]
         dist.all_gather(rows, mine, group=group)
-        rows = [[int(v) for v in x.tolist()] for x in rows]
+        rows = torch.stack(rows).tolist()  # one read-back (the round's one host wait) for all ranks' rows
         sizes = [r[0] for r in rows]
         n = sizes[rank]
         for _, c, ln in rows if wrapped else []:  # global order g = k*world + r

@@ -115,8 +115,10 @@ def _worker_bench_logic(rank, world, port, piece_bytes, K, q):
         sizes[k] = s.size
         return scratch[k], torch.tensor([s.size], dtype=torch.int64)  # the enqueue-only form: size as a tensor
 
-    def step():
-        result["out"], result["total"] = bench.pipelined_step(compress_fn, pieces, gathered)
+    def step():  # as in bench.py: the first step has its arguments judged, the repeats skip that
+        result["out"], result["total"] = bench.pipelined_step(compress_fn, pieces, gathered,
+                                                              validate=not result.get("validated", False))
+        result["validated"] = True
 
     dt = bench.run_steps(step, dist.barrier, 2, 1)
     ok, crcs = bench.verify_pieces(pieces, scratch, sizes, -15)
