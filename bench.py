@@ -243,7 +243,7 @@ def main():
                 checksum_fn=(lambda piece, k: comp.checksum_tensor(piece, args.container)) if args.container != "raw" else None,
                 validate=not result.get("validated", False))
             result["validated"] = True
-            result["sizes"] = [int(s.item()) for s in size_dev]
+            result["sizes"] = torch.cat(size_dev).tolist()  # one read-back
         result["local_n"] = sum(result["sizes"])
         result["out"], result["total"] = out, total
         for name, v in ms.items():
