@@ -55,6 +55,41 @@ def make_input(workload, n, rank, dev):
     return torch.from_numpy(synth.gen_mixed(n, seed=4 + rank)).to(dev), f"{n / 2**30:g} GiB mixed Silesia-like stripes per GPU"
 
 
+CORPUS_NAMES = ("enwik9", "enwik8", "dickens", "alice29.txt")
+
+
+def find_corpus(workload):
+    """SURVEY.md 8(d)(1) / BASELINE.md: a real corpus file under $STARFLATE_CORPUS_DIR replaces the text generator."""
+    d = os.environ.get("STARFLATE_CORPUS_DIR")
+    if not d or workload != "text":
+        return None
+    for name in CORPUS_NAMES:
+        p = os.path.join(d, name)
+        if os.path.isfile(p):
+            return p
+    return None
+
+
+def file_input(path, n, rank, dev):
+    """n bytes of the file for this rank: rank r starts at r*n (mod the file size); a short file is tiled."""
+    import numpy as np
+    import torch
+
+    size = os.path.getsize(path)
+    if size == 0:
+        raise SystemExit(f"{path} is empty")
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    start = (rank * n) % size
+    parts, left = [], n
+    while left:
+        take = min(left, size - start)
+        parts.append(np.asarray(mm[start:start + take]))
+        left -= take
+        start = 0
+    buf = parts[0] if len(parts) == 1 else np.concatenate(parts)
+    return torch.from_numpy(np.ascontiguousarray(buf)).to(dev), f"{n / 2**30:g} GiB per GPU from {os.path.basename(path)} ({size} bytes{', tiled' if size < n else ''})"
+
+
 def run_steps(step, fence, steps, warmup):
     """W untimed warm-up steps, then exactly K steps between two fences (barrier + device synchronise)."""
     for _ in range(warmup):
@@ -67,13 +102,13 @@ def run_steps(step, fence, steps, warmup):
     return time.perf_counter() - t0
 
 
-def pipelined_step(compress_fn, pieces, gathered, container="raw", checksum_fn=None, group=None, validate=True):
+def pipelined_step(compress_fn, pieces, gathered, container="raw", checksum_fn=None, group=None, validate=True, bound_fn=None):
     """One N > 1 step: block-cyclic rounds with the gather overlapped (what the driver's --gpus N runs).  validate: the
     argument checks of compress_pipelined (two small collectives); a repeated step passes False after the first."""
     from starflate_amd import multigpu
 
     return multigpu.compress_pipelined(compress_fn, pieces, out=gathered, container=container, checksum_fn=checksum_fn, group=group,
-                                       validate=validate)
+                                       validate=validate, bound_fn=bound_fn)
 
 
 def verify_pieces(pieces, streams, sizes, wbits):
@@ -148,6 +183,42 @@ def secondary_workload(comp, workload, n, dev, block_bytes, steps=3, effort="def
     return res
 
 
+def self_launch(gpus):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's JSON
+    line.  Runs before anything in this process has touched torch or HIP, and the parent never does: it only waits.
+    Children are new processes (no fork of GPU state, no exec from a GPU process)."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # only rank 0 prints the line; the other ranks' stdout goes to stderr so stdout stays one JSON line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, live = 0, set(range(gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the others", file=sys.stderr)
+                for o in live:  # exactly the processes started here
+                    procs[o].terminate()
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,7 +239,16 @@ def main():
     ap.add_argument("--no-decompress", action="store_true", help="skip the GPU decompress leg (N = 1 only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the N > 1 code path (RCCL group, rounds, gather) even with one rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = CPU rehearsal of the N > 1 launch / rounds / gather / verification with the stand-in compressor "
+                         "of tests/bench_stub.py (zlib); its line says so and is not a measurement")
+    ap.add_argument("--input-file", default=None,
+                    help="compress this file's bytes (tiled / cut to --bytes) instead of a generator; also: $STARFLATE_CORPUS_DIR "
+                         "(enwik9 / enwik8 / dickens / alice29.txt, first one found) when --workload text")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -180,31 +260,50 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rehearsal = args.backend == "gloo"
     multi = world > 1 or args.force_dist
+    if rehearsal and not multi:
+        raise SystemExit("--backend gloo rehearses the N > 1 path: use --gpus N > 1 or --force-dist")
+    if rehearsal:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        # RCCL prints a version banner on stdout when its communicator comes up: keep stdout for the one JSON line
+        # RCCL (and gloo) print a banner on stdout when the communicator comes up: keep stdout for the one JSON line
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            warm = torch.zeros(1, device=dev)
-            dist.all_reduce(warm)
-            torch.cuda.synchronize()
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.all_reduce(torch.zeros(1))
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                warm = torch.zeros(1, device=dev)
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
 
     n = args.bytes
-    data, wl = make_input(args.workload, n, rank, dev)
-    comp = Compressor(local_rank)
+    corpus = args.input_file or find_corpus(args.workload)
+    if corpus:
+        data, wl = file_input(corpus, n, rank, dev)
+    else:
+        data, wl = make_input(args.workload, n, rank, dev)
+    if rehearsal:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bench_stub
+
+        comp = bench_stub.Compressor()
+    else:
+        comp = Compressor(local_rank)
     comp.set_profiling(True)
     K = max(1, args.rounds) if multi else 1
     # every piece is compressed with the strip size of the whole shard, so rounds do not change the stream's ratio
@@ -241,7 +340,7 @@ def main():
             out, total = pipelined_step(
                 compress_fn, pieces, gathered, container=args.container,
                 checksum_fn=(lambda piece, k: comp.checksum_tensor(piece, args.container)) if args.container != "raw" else None,
-                validate=not result.get("validated", False))
+                validate=not result.get("validated", False), bound_fn=comp.compress_bound)
             result["validated"] = True
             result["sizes"] = torch.cat(size_dev).tolist()  # one read-back
         result["local_n"] = sum(result["sizes"])
@@ -252,7 +351,8 @@ def main():
     def fence():
         if multi:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -285,6 +385,15 @@ def main():
                                                  [c.tolist() for c in crcs])
 
     if rank != 0:
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if rehearsal:
+        print(json.dumps({"metric": "REHEARSAL of the N > 1 path on CPU (gloo, stand-in compressor) -- not a measurement",
+                          "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(ms_per_step, 3), "rehearsal": True, "backend": "gloo", "compressor": comp.name,
+                          "config": {"workload": wl, "parallelism": f"shard{world} block-cyclic x{K}"},
+                          "compressed_bytes": total_out, "roundtrip_ok": ok}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -418,7 +527,7 @@ def main():
         "metric": "compress MiB/s + ratio vs zlib -6, 1 GiB synthetic; 1/2/4/8 GPU",
         "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
+        "dtype": "u8", "data": f"file:{os.path.basename(corpus)}" if corpus else "synthetic",
         "config": {"workload": wl, "effort": args.effort, "block_bytes": bb, "deflate_block_bytes": SEG, "window_bytes": 32768, "strategy": "auto",
                    "container": args.container,
                    "parallelism": f"shard{world}" + (f" block-cyclic x{K}, gather overlapped" if multi else "")},

@@ -61,6 +61,13 @@ def _agree(ok, msg, dev, group):
         raise ValueError(msg if not ok else "compress_pipelined: another rank rejected its arguments")
 
 
+def _control_device(group):
+    """Where the small control tensors (sizes, flags) live: the current GPU under RCCL, the host under gloo."""
+    if "nccl" in str(dist.get_backend(group)):
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 _SIDE_STREAMS = {}  # device index -> the two side streams of compress_pipelined (made once: creating a stream is not free)
 
 
@@ -95,7 +102,8 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
     rank = dist.get_rank(group)
     K = len(pieces)
     wrapped = container != "raw"
-    dev = pieces[0].device if K else torch.device("cpu")
+    # the device of the small control tensors follows the group's backend, not the pieces (a rank may hold none)
+    dev = pieces[0].device if K else _control_device(group)
     header = wrapper_bytes(container, 0, 0)[0] if wrapped else b""
     # ---- arguments are judged before anything is enqueued, and by all ranks alike ----
     ok, msg = True, ""
@@ -106,20 +114,29 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
     elif wrapped and checksum_fn is None:
         ok, msg = False, "compress_pipelined: a container needs checksum_fn"
     if validate:
-        lens = torch.tensor([int(p.numel()) for p in pieces] + [K], dtype=torch.int64, device=dev)
-        all_lens = [torch.zeros_like(lens) for _ in range(world)]
-        dist.all_gather(all_lens, lens, group=group)
-        all_lens = torch.stack(all_lens).tolist()  # one read-back for all ranks' rows
-        if ok and any(r[-1] != K for r in all_lens):
-            ok, msg = False, "compress_pipelined: ranks disagree on the number of rounds"
-        if ok and rank == 0 and out is not None:
-            if bound_fn is None:
-                from ._capi import lib
-                bound_fn = lambda n: lib().sfh_compress_bound(int(n), 0)  # noqa: E731
-            need = len(header) + 8 + sum(bound_fn(n) for r in all_lens for n in r[:K])
-            if out.numel() < need:
-                ok, msg = False, f"compress_pipelined: `out` holds {out.numel()} bytes, the bound is {need}"
-        _agree(ok, msg, dev, group)
+        # K first, with a collective whose size does not depend on K: (min, -max) in one MIN all_reduce
+        cdev = _control_device(group)
+        kk = torch.tensor([K, -K], dtype=torch.int64, device=cdev)
+        dist.all_reduce(kk, op=dist.ReduceOp.MIN, group=group)
+        kmin, kmax = int(kk[0].item()), -int(kk[1].item())
+        if kmin != kmax:
+            raise ValueError(f"compress_pipelined: ranks disagree on the number of rounds ({kmin}..{kmax})")  # on every rank
+        if K:
+            lens = torch.tensor([int(p.numel()) for p in pieces], dtype=torch.int64, device=cdev)
+            all_lens = [torch.zeros_like(lens) for _ in range(world)]
+            dist.all_gather(all_lens, lens, group=group)
+            all_lens = torch.stack(all_lens).tolist()  # one read-back for all ranks' rows
+            if ok and rank == 0 and out is not None:
+                try:  # a failure here (the library missing, say) must not leave the peers waiting in _agree
+                    if bound_fn is None:
+                        from ._capi import lib
+                        bound_fn = lambda n: lib().sfh_compress_bound(int(n), 0)  # noqa: E731
+                    need = len(header) + 8 + sum(bound_fn(n) for r in all_lens for n in r)
+                    if out.numel() < need:
+                        ok, msg = False, f"compress_pipelined: `out` holds {out.numel()} bytes, the bound is {need}"
+                except Exception as e:  # noqa: BLE001
+                    ok, msg = False, f"compress_pipelined: cannot judge `out`: {e}"
+        _agree(ok, msg, cdev, group)
     elif not ok:
         raise ValueError(msg)
 
@@ -161,33 +178,31 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
         if k + 1 < K:
             enqueue(k + 1)  # the next round is on the device's queue before this round's sizes are waited for
         local, mine = enq.pop(k)
-        ctx = on(k)
-        ctx.__enter__()
-        rows = [torch.zeros(3, dtype=torch.int64, device=mine.device) for _ in range(world)]
-        dist.all_gather(rows, mine, group=group)
-        rows = torch.stack(rows).tolist()  # one read-back (the round's one host wait) for all ranks' rows
-        sizes = [r[0] for r in rows]
-        n = sizes[rank]
-        for _, c, ln in rows if wrapped else []:  # global order g = k*world + r
-            running = c if running is None else checksum_combine(container, running, c, ln)
-            n_in += ln
-        if rank == 0:
-            if out is not None:
-                dst, o0 = out, base
-            else:  # no preallocated output: one buffer per round, concatenated at the end
-                dst, o0 = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device=local.device), 0
-                parts.append(dst[: sum(sizes)])
-            dst[o0: o0 + sizes[0]] = local[: sizes[0]]
-            ops, off = [], o0 + sizes[0]
-            for r in range(1, world):
-                if sizes[r]:
-                    ops.append(dist.P2POp(dist.irecv, dst[off: off + sizes[r]], r, group=group))
-                off += sizes[r]
-        else:
-            ops = [dist.P2POp(dist.isend, local[:n], 0, group=group)] if n else []
-        if ops:
-            works.extend(dist.batch_isend_irecv(ops))
-        ctx.__exit__(None, None, None)
+        with on(k):
+            rows = [torch.zeros(3, dtype=torch.int64, device=mine.device) for _ in range(world)]
+            dist.all_gather(rows, mine, group=group)
+            rows = torch.stack(rows).tolist()  # one read-back (the round's one host wait) for all ranks' rows
+            sizes = [r[0] for r in rows]
+            n = sizes[rank]
+            for _, c, ln in rows if wrapped else []:  # global order g = k*world + r
+                running = c if running is None else checksum_combine(container, running, c, ln)
+                n_in += ln
+            if rank == 0:
+                if out is not None:
+                    dst, o0 = out, base
+                else:  # no preallocated output: one buffer per round, concatenated at the end
+                    dst, o0 = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device=local.device), 0
+                    parts.append(dst[: sum(sizes)])
+                dst[o0: o0 + sizes[0]] = local[: sizes[0]]
+                ops, off = [], o0 + sizes[0]
+                for r in range(1, world):
+                    if sizes[r]:
+                        ops.append(dist.P2POp(dist.irecv, dst[off: off + sizes[r]], r, group=group))
+                    off += sizes[r]
+            else:
+                ops = [dist.P2POp(dist.isend, local[:n], 0, group=group)] if n else []
+            if ops:
+                works.extend(dist.batch_isend_irecv(ops))
         keep.append(local)
         base += sum(sizes)
     for w in works:

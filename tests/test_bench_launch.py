@@ -1,0 +1,51 @@
+"""`python bench.py --gpus N` starts its N ranks by itself (the driver's command line) -- rehearsed here on CPU over
+gloo with the stand-in compressor of tests/bench_stub.py: launch, block-cyclic rounds, gather, verification, one
+JSON line on stdout, non-zero exit when a rank fails."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*extra, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH, *extra], capture_output=True, text=True, timeout=300, env=e)
+
+
+@pytest.mark.parametrize("gpus,container", [(2, "raw"), (3, "gzip")])
+def test_bench_self_launch_gloo(gpus, container):
+    r = _run("--gpus", str(gpus), "--backend", "gloo", "--bytes", str(1 << 20), "--rounds", "2", "--steps", "2", "--warmup", "1",
+             "--container", container)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["rehearsal"] is True and d["roundtrip_ok"] is True
+    assert d["steps"] == 2 and d["compressed_bytes"] > 0 and d["value"] > 0
+
+
+def test_bench_self_launch_propagates_failure():
+    # --bytes not a multiple of rounds * strip size: every rank exits with an error, and so must the parent
+    r = _run("--gpus", "2", "--backend", "gloo", "--bytes", str((1 << 20) + 1), "--rounds", "2")
+    assert r.returncode != 0
+    assert not r.stdout.strip()
+
+
+def test_bench_input_file(tmp_path):
+    # a "corpus" shorter than --bytes is tiled; found through $STARFLATE_CORPUS_DIR
+    p = tmp_path / "alice29.txt"
+    p.write_bytes(b"Alice was beginning to get very tired of sitting by her sister on the bank. " * 700)
+    r = _run("--gpus", "2", "--backend", "gloo", "--bytes", str(1 << 18), "--rounds", "1", "--steps", "1", "--warmup", "0",
+             env={"STARFLATE_CORPUS_DIR": str(tmp_path)})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip())
+    assert "alice29.txt" in d["config"]["workload"] and d["roundtrip_ok"] is True

@@ -162,6 +162,44 @@ def _worker_bad_args(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_mismatched_rounds(rank, world, port, q):
+    """Ranks that pass different numbers of pieces (also: none at all) all get the documented ValueError; nobody
+    aborts inside a collective of mismatched size."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from starflate_amd import multigpu
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = []
+    for ks in ((1, 2), (0, 2), (3, 1)):
+        pieces = [torch.zeros(32768, dtype=torch.uint8) for _ in range(ks[rank])]
+        try:
+            multigpu.compress_pipelined(lambda p, f, k: (torch.zeros(10, dtype=torch.uint8), 5), pieces, bound_fn=lambda n: n + 100)
+            got.append("no error")
+        except ValueError as e:
+            got.append("rounds" in str(e))
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mismatched_rounds_raise_on_every_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mismatched_rounds, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == [(0, [True, True, True]), (1, [True, True, True])]
+
+
 def test_bench_step_and_verify_logic_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
