@@ -89,6 +89,14 @@ class compressor {
   compressor(const compressor&) = delete;
   auto operator=(const compressor&) -> compressor& = delete;
   compressor(compressor&& o) noexcept : ctx_{std::exchange(o.ctx_, nullptr)}, init_{o.init_} {}
+  auto operator=(compressor&& o) noexcept -> compressor& {
+    if (this != &o) {
+      sfh_destroy(ctx_);
+      ctx_ = std::exchange(o.ctx_, nullptr);
+      init_ = o.init_;
+    }
+    return *this;
+  }
   ~compressor() { sfh_destroy(ctx_); }
   [[nodiscard]] auto status() const -> CompressStatus { return init_; }
   [[nodiscard]] auto native() const -> sfh_ctx* { return ctx_; }  // for the C-ABI entry points taking several contexts
@@ -160,16 +168,30 @@ inline auto compress(std::span<compressor* const> gpus, std::span<const std::byt
 }
 
 namespace detail {
-/// The calling thread's context for `device`, created on first use and kept for the thread's lifetime: the free
-/// function below does not pay for a stream, events and device scratch on every call.
-inline auto thread_compressor(int device) -> compressor& {
+inline auto thread_compressors() -> std::vector<std::pair<int, compressor>>& {
   thread_local std::vector<std::pair<int, compressor>> cache;
+  return cache;
+}
+/// The calling thread's context for `device`, created on first use and kept until the thread exits or calls
+/// release_thread_compressor(): the free function below does not pay for a stream, events and device scratch on
+/// every call.  A context holds device scratch sized by its largest call (2.3 bytes per input byte, at most 2.3 GiB).
+inline auto thread_compressor(int device) -> compressor& {
+  auto& cache = thread_compressors();
   for (auto& e : cache)
     if (e.first == device) return e.second;
   cache.emplace_back(device, compressor{device});
   return cache.back().second;
 }
 }  // namespace detail
+
+/// Frees the calling thread's cached context(s) -- stream, events, device scratch -- for `device`, or for every
+/// device with -1.  The next free-function compress() on this thread makes a new one.  Returns how many were freed.
+inline auto release_thread_compressor(int device = -1) -> std::size_t {
+  auto& cache = detail::thread_compressors();
+  const auto before = cache.size();
+  std::erase_if(cache, [device](const auto& e) { return device < 0 || e.first == device; });
+  return before - cache.size();
+}
 
 /// Compresses `src` into `dst` (dst.size() >= compress_bound(src.size())); returns the stream size.
 /// Re-entrant like the reference's decompress() (src/decompress.hpp:63-71): each thread keeps its own context per device.

@@ -139,10 +139,11 @@ class Compressor:
         self._check(self._lib.sfh_copy_subindex(self._h, sub.data_ptr(), words, 1, C.c_void_p(s)))
         return sub
 
-    def decompress_tensor(self, stream, index, out_n, out=None, hip_stream=None, subindex=None, block_bytes=32768):
+    def decompress_tensor(self, stream, index, out_n, out=None, hip_stream=None, subindex=None, *, block_bytes):
         """stream: 1-D uint8 CUDA tensor (exactly the compressed bytes); index: int64 CUDA tensor of segments + 1
         offsets; subindex: optional int32 CUDA tensor [segments, 32, 2] (last_subindex); out_n: decompressed size;
-        block_bytes: the strip size the stream was written with (last_block_bytes()).
+        block_bytes (required): the strip size the stream was written with (last_block_bytes() of the compressing call --
+        compress*() defaults to strips of up to 256 KiB, so there is no safe default here; 32768 = independent blocks).
         Returns (out tensor, DecompressStatus int, 0 = Success)."""
         import torch
 
@@ -166,7 +167,7 @@ class Compressor:
                                                     C.byref(st), C.c_void_p(s)))
         return out[:out_n], st.value
 
-    def decompress(self, data, index, out_n, subindex=None, block_bytes=32768):
+    def decompress(self, data, index, out_n, subindex=None, *, block_bytes):
         """Host buffers: bytes-like stream + numpy uint64 index [+ numpy uint32 sub-index] -> (bytes, DecompressStatus int)."""
         src = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         idx = np.ascontiguousarray(index, dtype=np.uint64)

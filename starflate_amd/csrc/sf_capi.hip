@@ -35,7 +35,11 @@ struct sfh_ctx {
   int profiling = 0;
   int k1_stamps = 0;  // SFH_K1_STAMPS=1: diagnostic k_lz77 build with s_memtime stamps
   uint32_t batch_chunks = sf::kBatchChunks;  // SFH_BATCH_CHUNKS=<n>: smaller batches (tests of the batch loop)
-  hipEvent_t ev[SFH_NSTAGES + 1] = {};
+  // per-kernel events of the last profiled call: kEvPerBatch per batch (before k_lz77, k_plan, k_scan, k_emit and after
+  // k_emit), then one after the container kernels; grown on demand, reused by later calls
+  static constexpr int kEvPerBatch = 5;
+  std::vector<hipEvent_t> ev;
+  uint32_t ev_batches = 0;       // batches the last profiled call recorded
   bool ev_valid = false;
   // host-buffer path (sfh_compress): copies of one batch run beside the kernels of its neighbours
   static constexpr int kPipe = 4;
@@ -210,6 +214,16 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   const uint32_t per_strip = ko.strip_bytes / sf::kChunk;
   const uint32_t want = pipe ? std::min(ctx->batch_chunks, kPipeBatchChunks) : ctx->batch_chunks;
   const uint32_t batch = std::max(per_strip, want / per_strip * per_strip);
+  const uint32_t nbatches = (nchunks + batch - 1) / batch;
+  ctx->ev_valid = false;
+  if (prof) {
+    const size_t need = (size_t)nbatches * sfh_ctx::kEvPerBatch + 1;
+    while (ctx->ev.size() < need) {
+      hipEvent_t e = nullptr;
+      SF_HIP(hipEventCreate(&e), "event");
+      ctx->ev.push_back(e);
+    }
+  }
   const size_t hdr = sf::wrapper_header_bytes(o.container);
   if (pipe) pipe->copied = hdr;  // the wrapper header is written last (k_wrap) and copied last
   // the stream bytes of batch `b` (its end is in h_tot once ev_batch fires) go down while later batches run
@@ -239,16 +253,17 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
     w.subidx += (size_t)c0 * 2 * sf::kSubRegions;
     sf::Options bo = ko;
     bo.final_stream = last ? ko.final_stream : 0u;
-    const bool ev = prof && first;
-    if (ev) SF_HIP(hipEventRecord(ctx->ev[0], s), "event");
+    // every batch has its own events (recorded behind the wait for its input, so a kernel's time excludes the copy)
+    hipEvent_t* ev = prof ? &ctx->ev[(size_t)bi * sfh_ctx::kEvPerBatch] : nullptr;
+    if (ev) SF_HIP(hipEventRecord(ev[0], s), "event");
     SF_HIP(sf::launch_lz77(bsrc, bn, nb, w, bo, s), "launch k_lz77");
-    if (ev) SF_HIP(hipEventRecord(ctx->ev[1], s), "event");
+    if (ev) SF_HIP(hipEventRecord(ev[1], s), "event");
     SF_HIP(sf::launch_plan(bn, nb, w, bo, s), "launch k_plan");
-    if (ev) SF_HIP(hipEventRecord(ctx->ev[2], s), "event");
+    if (ev) SF_HIP(hipEventRecord(ev[2], s), "event");
     SF_HIP(sf::launch_scan(nb, w, sf::wrapper_header_bytes(o.container), !first, d_out_n, s), "launch k_scan");
-    if (ev) SF_HIP(hipEventRecord(ctx->ev[3], s), "event");
+    if (ev) SF_HIP(hipEventRecord(ev[3], s), "event");
     SF_HIP(sf::launch_emit(bsrc, bn, nb, w, (uint8_t*)d_dst, s), "launch k_emit");
-    if (ev) SF_HIP(hipEventRecord(ctx->ev[4], s), "event");
+    if (ev) SF_HIP(hipEventRecord(ev[4], s), "event");
     if (pipe) {
       if (bi >= 1 && (rc = drain(bi - 1)) != SFH_OK) return rc;  // (its slot is free again before batch bi + kPipe - 1 needs it)
       SF_HIP(hipMemcpyAsync(&ctx->h_tot[bi % sfh_ctx::kPipe], d_out_n, sizeof(uint64_t), hipMemcpyDeviceToHost, s), "copy size");
@@ -260,7 +275,10 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
     SF_HIP(sf::launch_checksum((const uint8_t*)d_src, n, nchunks, o.container, ctx->ws.sums, s), "launch k_checksum");
     SF_HIP(sf::launch_wrap(ctx->ws.sums, nchunks, n, o.container, (uint8_t*)d_dst, d_out_n, nullptr, s), "launch k_wrap");
   }
-  if (prof) SF_HIP(hipEventRecord(ctx->ev[5], s), "event");
+  if (prof) {
+    SF_HIP(hipEventRecord(ctx->ev[(size_t)nbatches * sfh_ctx::kEvPerBatch], s), "event");
+    ctx->ev_batches = nbatches;
+  }
   ctx->ev_valid = prof;
   ctx->index_valid = true;
   return mark_call_end(ctx, s);
@@ -323,11 +341,6 @@ int sfh_create(sfh_ctx** out, int device) {
     sfh_destroy(ctx);
     return SFH_E_HIP;
   }
-  for (int k = 0; k <= SFH_NSTAGES; ++k)
-    if (hipEventCreate(&ctx->ev[k]) != hipSuccess) {
-      sfh_destroy(ctx);
-      return SFH_E_HIP;
-    }
   if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess) {
     sfh_destroy(ctx);
     return SFH_E_HIP;
@@ -355,8 +368,7 @@ void sfh_destroy(sfh_ctx* ctx) {
     if (ctx->ev_inf[k]) (void)hipEventDestroy(ctx->ev_inf[k]);
   (void)hipFree(ctx->d_in);
   (void)hipFree(ctx->d_out);
-  for (int k = 0; k <= SFH_NSTAGES; ++k)
-    if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+  for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   for (int k = 0; k < sfh_ctx::kPipe; ++k) {
     if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
@@ -451,6 +463,7 @@ int sfh_copy_index(sfh_ctx* ctx, uint64_t* dst, size_t entries, int dst_on_devic
     return fail(ctx, SFH_E_INVALID_ARG, "index: no compress call yet, or entries != segments + 1", hipSuccess);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  if (int rc = order_behind_last_call(ctx, s)) return rc;  // the index is written by the last call's k_scan, maybe on another stream
   SF_HIP(hipMemcpyAsync(dst, ctx->ws.offsets, entries * sizeof(uint64_t),
                         dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s), "copy index");
   SF_HIP(hipStreamSynchronize(s), "stream sync");
@@ -462,6 +475,7 @@ int sfh_copy_subindex(sfh_ctx* ctx, uint32_t* dst, size_t words, int dst_on_devi
     return fail(ctx, SFH_E_INVALID_ARG, "sub-index: no compress call yet, or words != segments * 64", hipSuccess);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  if (int rc = order_behind_last_call(ctx, s)) return rc;  // written by the last call's k_emit
   SF_HIP(hipMemcpyAsync(dst, ctx->ws.subidx, words * sizeof(uint32_t),
                         dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s), "copy sub-index");
   SF_HIP(hipStreamSynchronize(s), "stream sync");
@@ -666,7 +680,18 @@ void sfh_set_profiling(sfh_ctx* ctx, int on) {
 
 int sfh_last_stage_ms(sfh_ctx* ctx, float ms[SFH_NSTAGES]) {
   if (!ctx || !ms || !ctx->ev_valid) return SFH_E_INVALID_ARG;
-  for (int k = 0; k < SFH_NSTAGES; ++k) SF_HIP(hipEventElapsedTime(&ms[k], ctx->ev[k], ctx->ev[k + 1]), "elapsed");
+  // summed over every batch of the call (a > 1 GiB device call or any host-buffer call runs several)
+  for (int k = 0; k < SFH_NSTAGES; ++k) ms[k] = 0.f;
+  for (uint32_t b = 0; b < ctx->ev_batches; ++b) {
+    const hipEvent_t* e = &ctx->ev[(size_t)b * sfh_ctx::kEvPerBatch];
+    for (int k = 0; k < 4; ++k) {
+      float t = 0.f;
+      SF_HIP(hipEventElapsedTime(&t, e[k], e[k + 1]), "elapsed");
+      ms[k] += t;
+    }
+  }
+  const size_t last = (size_t)ctx->ev_batches * sfh_ctx::kEvPerBatch;
+  SF_HIP(hipEventElapsedTime(&ms[4], ctx->ev[last - 1], ctx->ev[last]), "elapsed");  // k_checksum + k_wrap
   return SFH_OK;
 }
 
@@ -680,6 +705,7 @@ int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes) {
   // per-batch arrays hold the last batch of the call (all of it for up to kBatchChunks chunks)
   const size_t nc = std::min<size_t>(ctx->last_chunks, std::max<uint32_t>(ctx->batch_chunks, sf::kMaxStrip / sf::kChunk));
   const size_t nall = ctx->last_chunks;
+  if (ctx->busy) SF_HIP(hipEventSynchronize(ctx->ev_done), "wait for the last call");  // whatever stream it ran on
   const void* p = nullptr;
   size_t avail = 0;
   switch (what) {

@@ -138,6 +138,16 @@ auto main(int argc, char** argv) -> int {
       break;
     }
   }
+  // the cached context can be given back (its device scratch with it); the next call makes a new one, same bytes
+  if (release_thread_compressor(0) != 1 || release_thread_compressor() != 0) { std::printf("release_thread_compressor count\n"); ++fail; }
+  {
+    const auto m = compress(html, again);
+    if (!m || !n || *m != *n || !std::equal(comp.begin(), comp.begin() + static_cast<std::ptrdiff_t>(*n), again.begin())) {
+      std::printf("compress() after release_thread_compressor differs\n");
+      ++fail;
+    }
+    if (release_thread_compressor() != 1) { std::printf("release_thread_compressor(-1)\n"); ++fail; }
+  }
   // strips: block_bytes = 65536 lets the second block of a strip match into the first -- smaller, same round trip
   // through the serial decoder and through the GPU decoder (the index carries the strip size); lazy levels 0..3
   {

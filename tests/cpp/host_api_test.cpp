@@ -143,6 +143,9 @@ static constexpr auto kTable = huffman::table{
     {std::pair{0_c, 'e'}, {10_c, 'i'}, {110_c, 'n'}, {1110_c, 'q'}, {11110_c, '\4'}, {11111_c, 'x'}}};
 
 static void test_find() {
+  // north_star's name for the type (the reference keeps it as a parameter name, huffman/src/decode.hpp:25,85)
+  static_assert(std::is_same_v<huffman::code_table<char, 5>, huffman::table<char, 5>>);
+  static_assert(std::is_same_v<huffman::code_table<std::uint16_t>, huffman::table<std::uint16_t, std::dynamic_extent>>);
   static_assert(kTable.find(0_c).value()->symbol == 'e');
   static_assert(kTable.find(11111_c).value()->symbol == 'x');
   CHECK(kTable.find(10_c).value()->symbol == 'i' && kTable.find(1110_c).value()->symbol == 'q');

@@ -152,7 +152,7 @@ def test_inflate_zlib_made_indexed_streams(compressor, starfleet, level, strateg
             parts.append(b + co.flush(zlib.Z_FINISH if c == nch - 1 else zlib.Z_FULL_FLUSH))
         stream = b"".join(parts)
         index = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
-        got, status = compressor.decompress(stream, index, data.size)  # host-buffer entry point
+        got, status = compressor.decompress(stream, index, data.size, block_bytes=32768)  # host-buffer entry point
         assert status == 0, (name, status)
         assert got == data.tobytes(), name
         # the same with strips of four segments: the window survives Z_SYNC_FLUSH and restarts at Z_FULL_FLUSH
@@ -171,28 +171,28 @@ def test_malformed_segments_report_reference_statuses(compressor, starfleet):
     nseg = (data.size + CHUNK - 1) // CHUNK
     raw = np.frombuffer(compressor.compress(data, strategy="stored"), np.uint8).copy()
     idx = compressor.last_index()
-    assert compressor.decompress(raw, idx, data.size) == (data.tobytes(), 0)
+    assert compressor.decompress(raw, idx, data.size, block_bytes=32768) == (data.tobytes(), 0)
     bad = raw.copy()
     bad[int(idx[2]) + 3] ^= 1  # NLEN of the third stored block
-    assert compressor.decompress(bad, idx, data.size)[1] == 3  # NoCompressionLenMismatch
+    assert compressor.decompress(bad, idx, data.size, block_bytes=32768)[1] == 3  # NoCompressionLenMismatch
     bad = raw.copy()
     bad[int(idx[1])] |= 0b110  # BTYPE 3 in the second segment; the first failing segment in stream order wins
     bad[int(idx[3]) + 3] ^= 1
-    assert compressor.decompress(bad, idx, data.size)[1] == 2  # InvalidBlockHeader
+    assert compressor.decompress(bad, idx, data.size, block_bytes=32768)[1] == 2  # InvalidBlockHeader
     dyn = np.frombuffer(compressor.compress(data, strategy="dynamic"), np.uint8).copy()
     idx = compressor.last_index()
-    assert compressor.decompress(dyn, idx, data.size) == (data.tobytes(), 0)
+    assert compressor.decompress(dyn, idx, data.size, block_bytes=32768) == (data.tobytes(), 0)
     cut = idx.copy()
     cut[1:] -= np.uint64(100)  # every segment starts 100 bytes early: garbage
-    assert compressor.decompress(dyn, cut, data.size)[1] != 0
+    assert compressor.decompress(dyn, cut, data.size, block_bytes=32768)[1] != 0
     short = idx.copy()
     short[-1] -= np.uint64(40)  # last segment truncated
-    assert compressor.decompress(dyn[: int(short[-1])], short, data.size)[1] in (5, 6, 7)
+    assert compressor.decompress(dyn[: int(short[-1])], short, data.size, block_bytes=32768)[1] in (5, 6, 7)
     rng = np.random.default_rng(3)
     noise = rng.integers(0, 256, dyn.size, dtype=np.uint8)
-    assert compressor.decompress(noise, idx, data.size)[1] != 0  # garbage never crashes, never reports success
+    assert compressor.decompress(noise, idx, data.size, block_bytes=32768)[1] != 0  # garbage never crashes, never reports success
     with pytest.raises(Exception):  # nseg must match the output size
-        compressor.decompress(dyn, idx[:-1], data.size)
+        compressor.decompress(dyn, idx[:-1], data.size, block_bytes=32768)
     assert nseg + 1 == idx.size
 
 
@@ -319,7 +319,7 @@ def test_fuzz_decoder_on_zlib_and_own_streams(compressor):
             b = co.compress(data[c * CHUNK:(c + 1) * CHUNK].tobytes())
             zs.append(b + co.flush(zlib.Z_FINISH if c == nch - 1 else zlib.Z_FULL_FLUSH))
         index = np.concatenate([[0], np.cumsum([len(p) for p in zs])]).astype(np.uint64)
-        got, st = compressor.decompress(b"".join(zs), index, data.size)
+        got, st = compressor.decompress(b"".join(zs), index, data.size, block_bytes=32768)
         assert st == 0 and got == data.tobytes(), (it, total, level, strat)
         bb = [32768, 65536, 131072][it % 3]
         own = compressor.compress(data, strategy=["auto", "dynamic", "fixed"][it % 3], block_bytes=bb)

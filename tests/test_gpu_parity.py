@@ -401,6 +401,69 @@ def test_one_context_on_two_streams_is_ordered(compressor):
         assert int(zb[k].item()) == nb and torch.equal(ob[k][:nb], want_b), k
 
 
+def test_index_read_on_another_stream_is_ordered(compressor):
+    """The index and the sub-index are written by the last call's k_scan / k_emit; a copy of them on ANOTHER stream than
+    the one that call ran on waits for it (sfh_copy_index / sfh_copy_subindex order themselves behind the call)."""
+    import torch
+
+    d = torch.from_numpy(synth.gen_text(64 << 20, seed=53)).cuda()
+    out = torch.zeros(compressor.compress_bound(d.numel()), dtype=torch.uint8, device="cuda")
+    _, n = compressor.compress_tensor(d, out=out)
+    want_idx = compressor.last_index().copy()
+    want_sub = compressor.last_subindex().copy()
+    small = torch.from_numpy(synth.gen_text(3 * CHUNK, seed=54)).cuda()
+    side, z = torch.cuda.Stream(), torch.zeros(1, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        compressor.compress_tensor(small)  # other offsets in the scratch
+        torch.cuda.synchronize()
+        compressor.compress_tensor_async(d, out, z, stream=side.cuda_stream)  # 64 MiB: still running when the copies are issued
+        idx = compressor.last_index(device="cuda")  # torch's current stream, not `side`
+        sub = compressor.last_subindex(device="cuda")
+        torch.cuda.synchronize()
+        assert np.array_equal(idx.cpu().numpy().astype(np.uint64), want_idx)
+        assert np.array_equal(sub.cpu().numpy().view(np.uint32).reshape(want_sub.shape), want_sub)
+        compressor.compress_tensor(small)
+        torch.cuda.synchronize()
+        compressor.compress_tensor_async(d, out, z, stream=side.cuda_stream)
+        offs = compressor.debug(_capi.DBG_OFFSETS, want_idx.size - 1)  # the debug read waits for the call, too
+        assert np.array_equal(offs, want_idx[:-1])
+
+
+def test_stage_ms_covers_every_batch(monkeypatch):
+    """sfh_last_stage_ms sums the per-kernel events of ALL batches of the call (a host-buffer call runs 64 MiB batches,
+    a device call beyond 1 GiB several): the sum of the stages of a 3-batch device call is its device time."""
+    import torch
+    from starflate_amd import Compressor
+
+    monkeypatch.setenv("SFH_BATCH_CHUNKS", "1024")  # 32 MiB batches
+    c = Compressor(0)
+    c.set_profiling(True)
+    d = torch.from_numpy(synth.gen_text(96 << 20, seed=55)).cuda()
+    out = torch.zeros(c.compress_bound(d.numel()), dtype=torch.uint8, device="cuda")
+    c.compress_tensor(d, out=out)
+    one = torch.from_numpy(synth.gen_text(32 << 20, seed=55)).cuda()
+    c.compress_tensor(one, out=out, block_bytes=c.last_block_bytes())
+    ms_one = sum(c.stage_ms().values())
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0.record()
+    c.compress_tensor(d, out=out)
+    t1.record()
+    torch.cuda.synchronize()
+    wall = t0.elapsed_time(t1)
+    ms = c.stage_ms()
+    total = sum(ms.values())
+    assert total > 2.2 * ms_one, (ms, ms_one)  # three batches, not the first one only
+    assert 0.6 * wall < total <= 1.02 * wall, (ms, wall)
+    # the host-buffer entry point (64 MiB batches at most; 32 MiB here): the same kernels, every batch counted (they run
+    # beside the copies of their neighbours and share HBM with them, so they take longer than on resident input)
+    host = d.cpu().numpy()
+    c.compress(host)
+    hs = sum(c.stage_ms().values())
+    assert 0.7 * total < hs < 4 * total, (hs, total)
+    c.close()
+
+
 def test_fuzz_bit_exact_vs_oracle(compressor):
     """Seeded fuzz: 300 inputs stitched from generators with very different match structure (runs, short and long
     periods, text, noise, low-entropy noise, counters, sparse bytes), sizes 0..160 KiB with ragged chunk tails."""
