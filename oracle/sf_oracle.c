@@ -52,7 +52,10 @@ typedef struct {
   uint32_t maxlen;
 } ctab;
 
-static void ctab_build(ctab* t, const uint8_t* bitsize, uint32_t nsyms) {
+/* Returns 1 when the lengths claim more code space than there is (Kraft sum > 1): canonicalize() then makes a
+ * code whose value does not fit its bitsize, which the reference's code constructor asserts against
+ * (huffman/src/code.hpp:33-44, "`value` exceeds `bitsize`") -- SFO_ERROR by this file's rule for asserts. */
+static int ctab_build(ctab* t, const uint8_t* bitsize, uint32_t nsyms) {
   memset(t, 0, sizeof *t);
   for (uint32_t s = 0; s < nsyms; s++)
     if (bitsize[s]) {
@@ -72,6 +75,7 @@ static void ctab_build(ctab* t, const uint8_t* bitsize, uint32_t nsyms) {
   /* canonicalize(), table.hpp:190-210 */
   uint64_t base_code = 0;
   uint32_t cur_len = 0;
+  int over = 0;
   for (uint32_t l = 1; l <= MAXLEN; l++) {
     for (uint32_t k = 0; k < t->count[l]; k++) {
       uint64_t value;
@@ -84,9 +88,11 @@ static void ctab_build(ctab* t, const uint8_t* bitsize, uint32_t nsyms) {
       }
       if (k == 0) t->first[l] = value;
       t->code[t->index[l] + k] = value;
+      if (value >> l) over = 1;
       ++base_code;
     }
   }
+  return over;
 }
 
 /* huffman/src/decode.hpp:83-102 decode_one: bits enter the code MSB-first
@@ -252,14 +258,14 @@ static int read_dynamic_tables(bitr* b, ctab* lt, ctab* dt) {
     cl_bits[cl_order[i]] = (uint8_t)v;
   }
   ctab clt;
-  ctab_build(&clt, cl_bits, 19);
+  if (ctab_build(&clt, cl_bits, 19)) return SFO_ERROR;
   uint8_t lens[320];
   int st = read_code_lengths(b, &clt, n_len, lens);
   if (st) return st;
-  ctab_build(lt, lens, n_len);
+  if (ctab_build(lt, lens, n_len)) return SFO_ERROR;
   st = read_code_lengths(b, &clt, n_dist, lens);
   if (st) return st;
-  ctab_build(dt, lens, n_dist);
+  if (ctab_build(dt, lens, n_dist)) return SFO_ERROR;
   return SFO_SUCCESS;
 }
 
@@ -340,6 +346,7 @@ void sfo_default_params(sfo_params* p) {
   p->far4_dist = 4096;
   p->strip_bytes = 0;
   p->rank_bytes = 8;
+  p->run_dist1 = 1;
 }
 
 static inline uint32_t load32(const uint8_t* p) {
@@ -496,6 +503,11 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
       if (rend - i < maxlen) maxlen = rend - i;
       uint32_t cmplen = (p->cap && p->cap < maxlen) ? p->cap : maxlen;
       uint32_t best = 0, bdist = 0;
+      if (p->use_prev && i >= 1) { /* distance 1: ranked like the others; it wins every tie */
+        uint32_t l = match_len(d, i, i - 1, cmplen);
+        if (p->rank_bytes && l > p->rank_bytes) l = p->rank_bytes;
+        if (l) { best = l; bdist = 1; }
+      }
       for (uint32_t t = 0; t < NT; t++) {
         uint32_t need = t ? LB : MM;
         if (i + shift + need > n) continue;
@@ -564,12 +576,22 @@ static uint32_t parse_regions(const uint8_t* data, uint32_t n, const sfo_params*
       for (uint32_t k2 = 1; take && k2 <= p->lazy; k2++)
         if (pos + k2 < end && len16[pos + k2] > l + (k2 - 1)) take = 0;
       if (take) {
+        uint32_t dist = dist16[pos];
         if (p->cap && l >= p->cap) { /* capped at match time: extend at the chain position */
           uint32_t maxlen = end - pos < 258 ? end - pos : 258;
-          uint32_t c = pos - dist16[pos];
+          uint32_t c = pos - dist;
           while (l < maxlen && data[pos + l] == data[c + l]) l++;
+          /* a long match whose bytes all equal the byte before it (a run of one byte value) is coded at
+           * distance 1 -- an overlapping copy, /root/reference/src/decompress.cpp:388-398 -- with the run's
+           * length.  Only matches of at least SFO_RUN_MIN bytes with room to be longer are looked at (the
+           * ones a whole wave extends on the GPU) */
+          if (p->run_dist1 && pos >= 1 && maxlen > SFO_RUN_MIN && l >= SFO_RUN_MIN) {
+            uint32_t r = 0;
+            while (r < maxlen && data[pos + r] == data[pos - 1]) r++;
+            if (r >= l) { l = r; dist = 1; }
+          }
         }
-        out[k++] = SFO_TOK_MATCH | ((l - 3) << 16) | (uint32_t)(dist16[pos] - 1);
+        out[k++] = SFO_TOK_MATCH | ((l - 3) << 16) | (uint32_t)(dist - 1);
         pos += l;
       } else {
         out[k++] = data[pos];

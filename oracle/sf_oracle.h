@@ -108,6 +108,12 @@ typedef struct sfo_params {
                             distance); only the winner is then compared up to `cap` bytes.  0: all compared to `cap` */
   uint32_t x_window;     /* analysis knob: 0 = SFO_WINDOW */
   uint32_t x_stride2;    /* analysis knob: 1 / 2 = only odd / even positions are searched, the others inherit */
+  uint32_t use_prev;     /* 1: the byte before (distance 1) is a candidate of every position but the strip's first: a run
+                            of one byte value is then coded at distance 1, as overlapping copies
+                            (/root/reference/src/decompress.cpp:388-398) */
+  uint32_t run_dist1;    /* 1: a taken match of SFO_RUN_MIN bytes or more (with room to be longer) is coded at distance 1
+                            when the bytes it covers all equal the byte before it (a run): its length is then the
+                            run's (region end and 258 as usual), if that is not shorter than the extended match */
 } sfo_params;
 
 #define SFO_WINDOW 32768u
@@ -115,6 +121,7 @@ typedef struct sfo_params {
 #define SFO_MIN_STRIPS 256u
 size_t sfo_resolve_strip_bytes(const sfo_params* p, size_t n);
 
+#define SFO_RUN_MIN 32u /* run_dist1: matches shorter than this are left alone */
 #define SFO_SKIP_SPAN 8192u
 #define SFO_SKIP_SLACK 128u
 

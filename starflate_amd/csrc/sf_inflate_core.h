@@ -295,6 +295,18 @@ SF_HD uint32_t read_lengths(BitReader& br, uint8_t* m, uint32_t type) {
     const uint32_t order = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 8 + ((k - 4) >> 1);
     clp |= (uint64_t)br.get(3) << (3 * order);
   }
+  // Lengths that claim more code space than there is (Kraft sum > 1) describe no prefix code: the reference's
+  // canonicalize() then makes a code whose value does not fit its bitsize and asserts (huffman/src/code.hpp:33-44).
+  // Every decoder of this repository (this one, the wave-parallel tables built from the same lengths, the oracle,
+  // the C++ host API) answers kError
+  {
+    uint32_t kraft = 0;
+    _Pragma("nounroll") for (uint32_t s = 0; s < 19; ++s) {
+      const uint32_t l = (uint32_t)(clp >> (3 * s)) & 7u;
+      kraft += l ? 128u >> l : 0u;
+    }
+    if (kraft > 128u) return kError;
+  }
   // 7-bit lookup table of the code-length code: (symbol << 3) | code bits, 0 = no code
   uint8_t* lut = m + L::kOffFastL + kOffClLut;
   _Pragma("nounroll") for (uint32_t e = 0; e < 128; ++e) lut[e] = 0;
@@ -339,6 +351,12 @@ SF_HD uint32_t read_lengths(BitReader& br, uint8_t* m, uint32_t type) {
     }
   }
   if (br.overrun()) return kSrcTooSmall;
+  {
+    uint32_t kl = 0, kd = 0;  // Kraft sums in units of 2^-15
+    _Pragma("nounroll") for (uint32_t s = 0; s < hlit; ++s) kl += lens[s] ? 32768u >> lens[s] : 0u;
+    _Pragma("nounroll") for (uint32_t s = 0; s < hdist; ++s) kd += lens[hlit + s] ? 32768u >> lens[hlit + s] : 0u;
+    if (kl > 32768u || kd > 32768u) return kError;
+  }
   // move the distance lengths to their fixed place [288..) so both layouts look alike (downwards: the
   // ranges may overlap and the destination is the higher one)
   if (hlit < 288) {

@@ -531,7 +531,32 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             l = kCap + kLaneExt + 4 * dl + ((uint32_t)__builtin_ctz(xx) >> 3);
           }
           l = l < xmax ? l : xmax;
+          // A run of one byte value: when the match's bytes all equal the byte before it, it is coded at distance 1 (an
+          // overlapping copy, /root/reference/src/decompress.cpp:388-398) with the run's length.  Lane k compares the
+          // eight bytes from offset 8k with the eight before them shifted by one: 33 lanes cover the longest match
+          static_assert(33 * 8 >= 258, "the run check covers the longest match");
+          bool run = false;
+          {
+            const uint32_t q1 = kWindow + xat + 8 * lane - 1;  // the byte before the lane's eight
+            const uint32_t* ep = s_data + (q1 >> 2);
+            const uint32_t e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
+            const uint32_t sh = q1 & 3;
+            const uint32_t w0 = __builtin_amdgcn_alignbyte(e1, e0, sh), w1 = __builtin_amdgcn_alignbyte(e2, e1, sh),
+                           w2 = __builtin_amdgcn_alignbyte(e3, e2, sh);
+            const uint32_t y0 = w0 ^ __builtin_amdgcn_alignbyte(w1, w0, 1), y1 = w1 ^ __builtin_amdgcn_alignbyte(w2, w1, 1);
+            const uint64_t rdiff = __builtin_amdgcn_ballot_w64((y0 | y1) != 0 && lane < 33);
+            uint32_t rl = 33 * 8;
+            if (rdiff) {
+              const uint32_t dl = (uint32_t)__builtin_ctzll(rdiff);
+              const uint32_t f = first_bit64((uint32_t)__builtin_amdgcn_readlane((int)y0, (int)dl),
+                                             (uint32_t)__builtin_amdgcn_readlane((int)y1, (int)dl));
+              rl = 8 * dl + (f >> 3);
+            }
+            rl = rl < xmax ? rl : xmax;
+            if (rl >= l && rb + xat >= 1) { run = true; l = rl; }  // (the strip's first byte has none before it)
+          }
           if (lane == src_lane) {
+            if (run) s_dist[xat] = 1;  // read back by this very lane (the walk's own extension, the emit)
             cap_mp -= 16;
             cap_len = l;
             exit_abs = lb + cap_mp + l;                // the walk had left the lane at this match

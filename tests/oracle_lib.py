@@ -38,6 +38,8 @@ class Params(C.Structure):
         ("rank_bytes", C.c_uint32),
         ("x_window", C.c_uint32),
         ("x_stride2", C.c_uint32),
+        ("use_prev", C.c_uint32),
+        ("run_dist1", C.c_uint32),
     ]
 
 

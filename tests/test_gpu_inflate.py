@@ -194,6 +194,15 @@ def test_malformed_segments_report_reference_statuses(compressor, starfleet):
     with pytest.raises(Exception):  # nseg must match the output size
         compressor.decompress(dyn, idx[:-1], data.size, block_bytes=32768)
     assert nseg + 1 == idx.size
+    # over-subscribed code lengths: Error (1) from both GPU paths, as from the oracle and the C++ host API
+    from test_oracle_decompress import oversubscribed_streams
+    for bad in oversubscribed_streams():
+        b = np.frombuffer(bytes(bad), np.uint8)
+        one = np.array([0, b.size], np.uint64)
+        assert O.decompress(b, 64)[0] == 1
+        assert compressor.decompress(b, one, 64, block_bytes=32768)[1] == 1
+        sub = np.zeros((1, 32, 2), np.uint32)
+        assert compressor.decompress(b, one, 64, subindex=sub, block_bytes=32768)[1] != 0
 
 
 def test_inflate_large_roundtrip_and_timing(compressor):

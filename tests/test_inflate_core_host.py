@@ -155,6 +155,11 @@ def test_malformed_segments_report_reference_statuses(core, starfleet):
     assert decode_segment(L, stream, 0, int(idx[1]) // 2, CHUNK)[0] in (5, 6, 7, 1)
     assert decode_segment(L, stream, 0, int(idx[1]), CHUNK - 1)[0] == 4
     assert decode_segment(L, stream, 0, int(idx[1]), CHUNK)[0] == 0
+    # over-subscribed code lengths: Error, as from the oracle and the C++ host API (one status from every decoder)
+    from test_oracle_decompress import oversubscribed_streams
+    for bad in oversubscribed_streams():
+        b = np.frombuffer(bytes(bad), np.uint8)
+        assert decode_segment(L, b, 0, b.size, 64)[0] == 1
     rng = np.random.default_rng(1)
     for _ in range(300):  # random garbage never crashes and never reports success with the wrong size
         g = rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8)

@@ -192,3 +192,30 @@ def test_container_wrappers(starfleet, container):
         assert s.size <= O.lib().sfo_compress_bound(data.size, O.default_params())
     with pytest.raises(RuntimeError):  # a non-final shard cannot carry a trailer
         O.compress(b"abc", O.default_params(container=container, final_stream=0))
+
+
+def test_runs_are_coded_at_distance_one():
+    """A long match whose bytes all equal the byte before it is coded at distance 1 with the run's length (an
+    overlapping copy, /root/reference/src/decompress.cpp:388-398): a chunk of one byte value is 2 matches per 512-byte
+    region, all at distance 1, and still round-trips; a periodic input (not a run) keeps its hash-table distances."""
+    zeros = np.zeros(3 * 32768 + 100, np.uint8)
+    p = O.default_params(strip_bytes=65536)
+    toks = O.strip_tokens(zeros[:65536], p)[0]
+    m = toks[(toks & 0x80000000) != 0]
+    assert m.size >= 2 * (65536 // 512) - 2 and np.all((m & 0x7FFF) == 0)          # dist - 1 == 0
+    assert np.sum(((m >> 16) & 0xFF) == 255) >= 65536 // 512 - 1                      # a 258 in every region
+    s = O.compress(zeros, p)
+    st, w, back = O.decompress(s, zeros.size)
+    assert st == 0 and w == zeros.size and np.array_equal(back, zeros)
+    assert zlib.decompress(s.tobytes(), -15) == zeros.tobytes()
+    off = O.compress(zeros, O.default_params(strip_bytes=65536, run_dist1=0))
+    assert s.size < 0.6 * off.size
+    line = np.tile(np.arange(61, dtype=np.uint8) + 40, 2000)[:65536]
+    tl = O.strip_tokens(line, p)[0]
+    ml = tl[(tl & 0x80000000) != 0]
+    assert np.all(((ml & 0x7FFF) + 1) % 61 == 0)
+    # a run shorter than the threshold, or one that the match does not cover entirely, is left alone
+    mix = np.concatenate([np.arange(200, dtype=np.uint8), np.full(40, 7, np.uint8), np.arange(200, dtype=np.uint8),
+                          np.full(40, 7, np.uint8), np.arange(50, dtype=np.uint8)])
+    sm = O.compress(mix, O.default_params())
+    assert zlib.decompress(sm.tobytes(), -15) == mix.tobytes()

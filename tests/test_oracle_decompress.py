@@ -290,6 +290,34 @@ def test_hazard_inputs_are_flagged():
     assert O.decompress(w.bytes(), 10)[0] == ERROR
 
 
+def oversubscribed_streams():
+    """Two dynamic blocks whose code lengths claim more code space than there is (Kraft sum > 1): canonicalize()
+    would make a code whose value exceeds its bitsize, which the reference asserts against
+    (huffman/src/code.hpp:33-44).  Every decoder of this repository reports Error (1) for them."""
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    w = BitWriter()  # code-length code with three 1-bit codes
+    w.put(1, 1); w.put(2, 2); w.put(0, 5); w.put(0, 5); w.put(0, 4)
+    for v in (1, 1, 1, 0):
+        w.put(v, 3)
+    w.put(0xFFFF, 16); w.put(0xFFFF, 16)
+    a = w.bytes()
+    w = BitWriter()  # a complete code-length code (symbols 1 and 2, one bit each) spelling 257 + 1 lengths of 1
+    w.put(1, 1); w.put(2, 2); w.put(0, 5); w.put(0, 5); w.put(14, 4)
+    for s in order[:18]:
+        w.put(1 if s in (1, 2) else 0, 3)
+    for _ in range(258):
+        w.put(0, 1)
+    w.put(0, 16)
+    return [a, w.bytes()]
+
+
+def test_oversubscribed_code_lengths_are_an_error():
+    for s in oversubscribed_streams():
+        assert O.decompress(s, 64)[0] == ERROR
+    # a complete code is still fine: probe E's 15-bit codes and an incomplete code-length code decode as before
+    # (test_probe_* above), and zlib's own streams below
+
+
 @pytest.mark.parametrize("level,strategy", [(0, 0), (1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)])
 def test_zlib_streams_all_block_types(starfleet, level, strategy):
     data = starfleet * 3

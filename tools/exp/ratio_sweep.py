@@ -9,7 +9,15 @@ from starflate_amd import synth
 
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n = mib << 20
-work = {"text": synth.gen_text(n, seed=3), "mixed": synth.gen_mixed(n, seed=4)}
+def gen_runs(n):  # bench.py's "runs" workload: half zeros, half one 61-byte line repeated
+    rng = np.random.default_rng(9)
+    line = rng.integers(32, 127, 61, dtype=np.uint8)
+    d = np.zeros(n, np.uint8)
+    d[n // 2:] = np.tile(line, (n - n // 2) // 61 + 1)[: n - n // 2]
+    return d
+
+
+work = {"text": synth.gen_text(n, seed=3), "mixed": synth.gen_mixed(n, seed=4), "runs": gen_runs(n)}
 z6 = {}
 for k, d in work.items():
     c = zlib.compressobj(6, zlib.DEFLATED, -15)
