@@ -331,7 +331,7 @@ void sfo_default_params(sfo_params* p) {
   memset(p, 0, sizeof *p);
   p->chunk_bytes = 32768;
   p->step = 1024;
-  p->hash_bits = 12;
+  p->hash_bits = 13;
   p->region_bytes = 512;
   p->min_match = 4;
   p->lazy = 3;
@@ -535,7 +535,19 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
       if (p->far4_dist && best == 4 && bdist > p->far4_dist) best = 0;
       if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)bdist; }
     }
-    if (p->x_stride2 && !(p->x_stride2 & 4)) {
+    if (p->x_stride2 & 8) {
+      /* analysis: the other parity inherits its PREDECESSOR's match, one byte shorter */
+      for (uint32_t i = b; i < e; i++) {
+        if ((i & 1) == (p->x_stride2 & 1) || i == b || i % R == 0) continue;
+        uint32_t l = len16[i - 1], dd = dist16[i - 1];
+        if (l >= MM + 1) {
+          uint32_t nl = l - 1;
+          if (p->far4_dist && nl == 4 && dd > p->far4_dist) continue;
+          len16[i] = (uint16_t)nl;
+          dist16[i] = (uint16_t)dd;
+        }
+      }
+    } else if (p->x_stride2 && !(p->x_stride2 & 4)) {
       /* the other parity inherits its successor's match, one byte longer, when the byte before it matches too */
       for (uint32_t i = b; i < e; i++) {
         if ((i & 1) == (p->x_stride2 & 1) || i + 1 >= n || (i + 1) % R == 0) continue;

@@ -28,7 +28,7 @@ namespace sf {
 constexpr uint32_t kChunk = 32768;      // bytes per DEFLATE block (byte-aligned in the stream)
 constexpr uint32_t kWindow = 32768;     // a match reaches back at most this far, and never before its strip
 constexpr uint32_t kStep = 1024;        // positions per hash-insertion step (= K1 threads)
-constexpr uint32_t kHashBits = 12;      // buckets of two 16-bit history levels each
+constexpr uint32_t kHashBits = 13;      // buckets of two 16-bit history levels each (32 KiB of LDS)
 constexpr uint32_t kMaxStrip = 1u << 24;  // largest block_bytes
 constexpr uint32_t kRegion = 512;       // parse region: matches never cross it (one wave of k_lz77 parses one)
 constexpr uint32_t kSubBytes = 1024;    // sub-index granularity: every kSubBytes-th position starts a token

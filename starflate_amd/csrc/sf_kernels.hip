@@ -121,13 +121,12 @@ static_assert(kEpochMax % (kRound / kStep) == 0 && kEpochSteps % (kRound / kStep
 // LDS carve (bytes); every offset is a multiple of 16
 constexpr uint32_t L_DATA = 0;                               // window | round | look-ahead
 constexpr uint32_t L_LEN4 = L_DATA + kWindow + kRound + kLook;  // 4 bits per position: capped len-3 (0: no match), eight per dword
-constexpr uint32_t L_DIST = L_LEN4 + kRound / 2 + 16;        // u16[kRound]
-constexpr uint32_t L_TABLE = L_DIST + 2 * kRound;            // u32[1<<kHashBits]
+constexpr uint32_t L_TABLE = L_LEN4 + kRound / 2 + 16;       // u32[1<<kHashBits]
 constexpr uint32_t L_HIST = L_TABLE + (4u << kHashBits);     // u32[320]
 constexpr uint32_t L_WTOT = L_HIST + 4 * kHistStride;        // u32[16] tokens | matches << 16 of each wave's region
 constexpr uint32_t K1_LDS = L_WTOT + 4 * K1_WAVES;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
-static_assert(L_WTOT % 16 == 0 && L_TABLE % 16 == 0 && L_DIST % 16 == 0 && L_LEN4 % 16 == 0 && L_HIST % 16 == 0, "LDS alignment");
+static_assert(L_WTOT % 16 == 0 && L_TABLE % 16 == 0 && L_LEN4 % 16 == 0 && L_HIST % 16 == 0, "LDS alignment");
 static_assert(kCap - 3 <= 15, "capped len-3 fits four bits");
 static_assert((kWindow + kLook) % 16 == 0 && kRound % 16 == 0, "window shift in 16-byte units");
 
@@ -185,6 +184,14 @@ __device__ __forceinline__ void rank8x2(const uint32_t* d32, uint32_t a0, uint32
   lb = rank_of(a0, a1, q0, q1, q2, cb & 3, maxlen);
 }
 
+// Workgroup barrier that orders LDS traffic only: the match step keeps a global store (the position's distance, see
+// k_lz77) in flight across its barriers, which __syncthreads() would wait for twice per step
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // 16-bit step code -> position relative to the epoch's first step: (sc-1)*1024 + t with
 // v = sc << 10 | (1023 - t); ordered like the specification's ((step+1) << 12) | (4095 - t), so MAX
 // keeps the same winner (the first position of the latest step)
@@ -225,7 +232,6 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
   uint32_t* s_data = reinterpret_cast<uint32_t*>(smem + L_DATA);
   uint8_t* s_bytes = smem + L_DATA;
   uint32_t* s_len4 = reinterpret_cast<uint32_t*>(smem + L_LEN4);
-  uint16_t* s_dist = reinterpret_cast<uint16_t*>(smem + L_DIST);
   uint32_t* s_table = reinterpret_cast<uint32_t*>(smem + L_TABLE);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + L_HIST);
   uint32_t* s_wtot = reinterpret_cast<uint32_t*>(smem + L_WTOT);
@@ -325,6 +331,11 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // The CU's two workgroups are in different phases most of the time.  The match phase is the long one and the one
       // that keeps the LDS and the vector units busy, so its waves go first when both workgroups have instructions ready
       // (measured: match 2 > walk 1 > stage = emit 0 takes 4 % off the kernel; walk at or above match gives it all back)
+      // The round's distances (16 bits per position) do not live in LDS: they are STAGED in the chunk's own item array,
+      // in the slots of the round's positions -- free at this point, because a chunk never has more items than positions
+      // (a match of kMinMatch bytes or more takes two) -- and every lane reads its eight back at the start of the parse,
+      // before any item of the round is written.  The 16 KiB this frees in LDS hold the larger hash table.
+      const uint32_t stage_off = 2u * rc * kRound;  // byte offset of the round's slots in the chunk's item array
       __builtin_amdgcn_s_setprio(2);
       for (uint32_t s = 0; s < nsteps; ++s) {
         const uint32_t rel = s * kStep + t;
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         if constexpr (DEPTH2) rank8x2(s_data, a0, a1, q0, q1, maxlen, l0, l1);
         else l0 = rank8(s_data, a0, a1, q0, maxlen);
         const uint32_t m0 = ok0 ? l0 : 0u, m1 = ok1 ? l1 : 0u;
-        __syncthreads();  // every far read of this step precedes every insertion of this step
+        lds_barrier();  // every far read of this step precedes every insertion of this step
         {
           // {code, old newest}: the upper half of code:farv.  The specification lets positions without kMinMatch
           // bytes left insert nothing; here they insert like the rest, which nothing can observe: every position
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           if (hp != h) atomicMax(&s_table[h], __builtin_amdgcn_alignbit(code, farv, 16));
           code += 1u << 10;
         }
-        __syncthreads();  // insertions complete before the near reads
+        lds_barrier();  // insertions complete before the near reads
         // longest wins; ties go to the smaller distance: near, then the newer far level
         uint32_t best = 0, bq = ad;
         if constexpr (NEAR) {
@@ -390,7 +401,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         // a 4-byte match farther than kFar4 costs more bits than four literals: drop it.  (maxlen <= n - p, so a
         // position without kMinMatch bytes left cannot reach kMinMatch.)
         const bool ok = best >= (bd > kFar4 ? kMinMatch + 1 : kMinMatch);
-        s_dist[rel] = (uint16_t)bd;  // only read where the length says there is a match
+        // (uniform base + a 32-bit byte offset: no 64-bit address arithmetic)
+        *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + 2u * rel)) = (uint16_t)bd;  // only read where the length says there is a match
         // two lanes' 4-bit lengths -> one byte (the odd lane's value comes over the DPP network)
         uint32_t v = ok ? best - 3 : 0u;
         v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
@@ -401,8 +413,21 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                      :: "v"(rel >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
       }
       __builtin_amdgcn_s_setprio(1);  // the parse: behind the other workgroup's match, ahead of its emit
-      __syncthreads();
+      __syncthreads();  // (also: the staged distances are visible to the whole workgroup)
       stamp(1);
+      // the lane's eight staged distances: asked for now, used by the extensions and the emit.  Every wave has them
+      // before any wave writes an item (the barrier between walk and emit waits for outstanding loads)
+      uint32_t D0, D1, D2, D3;
+      {
+        const uint4 D = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(gi) + (uint64_t)(stage_off + 16u * t));
+        D0 = D.x; D1 = D.y; D2 = D.z; D3 = D.w;
+        asm volatile("" : "+v"(D0), "+v"(D1), "+v"(D2), "+v"(D3));  // four registers, not an indexable vector (scratch)
+      }
+      auto dist_of = [&](uint32_t k) {  // distance of the lane's position k (0..7)
+        const uint32_t lo = (k & 2u) ? D1 : D0, hi = (k & 2u) ? D3 : D2;
+        const uint32_t w = (k & 4u) ? hi : lo;
+        return (k & 1u) ? w >> 16 : w & 0xFFFFu;
+      };
 
       // ---- parse: wave-local.  Thread t owns the eight positions [8t, 8t+8) of the round, a wave one
       // kRegion-byte parse region (matches never cross it), so the greedy/lazy chain of a region is
@@ -444,6 +469,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       stamp(2);
       uint32_t marks = 0;                              // chain positions among the eight
       uint32_t cap_mp = 8, cap_len = 0;                // the capped chain match that was extended (at most one per lane)
+      bool cap_run = false;                            // ... and whether it turned out to be a run (distance 1)
       uint32_t exit_abs = 0;                           // region-relative position where the chain leaves this lane (0: not on it)
       {
         const uint32_t lb = 8 * lane;                  // the lane's first position, region-relative
@@ -471,7 +497,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             uint32_t len = ((N >> (4 * mp)) & 15u) + 3;
             if (hit && len == kCap) {                    // capped at match time: extend (once per position)
               if (cap_mp != mp) {
-                const uint32_t xpa = kWindow + pb + mp, xca = xpa - s_dist[pb + mp];
+                cap_run = false;
+                const uint32_t xpa = kWindow + pb + mp, xca = xpa - dist_of(mp);
                 const uint32_t xmax = rend - (pb + mp) < 258u ? rend - (pb + mp) : 258u;
                 // the next kLaneExt bytes of both strings, straight-line (bytes past xmax are cut off below)
                 static_assert(kLaneExt == 16, "four dwords per string");
@@ -517,7 +544,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           if (need == 0) return false;
           const uint32_t src_lane = (uint32_t)__builtin_ctzll(need);
           const uint32_t xat = (uint32_t)__builtin_amdgcn_readlane((int)(pb + cap_mp - 16), (int)src_lane);  // round-relative position
-          const uint32_t xd = s_dist[xat];             // uniform address: one broadcast read
+          const uint32_t xd = (uint32_t)__builtin_amdgcn_readlane((int)dist_of((cap_mp - 16) & 7), (int)src_lane);
           const uint32_t xmax = rend - xat < 258u ? rend - xat : 258u;  // (rend is the same for the whole wave)
           const uint32_t ia = kWindow + xat + kCap + kLaneExt + 4 * lane, ja = ia - xd;
           const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1];
@@ -556,7 +583,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             if (rl >= l && rb + xat >= 1) { run = true; l = rl; }  // (the strip's first byte has none before it)
           }
           if (lane == src_lane) {
-            if (run) s_dist[xat] = 1;  // read back by this very lane (the walk's own extension, the emit)
+            cap_run = run;  // the emit then writes distance 1 for this match
             cap_mp -= 16;
             cap_len = l;
             exit_abs = lb + cap_mp + l;                // the walk had left the lane at this match
@@ -609,7 +636,6 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         // population count over both masks side by side
         const uint32_t both = marks | (cm << 8);
         auto item_at = [&](uint32_t below) { return ib0 + 2u * (uint32_t)__popc(both & (below | (below << 8))); };
-        const uint4 D = *reinterpret_cast<const uint4*>(&s_dist[pb]);
         const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + pb]);
         // first token of a sub-index region: its position is the region's first, which is always a token start,
         // so the flag can only ever go onto the lane's slot 0
@@ -640,9 +666,11 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             rest &= rest - 1u;
             const uint32_t at = item_at((1u << k) - 1u);
             uint32_t l3 = (N >> (4 * k)) & 15u;      // capped len-3 from the match phase
-            if (l3 == kCap - 3) l3 = cap_len - 3;    // capped match: the walk extended it
-            const uint32_t w = k < 4 ? (k < 2 ? D.x : D.y) : (k < 6 ? D.z : D.w);
-            const uint32_t d1 = ((w >> (16 * (k & 1))) & 0xFFFFu) - 1u;
+            uint32_t d1 = dist_of(k) - 1u;
+            if (l3 == kCap - 3) {                    // capped match: the walk extended it
+              l3 = cap_len - 3;
+              d1 = cap_run ? 0u : d1;
+            }
             put_item(at, (kItemMatch | l3) | (k == 0 ? flag : 0u));
             put_item(at + 2, d1);
             atomicAdd(&s_hist[kHistLen + l3], 1u);
