@@ -71,14 +71,16 @@ typedef struct sfh_options {
                             as one byte-aligned DEFLATE block per 32 KiB; inside it the 32 KiB window slides across
                             those blocks (src/decompress.cpp:178 only requires distance <= bytes written), so
                             larger strips compress better; 32768 makes every DEFLATE block independent */
-  uint32_t effort;       /* enum sfh_effort: SFH_EFFORT_DEFAULT tries both history levels of a hash bucket plus the
-                            step-local candidate; SFH_EFFORT_FAST only the newer level (a third fewer compares,
-                            about 3 % more output); SFH_EFFORT_FASTEST drops the step-local candidate as well
-                            (about 5 % more output than the default on text, more on very repetitive data) */
+  uint32_t effort;       /* enum sfh_effort.  SFH_EFFORT_DEFAULT searches the even positions (an odd one takes over its
+                            successor's match when its own byte fits in front of it) with both history levels of a hash
+                            bucket plus the step-local candidate; SFH_EFFORT_FAST only the newer level (about 2 % more
+                            output); SFH_EFFORT_FASTEST drops the step-local candidate as well (about 4 % more than the
+                            default on text, more on very repetitive data); SFH_EFFORT_THOROUGH searches every
+                            position (about 0.8 % less output than the default for a fifth more time) */
   uint32_t reserved;     /* must be 0 */
 } sfh_options;
 
-enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1, SFH_EFFORT_FASTEST = 2 };
+enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1, SFH_EFFORT_FASTEST = 2, SFH_EFFORT_THOROUGH = 3 };
 
 #define SFH_DEFAULT_BLOCK_BYTES 262144u
 

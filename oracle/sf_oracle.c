@@ -347,6 +347,7 @@ void sfo_default_params(sfo_params* p) {
   p->strip_bytes = 0;
   p->rank_bytes = 8;
   p->run_dist1 = 1;
+  p->stride2 = 1;
 }
 
 static inline uint32_t load32(const uint8_t* p) {
@@ -467,6 +468,7 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
   }
 
   uint32_t *T = m->T, *far = m->far;
+  const uint32_t xs2 = p->stride2 ? 2u : p->x_stride2; /* stride2 = the analysis knob's value 2: even positions searched */
   for (uint32_t s = s0; s < s1; s++) {
     uint32_t b = s * W;
     if (b >= n) break;
@@ -494,8 +496,8 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
     /* candidate evaluation */
     for (uint32_t i = b; i < e; i++) {
       uint32_t shift = 0; /* analysis knob: only one parity is searched ... */
-      if (p->x_stride2 && (i & 1) != (p->x_stride2 & 1)) {
-        if (!(p->x_stride2 & 4) || i + 1 >= e) continue;
+      if (xs2 && (i & 1) != (xs2 & 1)) {
+        if (!(xs2 & 4) || i + 1 >= e) continue;
         shift = 1; /* ... the other tries its successor's candidates, moved back by one */
       }
       uint32_t rend = (i / R + 1) * R;
@@ -535,10 +537,10 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
       if (p->far4_dist && best == 4 && bdist > p->far4_dist) best = 0;
       if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)bdist; }
     }
-    if (p->x_stride2 & 8) {
+    if (xs2 & 8) {
       /* analysis: the other parity inherits its PREDECESSOR's match, one byte shorter */
       for (uint32_t i = b; i < e; i++) {
-        if ((i & 1) == (p->x_stride2 & 1) || i == b || i % R == 0) continue;
+        if ((i & 1) == (xs2 & 1) || i == b || i % R == 0) continue;
         uint32_t l = len16[i - 1], dd = dist16[i - 1];
         if (l >= MM + 1) {
           uint32_t nl = l - 1;
@@ -547,15 +549,16 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
           dist16[i] = (uint16_t)dd;
         }
       }
-    } else if (p->x_stride2 && !(p->x_stride2 & 4)) {
+    } else if (xs2 && !(xs2 & 4)) {
       /* the other parity inherits its successor's match, one byte longer, when the byte before it matches too */
       for (uint32_t i = b; i < e; i++) {
-        if ((i & 1) == (p->x_stride2 & 1) || i + 1 >= n || (i + 1) % R == 0) continue;
+        if ((i & 1) == (xs2 & 1) || i + 1 >= n || (i + 1) % R == 0) continue;
         if (i + 1 >= e) continue; /* successor belongs to the next step: not known yet */
         uint32_t l = len16[i + 1], dd = dist16[i + 1];
         if (l && dd <= i && d[i] == d[i - dd]) {
           uint32_t nl = l + 1;
           if (p->cap && nl > p->cap) nl = p->cap;
+          if (nl > 258) nl = 258; /* (without a cap: the format's longest match) */
           len16[i] = (uint16_t)nl;
           dist16[i] = (uint16_t)dd;
         }

@@ -111,6 +111,10 @@ typedef struct sfo_params {
   uint32_t use_prev;     /* 1: the byte before (distance 1) is a candidate of every position but the strip's first: a run
                             of one byte value is then coded at distance 1, as overlapping copies
                             (/root/reference/src/decompress.cpp:388-398) */
+  uint32_t stride2;      /* 1: only the even positions of a strip are searched (all are inserted into the tables).  An odd
+                            position takes over its successor's match, one byte longer (capped like any match-time
+                            length), when its own byte equals the one that far back too and the successor lies in the
+                            same step and parse region; otherwise it has no match */
   uint32_t run_dist1;    /* 1: a taken match of SFO_RUN_MIN bytes or more (with room to be longer) is coded at distance 1
                             when the bytes it covers all equal the byte before it (a run): its length is then the
                             run's (region end and 258 as usual), if that is not shorter than the extended match */

@@ -211,7 +211,10 @@ __device__ __forceinline__ uint32_t entry_addr(uint32_t v, uint32_t k1) {
 // DEPTH2: both history levels of a bucket are tried (effort 0); otherwise only the newer one (effort 1: a third
 // fewer compares, about 3 % more output).  NEAR: the step-local candidate is tried too (efforts 0 and 1; effort 2
 // leaves it out: one table read and one candidate fewer, another 2 % of output on text, more on repetitive data)
-template <bool STAMPS, bool DEPTH2, bool NEAR>
+// STRIDE2: only the even positions are searched; an odd one takes over its successor's match when its own byte fits
+// in front of it (efforts 0..2; SFH_EFFORT_THOROUGH searches every position).  The search is then pipelined over the
+// two halves of the workgroup, see the match phase.
+template <bool STAMPS, bool DEPTH2, bool NEAR, bool STRIDE2>
 __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     const uint8_t* __restrict__ src, uint64_t n_total, uint32_t strip_bytes, uint16_t* __restrict__ items,
     uint32_t* __restrict__ nitems_out, uint32_t* __restrict__ ntok_out, uint32_t* __restrict__ hist_out,
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // ---- match finding over this round ----
       const uint32_t nsteps = (qn + kStep - 1) / kStep;
       const uint32_t K = kWindow + ebase * kStep - rb;  // LDS byte address of a coded position = entry_pos(code) + K (mod 2^32)
-      uint32_t code = ((rb / kStep - ebase + 1) << 10) | (1023u - t);  // this thread's step code, step by step
+      [[maybe_unused]] uint32_t code = ((rb / kStep - ebase + 1) << 10) | (1023u - t);  // this thread's step code, step by step
       // The CU's two workgroups are in different phases most of the time.  The match phase is the long one and the one
       // that keeps the LDS and the vector units busy, so its waves go first when both workgroups have instructions ready
       // (measured: match 2 > walk 1 > stage = emit 0 takes 4 % off the kernel; walk at or above match gives it all back)
@@ -337,6 +340,127 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // before any item of the round is written.  The 16 KiB this frees in LDS hold the larger hash table.
       const uint32_t stage_off = 2u * rc * kRound;  // byte offset of the round's slots in the chunk's item array
       __builtin_amdgcn_s_setprio(2);
+      if constexpr (STRIDE2) {
+        // Only the even positions are searched, so a step has 512 searches for 1024 threads.  The two halves of the
+        // workgroup (waves 0..7 and 8..15) take the steps in turn and split a search in two: in the INTERVAL before step
+        // `it` is inserted, the half whose turn it is does the first part of step `it` -- bytes, hash, the far levels as
+        // the table holds them before the step, their ranks -- while the other half does the second part of step it - 1,
+        // whose first part it did an interval ago -- the near candidate as the table stands after that step's insertions,
+        // the winner, its extension, the odd neighbour, the results -- and reads the buckets of step `it`'s ODD
+        // positions, which it will insert.  Every thread is busy in every interval; a search costs one thread two.
+        const uint32_t grp = wave >> 3;                   // (uniform) this wave's half
+        const uint32_t tp = t & 511u;                     // index in the half: position 2 tp (+ 1) of a step
+        // an odd position takes over its successor's match only inside the step and the parse region
+        const bool inh_here = tp != 0 && (tp & (kRegion / 2 - 1)) != 0;
+        uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;  // first part -> second part
+        for (uint32_t it = 0; it <= nsteps; ++it) {
+          uint32_t ins_h = 0, ins_v = 0;
+          const uint32_t code_it = (rb / kStep + it - ebase + 1) << 10;  // (uniform) step code of step `it`
+          if ((it & 1) == grp) {
+            if (it < nsteps) {
+              // ---- first part of the search at the even position 2 tp of step `it` ----
+              const uint32_t rel = it * kStep + 2 * tp;
+              const uint32_t ad = kWindow + rel;
+              const uint32_t dw = ad >> 2, sh0 = ad & 3;
+              const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2];
+              const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
+              const uint32_t h = (a0 * 2654435761u) >> (32 - kHashBits);
+              const uint32_t farv = s_table[h];
+              const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
+              const uint32_t c0 = entry_addr(f0, K - 1), c1 = entry_addr(f1, K - 1);
+              const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 != 0 && ad - c1 <= kWindow;
+              const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
+              const uint32_t maxlen = (uint32_t)max(min(min((int)(qn - rel), (int)(rend - rel)), (int)kCap), 0);
+              uint32_t l0, l1 = 0;
+              if constexpr (DEPTH2) rank8x2(s_data, a0, a1, c0, c1, maxlen, l0, l1);
+              else l0 = rank8(s_data, a0, a1, c0, maxlen);
+              f_a0 = a0; f_a1 = a1; f_h = h; f_q0 = c0; f_q1 = c1; f_maxlen = maxlen;
+              f_m0 = ok0 ? l0 : 0u;
+              f_m1 = ok1 ? l1 : 0u;
+              ins_h = h;
+              ins_v = __builtin_amdgcn_alignbit(code_it | (1023u - 2 * tp), farv, 16);
+            }
+          } else {
+            // What this half reads for step `it`'s odd positions (which it will insert) does not depend on the search it
+            // finishes: the loads are asked for first, so that their round trips run beside the search's
+            const bool prep = it < nsteps;
+            const uint32_t ado = kWindow + it * kStep + 2 * tp + 1;
+            uint32_t e0 = 0, e1 = 0;
+            uint32_t ho = 0, oldo = 0;
+            if (it >= 1) {
+              // ---- second part of the search at the even position 2 tp of step it - 1 ----
+              const uint32_t rel = (it - 1) * kStep + 2 * tp;
+              const uint32_t ad = kWindow + rel;
+              const uint32_t a0 = f_a0, a1 = f_a1, maxlen = f_maxlen;
+              uint32_t neare = NEAR ? s_table[f_h] : 0u;
+              uint32_t pbyte = s_bytes[ad - 1];         // the odd position's byte (used if a match is found)
+              // this position's bytes 8..15 (for the winner's extension, if it comes to that)
+              uint32_t d2 = s_data[(ad >> 2) + 2], d3 = s_data[(ad >> 2) + 3], d4 = s_data[(ad >> 2) + 4];
+              if (prep) { e0 = s_data[ado >> 2]; e1 = s_data[(ado >> 2) + 1]; }
+              asm volatile("" : "+v"(neare), "+v"(pbyte), "+v"(e0), "+v"(e1), "+v"(d2), "+v"(d3), "+v"(d4));  // one round trip for all
+              if (prep) {
+                ho = (__builtin_amdgcn_alignbyte(e1, e0, ado & 3) * 2654435761u) >> (32 - kHashBits);
+                oldo = s_table[ho];
+              }
+              uint32_t best = 0, bq = ad;
+              if constexpr (NEAR) {
+                uint32_t nc;  // the step's first position with this hash (this one's own entry at the latest)
+                asm("v_sub_u32 %0, %1, %2" : "=v"(nc) : "s"(kWindow + (it - 1) * kStep + 1023u), "v"((neare >> 16) & 1023u));
+                const bool okn = nc < ad;
+                const uint32_t qnr = okn ? nc : ad;
+                const uint32_t ln = rank8(s_data, a0, a1, qnr, maxlen);
+                best = okn ? ln : 0u;
+                bq = qnr;
+              }
+              if (f_m0 > best) { best = f_m0; bq = f_q0; }
+              if (f_m1 > best) { best = f_m1; bq = f_q1; }
+              const uint32_t bd = ad - bq;
+              const uint32_t cbyte = s_bytes[(bq - 1) & 0xFFFFu];  // the byte in front of the winner (any bq reads inside LDS)
+              if (best == kRank) {
+                const uint32_t sh0 = ad & 3;
+                const uint32_t a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0), a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
+                const uint32_t lx = kRank + cmp8<kRank / 4>(s_data, a2, a3, bq);
+                best = lx < maxlen ? lx : maxlen;
+              }
+              const bool ok = best >= (bd > kFar4 ? kMinMatch + 1 : kMinMatch);
+              const uint32_t len4 = ok ? best - 3 : 0u;
+              // the odd position in front: the same match one byte longer if its byte fits too (and the candidate is
+              // not the strip's first byte: the copy would start before the strip)
+              const bool inh = ok && inh_here && pbyte == cbyte && bq + rb > kWindow;
+              const uint32_t len4o = inh ? (best < kCap ? best - 2 : kCap - 3) : 0u;
+              uint8_t* const sg = reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + 2u * rel);
+              *reinterpret_cast<uint16_t*>(sg) = (uint16_t)bd;  // only read where the length says there is a match
+              if (inh) *reinterpret_cast<uint16_t*>(sg - 2) = (uint16_t)bd;  // (never the slot in front of the round's)
+              // 4-bit lengths, SHIFTED by one position: byte j = {position 2j - 1, position 2j} of the round -- the pair
+              // this thread knows
+              smem[L_LEN4 + (rel >> 1)] = (uint8_t)(len4o | (len4 << 4));
+            } else if (prep) {
+              e0 = s_data[ado >> 2];
+              e1 = s_data[(ado >> 2) + 1];
+              ho = (__builtin_amdgcn_alignbyte(e1, e0, ado & 3) * 2654435761u) >> (32 - kHashBits);
+              oldo = s_table[ho];
+            }
+            if (prep) {
+              // ---- the odd position 2 tp + 1 of step `it`: only inserted, by this thread ----
+              ins_h = ho;
+              ins_v = __builtin_amdgcn_alignbit(code_it | (1022u - 2 * tp), oldo, 16);
+            }
+          }
+          if (it == nsteps) break;
+          lds_barrier();  // every read of the table as it stands before step `it` precedes the step's insertions
+          {
+            // {code, old newest}: the upper half of code:bucket.  (Positions without kMinMatch bytes left insert like the
+            // rest, which nothing can observe.)  A lane whose predecessor in the wave has the same bucket need not insert:
+            // that one's position is two lower, its code larger (a run would otherwise serialise the wave's atomics)
+            const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)~ins_h, (int)ins_h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            if (hp != ins_h) atomicMax(&s_table[ins_h], ins_v);
+          }
+          lds_barrier();  // insertions complete before the near reads
+        }
+        // the last position of the last step that ran is odd and has no successor in its step: no match.  Its length
+        // lives in the low half of the byte behind the step's (nobody wrote it in this round; after eight steps it is the pad)
+        if (t == 0 && nsteps < kRound / kStep) smem[L_LEN4 + nsteps * (kStep / 2)] = 0;
+      } else {
       for (uint32_t s = 0; s < nsteps; ++s) {
         const uint32_t rel = s * kStep + t;
         const uint32_t ad = kWindow + rel;                 // its LDS byte address
@@ -412,6 +536,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
                      :: "v"(rel >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
       }
+      }
       __builtin_amdgcn_s_setprio(1);  // the parse: behind the other workgroup's match, ahead of its emit
       __syncthreads();  // (also: the staged distances are visible to the whole workgroup)
       stamp(1);
@@ -446,14 +571,22 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       const uint32_t pb = 8 * t;                       // the lane's first position, round-relative
       const uint32_t nv = qn > pb ? (qn - pb < 8 ? qn - pb : 8u) : 0u;  // its valid positions
       uint32_t T;                                      // take bits of the eight positions
-      const uint32_t N = s_len4[t];
+      uint32_t N;                                      // their 4-bit lengths
       {
         // lazy deferral looks up to `lazy` positions ahead, inside the region and the input
-        const uint32_t wn = lane == 63 ? 0u : s_len4[t + 1];
+        uint64_t W;
+        if constexpr (STRIDE2) {
+          // the lengths are stored shifted by one position (see the match phase): dword t holds positions 8t-1 .. 8t+6
+          const uint32_t w0 = s_len4[t], w1 = s_len4[t + 1];
+          W = ((uint64_t)w0 | ((uint64_t)(lane == 63 ? w1 & 15u : w1) << 32)) >> 4;
+        } else {
+          const uint32_t wn = lane == 63 ? 0u : s_len4[t + 1];
+          W = (uint64_t)s_len4[t] | ((uint64_t)wn << 32);
+        }
         // positions at or beyond qn carry stale lengths of an earlier round: clear them
         const uint32_t left = qn > pb ? qn - pb : 0u;  // valid positions from this dword's first on
-        uint64_t W = (uint64_t)N | ((uint64_t)wn << 32);
         if (left < 16) W &= left ? ((1ull << (4 * left)) - 1ull) : 0ull;
+        N = (uint32_t)W;
         uint32_t bits = 0;
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
@@ -1477,16 +1610,18 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
     hipLaunchKernelGGL(kernel, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items, ws.nitems, ws.ntok,
                        ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps);
   };
-  // effort: {both levels + near, newer level + near, newer level only}
-  const uint32_t kind = opt.depth2 ? 0u : (opt.near ? 1u : 2u);
+  // effort: {every position, both levels + near} {even positions: both levels + near, newer level + near, newer level only}
+  const uint32_t kind = !opt.stride2 ? 3u : opt.depth2 ? 0u : (opt.near ? 1u : 2u);
   if (ws.stamps) {
-    if (kind == 0) launch(k_lz77<true, true, true>, ws.stamps);
-    else if (kind == 1) launch(k_lz77<true, false, true>, ws.stamps);
-    else launch(k_lz77<true, false, false>, ws.stamps);
+    if (kind == 0) launch(k_lz77<true, true, true, true>, ws.stamps);
+    else if (kind == 1) launch(k_lz77<true, false, true, true>, ws.stamps);
+    else if (kind == 2) launch(k_lz77<true, false, false, true>, ws.stamps);
+    else launch(k_lz77<true, true, true, false>, ws.stamps);
   } else {
-    if (kind == 0) launch(k_lz77<false, true, true>, (uint64_t*)nullptr);
-    else if (kind == 1) launch(k_lz77<false, false, true>, (uint64_t*)nullptr);
-    else launch(k_lz77<false, false, false>, (uint64_t*)nullptr);
+    if (kind == 0) launch(k_lz77<false, true, true, true>, (uint64_t*)nullptr);
+    else if (kind == 1) launch(k_lz77<false, false, true, true>, (uint64_t*)nullptr);
+    else if (kind == 2) launch(k_lz77<false, false, false, true>, (uint64_t*)nullptr);
+    else launch(k_lz77<false, true, true, false>, (uint64_t*)nullptr);
   }
   return hipGetLastError();
 }

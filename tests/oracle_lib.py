@@ -39,6 +39,7 @@ class Params(C.Structure):
         ("x_window", C.c_uint32),
         ("x_stride2", C.c_uint32),
         ("use_prev", C.c_uint32),
+        ("stride2", C.c_uint32),
         ("run_dist1", C.c_uint32),
     ]
 

@@ -15,7 +15,7 @@ bb = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 data = synth.gen_text_torch(n, seed=3, device="cuda")
 c = Compressor(0)
 for _ in range(2):
-    c.compress_tensor(data, block_bytes=bb)
+    c.compress_tensor(data, block_bytes=bb, effort=os.environ.get("SF_EFFORT", "default"))
 both = c.debug(_capi.DBG_STAMPS, n // 32768).astype(np.float64)
 per = c.last_block_bytes() // 32768  # k_lz77 stamps one row per strip: scale to a 32 KiB chunk
 st = both[0][: (n // 32768 + per - 1) // per] / per
