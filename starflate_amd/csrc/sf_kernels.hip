@@ -301,13 +301,19 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         pre_lo = load4(rb + kRound + kLook + 8 * t);
         pre_hi = load4(rb + kRound + kLook + 8 * t + 4);
       }
-      // age the step codes: entries older than the window drop out, the rest move down by kEpochSteps
+      // age the step codes: all move down by kEpochSteps steps, saturating at 0 -- ONE packed 16-bit instruction per
+      // bucket (v_pk_sub_u16 clamp).  What falls below 1 << 10 (step field 0) is older than the window: empty
       if (rb / kStep - ebase >= kEpochMax) {
-        constexpr uint32_t kDrop = (kEpochSteps + 1) << 10, kSub = kEpochSteps << 10;
-        for (uint32_t idx = t; idx < (1u << kHashBits); idx += K1_THREADS) {
-          const uint32_t e = s_table[idx];
-          const uint32_t hi = e >> 16, lo = e & 0xFFFFu;
-          s_table[idx] = ((hi >= kDrop ? hi - kSub : 0u) << 16) | (lo >= kDrop ? lo - kSub : 0u);
+        constexpr uint32_t kSub2 = (kEpochSteps << 10) * 0x00010001u;
+        uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
+        static_assert((1u << kHashBits) % (4 * K1_THREADS) == 0, "ageing: whole 16-byte units per thread");
+        for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) {
+          uint4 e = t4[idx];
+          asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.x) : "s"(kSub2));
+          asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.y) : "s"(kSub2));
+          asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.z) : "s"(kSub2));
+          asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.w) : "s"(kSub2));
+          t4[idx] = e;
         }
         ebase += kEpochSteps;
       }
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               const uint32_t farv = s_table[h];
               const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
               const uint32_t c0 = entry_addr(f0, K - 1), c1 = entry_addr(f1, K - 1);
-              const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 != 0 && ad - c1 <= kWindow;
+              const bool ok0 = f0 >= kStep && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 >= kStep && ad - c1 <= kWindow;  // (a code below 1 << 10: empty)
               const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
               const uint32_t maxlen = (uint32_t)max(min(min((int)(qn - rel), (int)(rend - rel)), (int)kCap), 0);
               uint32_t l0, l1 = 0;
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         // the far candidates only need the (immutable) window: compare them ahead of the barriers
         const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
         const uint32_t c0 = entry_addr(f0, K - 1), c1 = entry_addr(f1, K - 1);
-        const bool ok0 = f0 != 0 && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 != 0 && ad - c1 <= kWindow;
+        const bool ok0 = f0 >= kStep && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 >= kStep && ad - c1 <= kWindow;  // (a code below 1 << 10: empty)
         // an empty or outdated entry decodes to some address that is not a candidate: it is still read (kept inside
         // the LDS allocation by a 16-bit mask that leaves real candidates alone), its rank is dropped
         static_assert(kWindow + kRound + kLook <= 0x10000 && 0x10000 + 16 <= K1_LDS, "candidate reads stay in LDS");
@@ -587,16 +593,27 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t left = qn > pb ? qn - pb : 0u;  // valid positions from this dword's first on
         if (left < 16) W &= left ? ((1ull << (4 * left)) - 1ull) : 0ull;
         N = (uint32_t)W;
-        uint32_t bits = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-          const uint32_t cur = (uint32_t)(W >> (4 * k)) & 15u;
-          const uint32_t a1 = lazy >= 1 ? (uint32_t)(W >> (4 * k + 4)) & 15u : 0u;
-          const uint32_t a2 = lazy >= 2 ? (uint32_t)(W >> (4 * k + 8)) & 15u : 0u;
-          const uint32_t a3 = lazy >= 3 ? (uint32_t)(W >> (4 * k + 12)) & 15u : 0u;
-          const bool defer = a1 > cur || a2 > cur + 1 || a3 > cur + 2;
-          bits |= (cur != 0 && !defer) ? (1u << k) : 0u;
-        }
+        // All eight positions at once, a byte per position (SWAR): the 4-bit lengths of positions 0..10 are spread into
+        // the bytes of three dwords; b > a + j for bytes a, b <= 15 is bit 7 of (b + 0x7F - j) - a, and no byte borrows from
+        // its neighbour (every byte stays in 112..142); the eight bit-7s are gathered by two byte dot products.
+        const uint32_t wl = (uint32_t)W, wh = (uint32_t)(W >> 32);
+        const uint32_t le = wl & 0x0F0F0F0Fu, lo4 = (wl >> 4) & 0x0F0F0F0Fu;   // positions 0,2,4,6 | 1,3,5,7
+        const uint32_t he = wh & 0x0F0F0F0Fu, ho4 = (wh >> 4) & 0x0F0F0F0Fu;   // positions 8,10,.. | 9,11,..
+        const uint32_t c0 = __builtin_amdgcn_perm(lo4, le, 0x05010400u);       // bytes = positions 0,1,2,3
+        const uint32_t c1 = __builtin_amdgcn_perm(lo4, le, 0x07030602u);       // positions 4..7
+        const uint32_t c2 = __builtin_amdgcn_perm(ho4, he, 0x05010400u);       // positions 8..11
+        // uniform: which look-aheads count (lazy = 0..3)
+        const uint32_t m1 = lazy >= 1 ? 0x80808080u : 0u, m2 = lazy >= 2 ? 0x80808080u : 0u, m3 = lazy >= 3 ? 0x80808080u : 0u;
+        auto take4 = [&](uint32_t cur, uint32_t nx) {  // cur: four positions, nx: the four behind them
+          const uint32_t a1 = __builtin_amdgcn_alignbyte(nx, cur, 1), a2 = __builtin_amdgcn_alignbyte(nx, cur, 2),
+                         a3 = __builtin_amdgcn_alignbyte(nx, cur, 3);
+          const uint32_t t1 = (a1 + 0x7F7F7F7Fu) - cur, t2 = (a2 + 0x7E7E7E7Eu) - cur, t3 = (a3 + 0x7D7D7D7Du) - cur;
+          const uint32_t defer = (t1 & m1) | (t2 & m2) | (t3 & m3);
+          return (cur + 0x7F7F7F7Fu) & ~defer & 0x80808080u;  // bit 7: a match, and nothing ahead says wait
+        };
+        const uint32_t k0 = take4(c0, c1), k1 = take4(c1, c2);
+        // 0x80 * (b0 + 2 b1 + 4 b2 + 8 b3) + 0x80 * (16 b4 + ...): bits 7..14
+        const uint32_t bits = __builtin_amdgcn_udot4(k1, 0x80402010u, __builtin_amdgcn_udot4(k0, 0x08040201u, 0u, false), false) >> 7;
         T = bits;
       }
       stamp(2);
