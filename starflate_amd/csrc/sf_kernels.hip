@@ -578,6 +578,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       const uint32_t nv = qn > pb ? (qn - pb < 8 ? qn - pb : 8u) : 0u;  // its valid positions
       uint32_t T;                                      // take bits of the eight positions
       uint32_t N;                                      // their 4-bit lengths
+      uint32_t c0, c1, k0, k1;                         // a byte per position: 4-bit length (0..13) | 0x80 where T says take
       {
         // lazy deferral looks up to `lazy` positions ahead, inside the region and the input
         uint64_t W;
@@ -599,8 +600,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t wl = (uint32_t)W, wh = (uint32_t)(W >> 32);
         const uint32_t le = wl & 0x0F0F0F0Fu, lo4 = (wl >> 4) & 0x0F0F0F0Fu;   // positions 0,2,4,6 | 1,3,5,7
         const uint32_t he = wh & 0x0F0F0F0Fu, ho4 = (wh >> 4) & 0x0F0F0F0Fu;   // positions 8,10,.. | 9,11,..
-        const uint32_t c0 = __builtin_amdgcn_perm(lo4, le, 0x05010400u);       // bytes = positions 0,1,2,3
-        const uint32_t c1 = __builtin_amdgcn_perm(lo4, le, 0x07030602u);       // positions 4..7
+        c0 = __builtin_amdgcn_perm(lo4, le, 0x05010400u);                      // bytes = positions 0,1,2,3
+        c1 = __builtin_amdgcn_perm(lo4, le, 0x07030602u);                      // positions 4..7
         const uint32_t c2 = __builtin_amdgcn_perm(ho4, he, 0x05010400u);       // positions 8..11
         // uniform: which look-aheads count (lazy = 0..3)
         const uint32_t m1 = lazy >= 1 ? 0x80808080u : 0u, m2 = lazy >= 2 ? 0x80808080u : 0u, m3 = lazy >= 3 ? 0x80808080u : 0u;
@@ -611,7 +612,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           const uint32_t defer = (t1 & m1) | (t2 & m2) | (t3 & m3);
           return (cur + 0x7F7F7F7Fu) & ~defer & 0x80808080u;  // bit 7: a match, and nothing ahead says wait
         };
-        const uint32_t k0 = take4(c0, c1), k1 = take4(c1, c2);
+        k0 = take4(c0, c1);
+        k1 = take4(c1, c2);
         // 0x80 * (b0 + 2 b1 + 4 b2 + 8 b3) + 0x80 * (16 b4 + ...): bits 7..14
         const uint32_t bits = __builtin_amdgcn_udot4(k1, 0x80402010u, __builtin_amdgcn_udot4(k0, 0x08040201u, 0u, false), false) >> 7;
         T = bits;
@@ -624,65 +626,83 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       {
         const uint32_t lb = 8 * lane;                  // the lane's first position, region-relative
         const uint32_t rend = (pb & ~(kRegion - 1)) + kRegion < qn ? (pb & ~(kRegion - 1)) + kRegion : qn;  // region end, round-relative
-        // follow the chain from local offset e (< nv): at most two matches fit into eight positions, so two
-        // predicated passes (literals up to a taken match, the match) cover the lane; straight-line code but for
-        // the extension of a match that was capped at match time (kCap bytes or more: it leaves the lane whatever
-        // its length).  The lane itself looks at the next kLaneExt bytes, which settles nearly every such match of
-        // ordinary data; one that is still going then (a run, a repeated record) is noted for the wave
+        // The lane's TRANSFER FUNCTION, for all eight possible entries at once (a byte per entry, SWAR): where the chain
+        // leaves the lane when it enters at position e (ex: 8..23 = the position behind the lane's eight it jumps to,
+        // 0x80 | k = it takes the match at k that was capped at match time, whose length only the extension knows)
+        // and which of the lane's positions it visits (mk).  A position's successor is position + 1 (literal) or
+        // + length (taken match); successors of successors by pointer doubling -- v_perm_b32 IS an eight-entry byte
+        // table -- three times, since a chain has at most eight hops inside a lane.  The reconcile rounds below then
+        // look an entry up instead of walking it.
+        uint32_t elo, ehi, mlo = 0x08040201u, mhi = 0x80402010u;
+        {
+          auto spread = [](uint32_t bit7s) { return (bit7s >> 7) * 0xFFu; };  // 0x80 -> 0xFF in every byte
+          const uint32_t t0 = spread(k0), t1 = spread(k1);
+          const uint32_t s0 = (t0 & (c0 + 0x03030303u)) | (~t0 & 0x01010101u), s1 = (t1 & (c1 + 0x03030303u)) | (~t1 & 0x01010101u);
+          constexpr uint32_t kCap4 = (kCap - 3) * 0x01010101u;
+          const uint32_t cp0 = spread(~((c0 ^ kCap4) + 0x7F7F7F7Fu) & k0), cp1 = spread(~((c1 ^ kCap4) + 0x7F7F7F7Fu) & k1);
+          elo = (cp0 & 0x83828180u) | (~cp0 & (s0 + 0x03020100u));
+          ehi = (cp1 & 0x87868584u) | (~cp1 & (s1 + 0x07060504u));
+#pragma unroll
+          for (uint32_t j = 0; j < 3; ++j) {
+            const uint32_t tm0 = spread((elo + 0x78787878u) & 0x80808080u), tm1 = spread((ehi + 0x78787878u) & 0x80808080u);  // final already
+            const uint32_t g0 = __builtin_amdgcn_perm(ehi, elo, elo), g1 = __builtin_amdgcn_perm(ehi, elo, ehi);
+            const uint32_t h0 = __builtin_amdgcn_perm(mhi, mlo, elo), h1 = __builtin_amdgcn_perm(mhi, mlo, ehi);
+            mlo |= h0 & ~tm0;
+            mhi |= h1 & ~tm1;
+            elo = (tm0 & elo) | (~tm0 & g0);
+            ehi = (tm1 & ehi) | (~tm1 & g1);
+          }
+        }
+        const uint32_t vmask = (1u << nv) - 1u;          // the lane's valid positions
+        // The chain enters at local offset e (< nv).  A match that was capped at match time (kCap bytes or more: it leaves
+        // the lane whatever its length) is extended here, once per position: the lane itself looks at the next kLaneExt
+        // bytes, which settles nearly every such match of ordinary data; one that is still going then (a run, a repeated
+        // record) is noted for the wave
         constexpr uint32_t kLaneExt = 16;
         // cap_mp: 0..7 the position whose extended length cap_len holds, 8 none, 16 + p: position p waits for the wave
         auto walk = [&](uint32_t e) {
-          uint32_t pos = e, mk = 0;
           cap_mp = cap_mp >= 16 ? 8u : cap_mp;           // a request of an earlier walk is void
-#pragma unroll
-          for (uint32_t it = 0; it < 2; ++it) {
-            const bool act = pos < nv;
-            const uint32_t m = act ? (T >> (pos & 7)) : 0u;
-            const bool hit = m != 0;
-            const uint32_t k = ffbl(m) & 7u;  // only used where hit (m has a bit among its low eight)
-            // literals from pos up to the match position (or the lane's last valid one): bits pos&7 .. hi
-            const uint32_t hi = hit ? (pos & 7) + k : nv - 1u;
-            mk |= act ? (2u << hi) - (1u << (pos & 7)) : 0u;
-            const uint32_t mp = (pos + k) & 7;
-            uint32_t len = ((N >> (4 * mp)) & 15u) + 3;
-            if (hit && len == kCap) {                    // capped at match time: extend (once per position)
-              if (cap_mp != mp) {
-                cap_run = false;
-                const uint32_t xpa = kWindow + pb + mp, xca = xpa - dist_of(mp);
-                const uint32_t xmax = rend - (pb + mp) < 258u ? rend - (pb + mp) : 258u;
-                // the next kLaneExt bytes of both strings, straight-line (bytes past xmax are cut off below)
-                static_assert(kLaneExt == 16, "four dwords per string");
-                const uint32_t ia = xpa + kCap, ja = xca + kCap;
-                const uint32_t* ip = s_data + (ia >> 2);
-                const uint32_t* jp = s_data + (ja >> 2);
-                const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3], i4 = ip[4];
-                const uint32_t j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4];
-                const uint32_t si = ia & 3, sj = ja & 3;
-                const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, si) ^ __builtin_amdgcn_alignbyte(j1, j0, sj);
-                const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, si) ^ __builtin_amdgcn_alignbyte(j2, j1, sj);
-                const uint32_t x2 = __builtin_amdgcn_alignbyte(i3, i2, si) ^ __builtin_amdgcn_alignbyte(j3, j2, sj);
-                const uint32_t x3 = __builtin_amdgcn_alignbyte(i4, i3, si) ^ __builtin_amdgcn_alignbyte(j4, j3, sj);
-                // first differing bit of x3:x2:x1:x0 (all ones when there is none: ffbl(0) = 0xFFFFFFFF survives the ORs)
-                const uint32_t fb = min(min(ffbl(x0), ffbl(x1) | 32u), min(ffbl(x2) | 64u, ffbl(x3) | 96u));
-                const bool open = fb >= 8 * kLaneExt;      // all kLaneExt bytes equal
-                uint32_t l = kCap + (open ? kLaneExt : fb >> 3);
-                l = l < xmax ? l : xmax;
-                if (open && l < xmax) {
-                  cap_mp = 16 + mp;                      // still equal after kLaneExt more bytes: the wave's turn
-                  len = kCap + kLaneExt;                 // provisional (the chain has left the lane anyway)
-                } else {
-                  cap_mp = mp;
-                  cap_len = l;
-                  len = l;
-                }
+          const uint32_t ex = __builtin_amdgcn_perm(ehi, elo, e) & 0xFFu;
+          uint32_t pos = ex;
+          if (ex & 0x80u) {                              // capped at match time: extend (once per position)
+            const uint32_t mp = ex & 7u;
+            uint32_t len;
+            if (cap_mp != mp) {
+              cap_run = false;
+              const uint32_t xpa = kWindow + pb + mp, xca = xpa - dist_of(mp);
+              const uint32_t xmax = rend - (pb + mp) < 258u ? rend - (pb + mp) : 258u;
+              // the next kLaneExt bytes of both strings, straight-line (bytes past xmax are cut off below)
+              static_assert(kLaneExt == 16, "four dwords per string");
+              const uint32_t ia = xpa + kCap, ja = xca + kCap;
+              const uint32_t* ip = s_data + (ia >> 2);
+              const uint32_t* jp = s_data + (ja >> 2);
+              const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3], i4 = ip[4];
+              const uint32_t j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4];
+              const uint32_t si = ia & 3, sj = ja & 3;
+              const uint32_t x0 = __builtin_amdgcn_alignbyte(i1, i0, si) ^ __builtin_amdgcn_alignbyte(j1, j0, sj);
+              const uint32_t x1 = __builtin_amdgcn_alignbyte(i2, i1, si) ^ __builtin_amdgcn_alignbyte(j2, j1, sj);
+              const uint32_t x2 = __builtin_amdgcn_alignbyte(i3, i2, si) ^ __builtin_amdgcn_alignbyte(j3, j2, sj);
+              const uint32_t x3 = __builtin_amdgcn_alignbyte(i4, i3, si) ^ __builtin_amdgcn_alignbyte(j4, j3, sj);
+              // first differing bit of x3:x2:x1:x0 (all ones when there is none: ffbl(0) = 0xFFFFFFFF survives the ORs)
+              const uint32_t fb = min(min(ffbl(x0), ffbl(x1) | 32u), min(ffbl(x2) | 64u, ffbl(x3) | 96u));
+              const bool open = fb >= 8 * kLaneExt;      // all kLaneExt bytes equal
+              uint32_t l = kCap + (open ? kLaneExt : fb >> 3);
+              l = l < xmax ? l : xmax;
+              if (open && l < xmax) {
+                cap_mp = 16 + mp;                        // still equal after kLaneExt more bytes: the wave's turn
+                len = kCap + kLaneExt;                   // provisional (the chain has left the lane anyway)
               } else {
-                len = cap_len;
+                cap_mp = mp;
+                cap_len = l;
+                len = l;
               }
+            } else {
+              len = cap_len;
             }
-            pos = hit ? mp + len : (act ? 8u : pos);
+            pos = mp + len;
           }
-          marks = mk;
-          exit_abs = lb + (pos > 8 ? pos : 8u);
+          marks = __builtin_amdgcn_perm(mhi, mlo, e) & vmask;
+          exit_abs = lb + pos;                           // (pos >= 8: the chain has left the lane)
         };
         // A long capped match, by the whole wave: lane l compares the four bytes at offset kCap + kLaneExt + 4 l of
         // the two strings, so one pass covers the 258 bytes a match can have.  Only the FIRST waiting lane is served
