@@ -342,8 +342,9 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // (measured: match 2 > walk 1 > stage = emit 0 takes 4 % off the kernel; walk at or above match gives it all back)
       // The round's distances (16 bits per position) do not live in LDS: they are STAGED in the chunk's own item array,
       // in the slots of the round's positions -- free at this point, because a chunk never has more items than positions
-      // (a match of kMinMatch bytes or more takes two) -- and every lane reads its eight back at the start of the parse,
-      // before any item of the round is written.  The 16 KiB this frees in LDS hold the larger hash table.
+      // (a match of kMinMatch bytes or more takes two) -- and every lane reads its own back at the start of the parse,
+      // before any item of the round is written.  The 16 KiB this frees in LDS hold the larger hash table.  (With the even
+      // positions searched only, one slot per even position: an odd position's distance is its successor's.)
       const uint32_t stage_off = 2u * rc * kRound;  // byte offset of the round's slots in the chunk's item array
       __builtin_amdgcn_s_setprio(2);
       if constexpr (STRIDE2) {
@@ -434,9 +435,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               // not the strip's first byte: the copy would start before the strip)
               const bool inh = ok && inh_here && pbyte == cbyte && bq + rb > kWindow;
               const uint32_t len4o = inh ? (best < kCap ? best - 2 : kCap - 3) : 0u;
-              uint8_t* const sg = reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + 2u * rel);
-              *reinterpret_cast<uint16_t*>(sg) = (uint16_t)bd;  // only read where the length says there is a match
-              if (inh) *reinterpret_cast<uint16_t*>(sg - 2) = (uint16_t)bd;  // (never the slot in front of the round's)
+              // one staging slot per EVEN position (an odd position that has a match has its successor's distance)
+              *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + rel)) = (uint16_t)bd;  // only read where the length says there is a match
               // 4-bit lengths, SHIFTED by one position: byte j = {position 2j - 1, position 2j} of the round -- the pair
               // this thread knows
               smem[L_LEN4 + (rel >> 1)] = (uint8_t)(len4o | (len4 << 4));
@@ -548,16 +548,28 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       stamp(1);
       // the lane's eight staged distances: asked for now, used by the extensions and the emit.  Every wave has them
       // before any wave writes an item (the barrier between walk and emit waits for outstanding loads)
-      uint32_t D0, D1, D2, D3;
-      {
+      uint32_t D0, D1, D2 = 0, D3 = 0;
+      if constexpr (STRIDE2) {
+        // four slots: the lane's even positions; position 7's successor is the next lane's position 0
+        const uint2 D = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(gi) + (uint64_t)(stage_off + 8u * t));
+        D0 = D.x; D1 = D.y;
+        asm volatile("" : "+v"(D0), "+v"(D1));
+        D2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)D0, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);  // (lane 63: its position 7 ends the region, never inherits)
+      } else {
         const uint4 D = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(gi) + (uint64_t)(stage_off + 16u * t));
         D0 = D.x; D1 = D.y; D2 = D.z; D3 = D.w;
         asm volatile("" : "+v"(D0), "+v"(D1), "+v"(D2), "+v"(D3));  // four registers, not an indexable vector (scratch)
       }
       auto dist_of = [&](uint32_t k) {  // distance of the lane's position k (0..7)
-        const uint32_t lo = (k & 2u) ? D1 : D0, hi = (k & 2u) ? D3 : D2;
-        const uint32_t w = (k & 4u) ? hi : lo;
-        return (k & 1u) ? w >> 16 : w & 0xFFFFu;
+        if constexpr (STRIDE2) {
+          const uint32_t e = (k + 1u) >> 1;            // even position 2e holds it (an odd k: its successor's); e = 0..4
+          const uint32_t w = (e & 4u) ? D2 : ((e & 2u) ? D1 : D0);
+          return (e & 1u) ? w >> 16 : w & 0xFFFFu;
+        } else {
+          const uint32_t lo = (k & 2u) ? D1 : D0, hi = (k & 2u) ? D3 : D2;
+          const uint32_t w = (k & 4u) ? hi : lo;
+          return (k & 1u) ? w >> 16 : w & 0xFFFFu;
+        }
       };
 
       // ---- parse: wave-local.  Thread t owns the eight positions [8t, 8t+8) of the round, a wave one
