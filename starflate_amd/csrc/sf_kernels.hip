@@ -1391,7 +1391,7 @@ constexpr uint32_t K4_IPT = 8;  // items per thread per batch (one 16-byte load)
 // literal, + the largest dynamic header) + alignment and the bit writers' slack; four workgroups fit a CU's LDS
 constexpr uint32_t K4_STAGE_WORDS = 9392;
 static_assert(4 * K4_STAGE_WORDS >= kChunk + kChunk / 8 + 640 + 16 + 8, "k_emit: stage holds the largest chunk");
-static_assert(4 * (4 * K4_STAGE_WORDS + 4 * (288 + 32 + 256 + 2 * 8 + kSubRegions)) <= 160 * 1024, "k_emit: four workgroups per CU");
+static_assert(4 * (4 * K4_STAGE_WORDS + 4 * (288 + 32 + 256 + 2 * 8 + kSubRegions) + 512) <= 160 * 1024, "k_emit: four workgroups per CU");
 
 // code bits of one token: literal byte, or match (l3 = len-3, d1 = dist-1)
 __device__ __forceinline__ void literal_bits(uint32_t byte, const uint32_t* lcode, uint64_t& value, uint32_t& nb) {
@@ -1438,6 +1438,9 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
   __shared__ uint32_t s_lenlut[256];
   __shared__ uint32_t s_wtot[2][K4_WAVES];
   __shared__ uint32_t s_rtok[kSubRegions];
+  // distance - 1 -> symbol: [d] below 256, [256 + (d >> 7)] from there on (symbols 16.. cover whole multiples of 128)
+  __shared__ uint8_t s_dsym[512];
+  static_assert(K4_THREADS == 512, "one table entry per thread");
 
   const uint32_t t = threadIdx.x, lane = t & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
@@ -1505,6 +1508,7 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
   }
   __syncthreads();
   if (t < 256) s_lenlut[t] = lenlut_entry(t, s_lcode);
+  s_dsym[t] = (uint8_t)dist_symbol_of(t < 256 ? t : (t - 256) << 7);
   {
     uint8_t* sb = reinterpret_cast<uint8_t*>(s_stage) + sh;
     const uint8_t* hb = reinterpret_cast<const uint8_t*>(C.header);
@@ -1551,7 +1555,8 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
     for (uint32_t k = 0; k < K4_IPT; ++k) {
       lcv[k] = s_lcode[e[k + 1] & 0xFFu];
       lev[k] = s_lenlut[e[k + 1] & 0xFFu];
-      dcv[k] = s_dcode[dist_symbol_of(e[k + 1] & 0x7FFFu)];
+      const uint32_t dd = e[k + 1] & 0x7FFFu;
+      dcv[k] = s_dcode[s_dsym[dd < 256 ? dd : 256 + (dd >> 7)]];
     }
     asm volatile("" : "+v"(lcv[0]), "+v"(lcv[1]), "+v"(lcv[2]), "+v"(lcv[3]), "+v"(lcv[4]), "+v"(lcv[5]), "+v"(lcv[6]), "+v"(lcv[7]),
                       "+v"(lev[0]), "+v"(lev[1]), "+v"(lev[2]), "+v"(lev[3]), "+v"(lev[4]), "+v"(lev[5]), "+v"(lev[6]), "+v"(lev[7]),
