@@ -199,8 +199,9 @@ static_assert(kStep == 1024, "entry encoding");
 __device__ __forceinline__ uint32_t entry_pos(uint32_t v) { return v - 1u - 2u * (v & 1023u); }
 // entry_pos(v) + k1 + 1 in three instructions (the multiply-add is spelled out: left to itself the compiler
 // expands the expression into twice as many shifts and masks)
+template <uint32_t SH>
 __device__ __forceinline__ uint32_t entry_addr(uint32_t v, uint32_t k1) {
-  const uint32_t lo = v & 1023u;
+  const uint32_t lo = v & ((1u << SH) - 1u);
   uint32_t c;
   asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(c) : "v"(lo), "v"(v));
   return c + k1;
@@ -229,6 +230,12 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     }
   };
   if constexpr (STAMPS) st_t = __builtin_amdgcn_s_memtime();
+  // positions per insertion step: 1024 of which the even ones are searched, or 512 all of which are (thorough)
+  constexpr uint32_t SH = STRIDE2 ? 10u : 9u, STEP = 1u << SH;
+  // step codes in a 16-bit table half: ((step - epoch) + 1) << SH | (STEP - 1 - index in the step); the epoch advances by
+  // kEpS steps whenever a round would reach kEpMax steps past it, entries older than that vanish
+  constexpr uint32_t kEpS = (kEpochSteps << 10) >> SH, kEpMax = (kEpochMax << 10) >> SH;
+  static_assert(((kEpMax + 1) << SH) <= 65536 && kRound % STEP == 0, "step codes");
 
   // static LDS (its address is a compile-time constant: no base register, no add per access)
   __shared__ __attribute__((aligned(16))) uint8_t smem[K1_LDS];
@@ -303,8 +310,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       }
       // age the step codes: all move down by kEpochSteps steps, saturating at 0 -- ONE packed 16-bit instruction per
       // bucket (v_pk_sub_u16 clamp).  What falls below 1 << 10 (step field 0) is older than the window: empty
-      if (rb / kStep - ebase >= kEpochMax) {
-        constexpr uint32_t kSub2 = (kEpochSteps << 10) * 0x00010001u;
+      if (rb / STEP - ebase >= kEpMax) {
+        constexpr uint32_t kSub2 = (kEpS << SH) * 0x00010001u;
         uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
         static_assert((1u << kHashBits) % (4 * K1_THREADS) == 0, "ageing: whole 16-byte units per thread");
         for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) {
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.w) : "s"(kSub2));
           t4[idx] = e;
         }
-        ebase += kEpochSteps;
+        ebase += kEpS;
       }
       __syncthreads();
     }
@@ -334,9 +341,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       tot_items += qn;
     } else {
       // ---- match finding over this round ----
-      const uint32_t nsteps = (qn + kStep - 1) / kStep;
-      const uint32_t K = kWindow + ebase * kStep - rb;  // LDS byte address of a coded position = entry_pos(code) + K (mod 2^32)
-      [[maybe_unused]] uint32_t code = ((rb / kStep - ebase + 1) << 10) | (1023u - t);  // this thread's step code, step by step
+      const uint32_t nsteps = (qn + STEP - 1) / STEP;
+      const uint32_t K = kWindow + ebase * STEP - rb;  // LDS byte address of a coded position = entry_pos(code) + K (mod 2^32)
       // The CU's two workgroups are in different phases most of the time.  The match phase is the long one and the one
       // that keeps the LDS and the vector units busy, so its waves go first when both workgroups have instructions ready
       // (measured: match 2 > walk 1 > stage = emit 0 takes 4 % off the kernel; walk at or above match gives it all back)
@@ -347,26 +353,29 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // positions searched only, one slot per even position: an odd position's distance is its successor's.)
       const uint32_t stage_off = 2u * rc * kRound;  // byte offset of the round's slots in the chunk's item array
       __builtin_amdgcn_s_setprio(2);
-      if constexpr (STRIDE2) {
-        // Only the even positions are searched, so a step has 512 searches for 1024 threads.  The two halves of the
-        // workgroup (waves 0..7 and 8..15) take the steps in turn and split a search in two: in the INTERVAL before step
-        // `it` is inserted, the half whose turn it is does the first part of step `it` -- bytes, hash, the far levels as
-        // the table holds them before the step, their ranks -- while the other half does the second part of step it - 1,
-        // whose first part it did an interval ago -- the near candidate as the table stands after that step's insertions,
-        // the winner, its extension, the odd neighbour, the results -- and reads the buckets of step `it`'s ODD
-        // positions, which it will insert.  Every thread is busy in every interval; a search costs one thread two.
+      {
+        // A step has 512 searches for 1024 threads: the even positions of 1024 (STRIDE2), or all of 512 (thorough).  The
+        // two halves of the workgroup (waves 0..7 and 8..15) take the steps in turn and split a search in two: in the
+        // INTERVAL before step `it` is inserted, the half whose turn it is does the first part of step `it` -- bytes,
+        // hash, the far levels as the table holds them before the step, their ranks -- while the other half does the
+        // second part of step it - 1, whose first part it did an interval ago -- the near candidate as the table stands
+        // after that step's insertions, the winner, its extension, the results -- and, with STRIDE2, reads the buckets of
+        // step `it`'s ODD positions, which it will insert.  Every thread is busy in every interval; a search costs one
+        // thread two.
         const uint32_t grp = wave >> 3;                   // (uniform) this wave's half
-        const uint32_t tp = t & 511u;                     // index in the half: position 2 tp (+ 1) of a step
+        const uint32_t tp = t & 511u;                     // index in the half
+        const uint32_t ps = STRIDE2 ? 2 * tp : tp;        // the thread's searched position within a step
         // an odd position takes over its successor's match only inside the step and the parse region
-        const bool inh_here = tp != 0 && (tp & (kRegion / 2 - 1)) != 0;
+        [[maybe_unused]] const bool inh_here = tp != 0 && (tp & (kRegion / 2 - 1)) != 0;
         uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;  // first part -> second part
         for (uint32_t it = 0; it <= nsteps; ++it) {
           uint32_t ins_h = 0, ins_v = 0;
-          const uint32_t code_it = (rb / kStep + it - ebase + 1) << 10;  // (uniform) step code of step `it`
+          bool has_ins = false;                           // (uniform) this wave inserts in this interval
+          const uint32_t code_it = (rb / STEP + it - ebase + 1) << SH;  // (uniform) step code of step `it`
           if ((it & 1) == grp) {
             if (it < nsteps) {
-              // ---- first part of the search at the even position 2 tp of step `it` ----
-              const uint32_t rel = it * kStep + 2 * tp;
+              // ---- first part of the search at position ps of step `it` ----
+              const uint32_t rel = it * STEP + ps;
               const uint32_t ad = kWindow + rel;
               const uint32_t dw = ad >> 2, sh0 = ad & 3;
               const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2];
@@ -374,10 +383,16 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               const uint32_t h = (a0 * 2654435761u) >> (32 - kHashBits);
               const uint32_t farv = s_table[h];
               const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
-              const uint32_t c0 = entry_addr(f0, K - 1), c1 = entry_addr(f1, K - 1);
-              const bool ok0 = f0 >= kStep && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 >= kStep && ad - c1 <= kWindow;  // (a code below 1 << 10: empty)
+              const uint32_t c0 = entry_addr<SH>(f0, K - 1), c1 = entry_addr<SH>(f1, K - 1);
+              // (a code below 1 << SH: empty.)  An empty or outdated entry decodes to some address that is not a candidate:
+              // it is still read (kept inside the LDS allocation by a 16-bit mask that leaves real candidates alone), its
+              // rank is dropped
+              static_assert(kWindow + kRound + kLook <= 0x10000 && 0x10000 + 16 <= K1_LDS, "candidate reads stay in LDS");
+              const bool ok0 = f0 >= STEP && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 >= STEP && ad - c1 <= kWindow;
+              // bytes a match may take from here: inside the round's valid part, the parse region and kCap (0 beyond qn)
               const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
               const uint32_t maxlen = (uint32_t)max(min(min((int)(qn - rel), (int)(rend - rel)), (int)kCap), 0);
+              // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
               uint32_t l0, l1 = 0;
               if constexpr (DEPTH2) rank8x2(s_data, a0, a1, c0, c1, maxlen, l0, l1);
               else l0 = rank8(s_data, a0, a1, c0, maxlen);
@@ -385,22 +400,23 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               f_m0 = ok0 ? l0 : 0u;
               f_m1 = ok1 ? l1 : 0u;
               ins_h = h;
-              ins_v = __builtin_amdgcn_alignbit(code_it | (1023u - 2 * tp), farv, 16);
+              ins_v = __builtin_amdgcn_alignbit(code_it | (STEP - 1u - ps), farv, 16);
+              has_ins = true;
             }
           } else {
             // What this half reads for step `it`'s odd positions (which it will insert) does not depend on the search it
             // finishes: the loads are asked for first, so that their round trips run beside the search's
-            const bool prep = it < nsteps;
-            const uint32_t ado = kWindow + it * kStep + 2 * tp + 1;
+            const bool prep = STRIDE2 && it < nsteps;
+            const uint32_t ado = kWindow + it * STEP + 2 * tp + 1;
             uint32_t e0 = 0, e1 = 0;
             uint32_t ho = 0, oldo = 0;
             if (it >= 1) {
-              // ---- second part of the search at the even position 2 tp of step it - 1 ----
-              const uint32_t rel = (it - 1) * kStep + 2 * tp;
+              // ---- second part of the search at position ps of step it - 1 ----
+              const uint32_t rel = (it - 1) * STEP + ps;
               const uint32_t ad = kWindow + rel;
               const uint32_t a0 = f_a0, a1 = f_a1, maxlen = f_maxlen;
               uint32_t neare = NEAR ? s_table[f_h] : 0u;
-              uint32_t pbyte = s_bytes[ad - 1];         // the odd position's byte (used if a match is found)
+              uint32_t pbyte = STRIDE2 ? s_bytes[ad - 1] : 0u;  // the odd position's byte (used if a match is found)
               // this position's bytes 8..15 (for the winner's extension, if it comes to that)
               uint32_t d2 = s_data[(ad >> 2) + 2], d3 = s_data[(ad >> 2) + 3], d4 = s_data[(ad >> 2) + 4];
               if (prep) { e0 = s_data[ado >> 2]; e1 = s_data[(ado >> 2) + 1]; }
@@ -409,10 +425,13 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 ho = (__builtin_amdgcn_alignbyte(e1, e0, ado & 3) * 2654435761u) >> (32 - kHashBits);
                 oldo = s_table[ho];
               }
+              // longest wins; ties go to the smaller distance: near, then the newer far level
               uint32_t best = 0, bq = ad;
               if constexpr (NEAR) {
-                uint32_t nc;  // the step's first position with this hash (this one's own entry at the latest)
-                asm("v_sub_u32 %0, %1, %2" : "=v"(nc) : "s"(kWindow + (it - 1) * kStep + 1023u), "v"((neare >> 16) & 1023u));
+                // the step's first position with this hash: this one's own entry at the latest, so the bucket is not empty
+                // (and it is of this very step: only its index in the step has to be decoded)
+                uint32_t nc;
+                asm("v_sub_u32 %0, %1, %2" : "=v"(nc) : "s"(kWindow + (it - 1) * STEP + STEP - 1u), "v"((neare >> 16) & (STEP - 1u)));
                 const bool okn = nc < ad;
                 const uint32_t qnr = okn ? nc : ad;
                 const uint32_t ln = rank8(s_data, a0, a1, qnr, maxlen);
@@ -422,24 +441,39 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               if (f_m0 > best) { best = f_m0; bq = f_q0; }
               if (f_m1 > best) { best = f_m1; bq = f_q1; }
               const uint32_t bd = ad - bq;
-              const uint32_t cbyte = s_bytes[(bq - 1) & 0xFFFFu];  // the byte in front of the winner (any bq reads inside LDS)
+              const uint32_t cbyte = STRIDE2 ? s_bytes[(bq - 1) & 0xFFFFu] : 0u;  // the byte in front of the winner (any bq reads inside LDS)
               if (best == kRank) {
+                // the winner's next eight bytes, only where its first kRank all matched
                 const uint32_t sh0 = ad & 3;
                 const uint32_t a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0), a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
-                const uint32_t lx = kRank + cmp8<kRank / 4>(s_data, a2, a3, bq);
+                const uint32_t lx = kRank + cmp8<kRank / 4>(s_data, a2, a3, bq);  // maxlen <= kCap does the capping
                 best = lx < maxlen ? lx : maxlen;
               }
+              // a 4-byte match farther than kFar4 costs more bits than four literals: drop it.  (maxlen <= n - p, so a
+              // position without kMinMatch bytes left cannot reach kMinMatch.)
               const bool ok = best >= (bd > kFar4 ? kMinMatch + 1 : kMinMatch);
               const uint32_t len4 = ok ? best - 3 : 0u;
-              // the odd position in front: the same match one byte longer if its byte fits too (and the candidate is
-              // not the strip's first byte: the copy would start before the strip)
-              const bool inh = ok && inh_here && pbyte == cbyte && bq + rb > kWindow;
-              const uint32_t len4o = inh ? (best < kCap ? best - 2 : kCap - 3) : 0u;
-              // one staging slot per EVEN position (an odd position that has a match has its successor's distance)
-              *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + rel)) = (uint16_t)bd;  // only read where the length says there is a match
-              // 4-bit lengths, SHIFTED by one position: byte j = {position 2j - 1, position 2j} of the round -- the pair
-              // this thread knows
-              smem[L_LEN4 + (rel >> 1)] = (uint8_t)(len4o | (len4 << 4));
+              if constexpr (STRIDE2) {
+                // the odd position in front: the same match one byte longer if its byte fits too (and the candidate is
+                // not the strip's first byte: the copy would start before the strip)
+                const bool inh = ok && inh_here && pbyte == cbyte && bq + rb > kWindow;
+                const uint32_t len4o = inh ? (best < kCap ? best - 2 : kCap - 3) : 0u;
+                // one staging slot per EVEN position (an odd position that has a match has its successor's distance)
+                *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + rel)) = (uint16_t)bd;  // only read where the length says there is a match
+                // 4-bit lengths, SHIFTED by one position: byte j = {position 2j - 1, position 2j} of the round -- the pair
+                // this thread knows
+                smem[L_LEN4 + (rel >> 1)] = (uint8_t)(len4o | (len4 << 4));
+              } else {
+                *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + 2u * rel)) = (uint16_t)bd;
+                // two lanes' 4-bit lengths -> one byte (the odd lane's value comes over the DPP network), stored by the
+                // even lanes.  All 64 lanes of the wave are active here, so the execution mask is switched and restored by
+                // hand: two scalar moves instead of the save / branch / restore a divergent `if` compiles to (smem sits at
+                // LDS address 0: it is the kernel's only __shared__ object)
+                uint32_t v = len4;
+                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
+                asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
+                             :: "v"(rel >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
+              }
             } else if (prep) {
               e0 = s_data[ado >> 2];
               e1 = s_data[(ado >> 2) + 1];
@@ -449,99 +483,26 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             if (prep) {
               // ---- the odd position 2 tp + 1 of step `it`: only inserted, by this thread ----
               ins_h = ho;
-              ins_v = __builtin_amdgcn_alignbit(code_it | (1022u - 2 * tp), oldo, 16);
+              ins_v = __builtin_amdgcn_alignbit(code_it | (STEP - 2u - 2 * tp), oldo, 16);
+              has_ins = true;
             }
           }
           if (it == nsteps) break;
           lds_barrier();  // every read of the table as it stands before step `it` precedes the step's insertions
-          {
+          if (has_ins) {
             // {code, old newest}: the upper half of code:bucket.  (Positions without kMinMatch bytes left insert like the
-            // rest, which nothing can observe.)  A lane whose predecessor in the wave has the same bucket need not insert:
-            // that one's position is two lower, its code larger (a run would otherwise serialise the wave's atomics)
+            // rest, which nothing can observe: every position after them in the strip is such a position too and takes no
+            // match, the next strip starts from an empty table.)  A lane whose predecessor in the wave has the same bucket
+            // need not insert: that one's position is lower, its code larger (a run would otherwise serialise the wave's
+            // atomics)
             const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)~ins_h, (int)ins_h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
             if (hp != ins_h) atomicMax(&s_table[ins_h], ins_v);
           }
           lds_barrier();  // insertions complete before the near reads
         }
-        // the last position of the last step that ran is odd and has no successor in its step: no match.  Its length
-        // lives in the low half of the byte behind the step's (nobody wrote it in this round; after eight steps it is the pad)
-        if (t == 0 && nsteps < kRound / kStep) smem[L_LEN4 + nsteps * (kStep / 2)] = 0;
-      } else {
-      for (uint32_t s = 0; s < nsteps; ++s) {
-        const uint32_t rel = s * kStep + t;
-        const uint32_t ad = kWindow + rel;                 // its LDS byte address
-        const uint32_t dw = ad >> 2, sh0 = ad & 3;
-        const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2];
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
-        const uint32_t h = (a0 * 2654435761u) >> (32 - kHashBits);
-        const uint32_t farv = s_table[h];
-        // the far candidates only need the (immutable) window: compare them ahead of the barriers
-        const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
-        const uint32_t c0 = entry_addr(f0, K - 1), c1 = entry_addr(f1, K - 1);
-        const bool ok0 = f0 >= kStep && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 >= kStep && ad - c1 <= kWindow;  // (a code below 1 << 10: empty)
-        // an empty or outdated entry decodes to some address that is not a candidate: it is still read (kept inside
-        // the LDS allocation by a 16-bit mask that leaves real candidates alone), its rank is dropped
-        static_assert(kWindow + kRound + kLook <= 0x10000 && 0x10000 + 16 <= K1_LDS, "candidate reads stay in LDS");
-        const uint32_t q0 = c0, q1 = c1;
-        // bytes a match may take from here: inside the round's valid part, the parse region and kCap (0 beyond qn)
-        const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
-        const uint32_t maxlen = (uint32_t)max(min(min((int)(qn - rel), (int)(rend - rel)), (int)kCap), 0);
-        // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
-        uint32_t l0, l1 = 0;
-        if constexpr (DEPTH2) rank8x2(s_data, a0, a1, q0, q1, maxlen, l0, l1);
-        else l0 = rank8(s_data, a0, a1, q0, maxlen);
-        const uint32_t m0 = ok0 ? l0 : 0u, m1 = ok1 ? l1 : 0u;
-        lds_barrier();  // every far read of this step precedes every insertion of this step
-        {
-          // {code, old newest}: the upper half of code:farv.  The specification lets positions without kMinMatch
-          // bytes left insert nothing; here they insert like the rest, which nothing can observe: every position
-          // after them in the strip is such a position too and takes no match (maxlen < kMinMatch), the next
-          // strip starts from an empty table
-          // a lane whose predecessor in the wave has the same bucket need not insert: that one's code is larger (a
-          // run of equal bytes would otherwise serialise sixty-four atomics on one address)
-          const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)~h, (int)h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-          if (hp != h) atomicMax(&s_table[h], __builtin_amdgcn_alignbit(code, farv, 16));
-          code += 1u << 10;
-        }
-        lds_barrier();  // insertions complete before the near reads
-        // longest wins; ties go to the smaller distance: near, then the newer far level
-        uint32_t best = 0, bq = ad;
-        if constexpr (NEAR) {
-          // the step's first position with this hash: this one's own entry at the latest, so the bucket is not empty
-          // (and it is of this very step: only its thread index has to be decoded)
-          uint32_t nc;  // = address of the step's thread 1023 - the entry's low ten bits, the former kept scalar
-          asm("v_sub_u32 %0, %1, %2" : "=v"(nc) : "s"(kWindow + s * kStep + 1023u), "v"((s_table[h] >> 16) & 1023u));
-          const bool okn = nc < ad;
-          const uint32_t qnr = okn ? nc : ad;
-          const uint32_t ln = rank8(s_data, a0, a1, qnr, maxlen);
-          best = okn ? ln : 0u;
-          bq = qnr;
-        }
-        if (m0 > best) { best = m0; bq = q0; }
-        if (m1 > best) { best = m1; bq = q1; }
-        const uint32_t bd = ad - bq;
-        if (best == kRank) {
-          // the winner's next eight bytes, only where its first kRank all matched: the kernel is bound by the LDS,
-          // and a gather's cost follows the number of lanes that take part in it
-          const uint32_t d3 = s_data[dw + 3], d4 = s_data[dw + 4];
-          const uint32_t a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0), a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
-          const uint32_t lx = kRank + cmp8<kRank / 4>(s_data, a2, a3, bq);  // maxlen <= kCap does the capping
-          best = lx < maxlen ? lx : maxlen;
-        }
-        // a 4-byte match farther than kFar4 costs more bits than four literals: drop it.  (maxlen <= n - p, so a
-        // position without kMinMatch bytes left cannot reach kMinMatch.)
-        const bool ok = best >= (bd > kFar4 ? kMinMatch + 1 : kMinMatch);
-        // (uniform base + a 32-bit byte offset: no 64-bit address arithmetic)
-        *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + 2u * rel)) = (uint16_t)bd;  // only read where the length says there is a match
-        // two lanes' 4-bit lengths -> one byte (the odd lane's value comes over the DPP network)
-        uint32_t v = ok ? best - 3 : 0u;
-        v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
-        // stored by the even lanes.  All 1024 threads are active here, so the execution mask is switched and
-        // restored by hand: two scalar moves instead of the save / branch / restore a divergent `if` compiles to
-        // (smem sits at LDS address 0: it is the kernel's only __shared__ object)
-        asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
-                     :: "v"(rel >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
-      }
+        // STRIDE2: the last position of the last step that ran is odd and has no successor in its step: no match.  Its length
+        // lives in the low half of the byte behind the step's (nobody wrote it in this round; after all steps it is the pad)
+        if (STRIDE2 && t == 0 && nsteps < kRound / STEP) smem[L_LEN4 + nsteps * (STEP / 2)] = 0;
       }
       __builtin_amdgcn_s_setprio(1);  // the parse: behind the other workgroup's match, ahead of its emit
       __syncthreads();  // (also: the staged distances are visible to the whole workgroup)

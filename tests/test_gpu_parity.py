@@ -97,9 +97,9 @@ def test_effort_fast_bit_exact_vs_oracle(compressor, starfleet):
             assert np.array_equal(got2, want2)
             _roundtrip(got2, data)
             assert got2.size >= got.size
-            # SFH_EFFORT_THOROUGH: every position is searched (the specification's stride2 = 0)
+            # SFH_EFFORT_THOROUGH: every position is searched, in steps of 512 (the specification's stride2 = 0, step = 512)
             got3 = np.frombuffer(compressor.compress(data, effort="thorough", block_bytes=bb), np.uint8)
-            want3 = O.compress(data, O.default_params(stride2=0, strip_bytes=bb))
+            want3 = O.compress(data, O.default_params(stride2=0, step=512, strip_bytes=bb))
             assert np.array_equal(got3, want3)
             _roundtrip(got3, data)
 
