@@ -124,7 +124,8 @@ constexpr uint32_t L_LEN4 = L_DATA + kWindow + kRound + kLook;  // 4 bits per po
 constexpr uint32_t L_TABLE = L_LEN4 + kRound / 2 + 16;       // u32[1<<kHashBits]
 constexpr uint32_t L_HIST = L_TABLE + (4u << kHashBits);     // u32[320]
 constexpr uint32_t L_WTOT = L_HIST + 4 * kHistStride;        // u32[16] tokens | matches << 16 of each wave's region
-constexpr uint32_t K1_LDS = L_WTOT + 4 * K1_WAVES;
+constexpr uint32_t L_DSYM = L_WTOT + 4 * K1_WAVES;            // u8[512] distance - 1 -> symbol: [d] below 256, [256 + (d >> 7)] from there on
+constexpr uint32_t K1_LDS = L_DSYM + 512;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
 static_assert(L_WTOT % 16 == 0 && L_TABLE % 16 == 0 && L_LEN4 % 16 == 0 && L_HIST % 16 == 0, "LDS alignment");
 static_assert(kCap - 3 <= 15, "capped len-3 fits four bits");
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) s_hist[idx] = (idx == 256) ? 1u : 0u;
     if (t < kLook / 4) s_data[(kWindow + kRound) / 4 + t] = load4(4 * t);
     if (t < 4) s_len4[kRound / 8 + t] = 0;  // pad read by the take pass
+    if (t < 512) smem[L_DSYM + t] = (uint8_t)dist_symbol_of(t < 256 ? t : (t - 256) << 7);
   }
   // this thread's eight bytes of round 0 (positions kLook + 8t ..)
   uint32_t pre_lo = load4(kLook + 8 * t), pre_hi = load4(kLook + 8 * t + 4);
@@ -365,6 +367,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t grp = wave >> 3;                   // (uniform) this wave's half
         const uint32_t tp = t & 511u;                     // index in the half
         const uint32_t ps = STRIDE2 ? 2 * tp : tp;        // the thread's searched position within a step
+        const uint32_t to_rend = kRegion - (ps & (kRegion - 1));  // ... and how far its parse region's end is
+        static_assert(STEP % kRegion == 0, "steps are whole regions");
         // an odd position takes over its successor's match only inside the step and the parse region
         [[maybe_unused]] const bool inh_here = tp != 0 && (tp & (kRegion / 2 - 1)) != 0;
         uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;  // first part -> second part
@@ -389,9 +393,9 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               // rank is dropped
               static_assert(kWindow + kRound + kLook <= 0x10000 && 0x10000 + 16 <= K1_LDS, "candidate reads stay in LDS");
               const bool ok0 = f0 >= STEP && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 >= STEP && ad - c1 <= kWindow;
-              // bytes a match may take from here: inside the round's valid part, the parse region and kCap (0 beyond qn)
-              const uint32_t rend = (rel & ~(kRegion - 1)) + kRegion;
-              const uint32_t maxlen = (uint32_t)max(min(min((int)(qn - rel), (int)(rend - rel)), (int)kCap), 0);
+              // bytes a match may take from here: inside the round's valid part, the parse region and kCap (0 beyond qn).
+              // (A step is a whole number of regions: the distance to the region's end does not depend on the step.)
+              const uint32_t maxlen = (uint32_t)max(min(min((int)(qn - rel), (int)to_rend), (int)kCap), 0);
               // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
               uint32_t l0, l1 = 0;
               if constexpr (DEPTH2) rank8x2(s_data, a0, a1, c0, c1, maxlen, l0, l1);
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           }
           if (it == nsteps) break;
           lds_barrier();  // every read of the table as it stands before step `it` precedes the step's insertions
-          if (has_ins) {
+          if (STRIDE2 || has_ins) {  // (STRIDE2: every wave inserts, its even or its odd positions)
             // {code, old newest}: the upper half of code:bucket.  (Positions without kMinMatch bytes left insert like the
             // rest, which nothing can observe: every position after them in the strip is such a position too and takes no
             // match, the next strip starts from an empty table.)  A lane whose predecessor in the wave has the same bucket
@@ -817,8 +821,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             put_item(at, (kItemMatch | l3) | (k == 0 ? flag : 0u));
             put_item(at + 2, d1);
             atomicAdd(&s_hist[kHistLen + l3], 1u);
-            uint32_t eb, ev;
-            atomicAdd(&s_hist[kHistD + dist_symbol(d1, eb, ev)], 1u);
+            atomicAdd(&s_hist[kHistD + smem[L_DSYM + (d1 < 256 ? d1 : 256 + (d1 >> 7))]], 1u);
           }
         }
       }
@@ -1461,7 +1464,8 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
     uint4* z = reinterpret_cast<uint4*>(s_stage);
     for (uint32_t k = t; k < (nwords + 2 + 3) / 4 && k < K4_STAGE_WORDS / 4; k += K4_THREADS) z[k] = make_uint4(0, 0, 0, 0);
   }
-  if (t < 288) s_lcode[t] = pre_code;
+  // literals: code | bits << 24 like a length entry (one select in the loop); 256..287 stay code | bits << 16
+  if (t < 288) s_lcode[t] = t < 256 ? (pre_code & 0xFFFFu) | ((pre_code >> 16) << 24) : pre_code;
   else if (t < 320) s_dcode[t - 288] = pre_code | (dist_extra_of_sym(t - 288) << 24);  // code | length << 16 | extra bits << 24
   if (t < kSubRegions) {
     s_rtok[t] = pre_rtok;
@@ -1531,8 +1535,9 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
       const uint32_t dc = dcv[k];                       // code | length << 16 | extra bits << 24
       const uint32_t dl = (dc >> 16) & 0xFFu, de = dc >> 24;
       const uint32_t vd = (dc & 0xFFFFu) | (__builtin_amdgcn_ubfe(cur, 0, de) << dl);
-      const uint32_t v = dist ? vd : head ? (lev[k] & 0xFFFFFFu) : (lcv[k] & 0xFFFFu);
-      const uint32_t n = dist ? dl + de : head ? lev[k] >> 24 : lcv[k] >> 16;
+      const uint32_t w = head ? lev[k] : lcv[k];        // value | bits << 24
+      const uint32_t v = dist ? vd : (w & 0xFFFFFFu);
+      const uint32_t n = dist ? dl + de : w >> 24;
       val[k] = live ? v : 0u;
       nb[k] = live ? n : 0u;
       starts |= (live && !dist && (cur & kItemRegion)) ? 1u << k : 0u;
