@@ -76,7 +76,8 @@ typedef struct sfh_options {
                             bucket plus the step-local candidate; SFH_EFFORT_FAST only the newer level (about 2 % more
                             output); SFH_EFFORT_FASTEST drops the step-local candidate as well (about 4 % more than the
                             default on text, more on very repetitive data); SFH_EFFORT_THOROUGH searches every
-                            position (about 0.8 % less output than the default for a fifth more time) */
+                            position, in insertion steps of 512 (about 1.3 % less output than the default on text, 2.5 %
+                            on mixed data, for a quarter more time) */
   uint32_t reserved;     /* must be 0 */
 } sfh_options;
 
