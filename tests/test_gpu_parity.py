@@ -520,9 +520,12 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
         lazy = [3, 0, 1, 2, 3][it % 5]
         fast = it % 7 != 0
         bb = [0, 32768, 65536, 131072][it % 3 if it % 11 else 3]
-        got = np.frombuffer(compressor.compress(data, strategy=strategy, lazy=lazy, stored_fast_path=fast, block_bytes=bb), np.uint8)
-        want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=int(fast), strip_bytes=bb))
-        assert np.array_equal(got, want), (it, total, strategy, lazy, fast, bb, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
+        # every effort: default (even positions searched), thorough (all, steps of 512), fast (one level), fastest (no near)
+        effort, ekw = [("default", {}), ("thorough", dict(stride2=0, step=512)), ("default", {}), ("fast", dict(depth=1)),
+                       ("fastest", dict(depth=1, use_near=0))][it % 5 if it % 13 else 1]
+        got = np.frombuffer(compressor.compress(data, strategy=strategy, lazy=lazy, stored_fast_path=fast, block_bytes=bb, effort=effort), np.uint8)
+        want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=int(fast), strip_bytes=bb, **ekw))
+        assert np.array_equal(got, want), (it, total, strategy, lazy, fast, bb, effort, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
         if it % 10 == 0:
             _roundtrip(got, data)
             idx, sub = compressor.last_index(), compressor.last_subindex()
