@@ -219,3 +219,30 @@ def test_runs_are_coded_at_distance_one():
                           np.full(40, 7, np.uint8), np.arange(50, dtype=np.uint8)])
     sm = O.compress(mix, O.default_params())
     assert zlib.decompress(sm.tobytes(), -15) == mix.tobytes()
+
+
+def test_stride2_searches_even_positions_and_inherits_from_the_successor(starfleet):
+    """stride2 (every effort but thorough): only even strip positions are searched; an odd position has a match only as its
+    successor's, one byte longer at the same distance, with its own byte matching too -- inside the step and the region."""
+    data = np.frombuffer(starfleet, np.uint8)[:32768].copy()
+    p2 = O.default_params()
+    assert p2.stride2 == 1 and p2.step == 1024 and p2.hash_bits == 13
+    ln, ds = O.match_chunk(data, p2)
+    full_ln, full_ds = O.match_chunk(data, O.default_params(stride2=0))
+    # even positions: exactly what the full search finds there
+    assert np.array_equal(ln[0::2], full_ln[0::2]) and np.array_equal(ds[0::2][ln[0::2] > 0], full_ds[0::2][full_ln[0::2] > 0])
+    odd = np.flatnonzero(ln[1::2] > 0) * 2 + 1
+    assert odd.size > 100
+    for i in odd[:2000]:
+        i = int(i)
+        assert ln[i + 1] > 0 and ds[i] == ds[i + 1]                      # the successor's match ...
+        assert ln[i] == min(int(ln[i + 1]) + 1, p2.cap)                  # ... one byte longer, capped
+        assert data[i] == data[i - int(ds[i])] and int(ds[i]) <= i       # its own byte fits, inside the strip
+        assert (i + 1) % p2.step != 0 and (i + 1) % p2.region_bytes != 0  # same step, same parse region
+    # every effort round-trips; thorough (all positions, steps of 512) is never larger on this text
+    sizes = {}
+    for name, kw in (("thorough", dict(stride2=0, step=512)), ("default", {}), ("fast", dict(depth=1)), ("fastest", dict(depth=1, use_near=0))):
+        s = O.compress(np.frombuffer(starfleet, np.uint8), O.default_params(**kw))
+        _check(s, np.frombuffer(starfleet, np.uint8))
+        sizes[name] = s.size
+    assert sizes["thorough"] <= sizes["default"] <= sizes["fast"] <= sizes["fastest"]
