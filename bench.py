@@ -151,6 +151,27 @@ def traffic_from_profile(kernel):
         return None
 
 
+def issue_from_profile(kernel, kernel_ms, n):
+    """What bounds the kernels is the vector ALU's issue rate, not HBM: vector instructions per launch
+    from the last committed PMC profile (SQ_INSTS_VALU of the same 1 GiB workload -- NOT counted in this run) over this run's
+    kernel time, as cycles per wave-instruction per SIMD; profiles/r03_valu_ops.log has what the instructions cost."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        for name, v in d.items():
+            if kernel in name and "SQ_INSTS_VALU" in v:
+                insts = v["SQ_INSTS_VALU"] / max(v.get("pmc_dispatches", 1), 1) * (n / 2**30)
+                simds, ghz = 1024, 2.4
+                return {"bound": "valu-issue", "valu_wave_instructions_per_launch": int(insts), "simds": simds, "clock_ghz": ghz,
+                        "cycles_per_instruction_per_simd": round(kernel_ms * 1e-3 * ghz * 1e9 / (insts / simds), 2),
+                        "instruction_cost_cycles": "2.3-2.9 (and/or/xor/add/sub/lshr/mov/bitop3), 4.1-4.5 (all other integer VALU) at 8 waves per SIMD: tools/micro/valu_ops.hip",
+                        "source": "profiles/r03_pmc_summary.json (instruction count; not collected live) / this run's kernel time"}
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
 def secondary_workload(comp, workload, n, dev, block_bytes, steps=3, effort="default", data=None, wl=None):
     """MiB/s + ratio of another BASELINE workload (configs[3] / [4] shapes), or of the main one at another effort."""
     import torch
@@ -425,7 +446,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_from_profile": traffic_from_profile(dom),
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
-                "read_frac": round(n / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                "read_frac": round(n / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "issue": issue_from_profile(dom, stage_ms[dom], n) if args.effort == "default" and args.workload == "text" else None}
     try:  # what hipDeviceProp_t implies; `peak` above stays the guide's figure
         dp = _capi.device_props(local_rank)
         roofline["device"] = {"name": dp["name"], "arch": dp["arch"], "compute_units": dp["compute_units"],
