@@ -127,11 +127,12 @@ def test_largest_and_odd_strips(compressor):
     """block_bytes at its maximum (16 MiB: the table's step codes are aged a thousand times, the decoder walks 512
     segments per strip) and at a non-power-of-two multiple of 32 KiB: bit-exact, and decodable on the GPU."""
     data = np.concatenate([synth.gen_text(20 << 20, seed=71), synth.gen_mixed(13 << 20, seed=72, stripe=1 << 18)[: (13 << 20) - 77]])
-    for bb in (16 << 20, 3 * CHUNK):
-        got = np.frombuffer(compressor.compress(data, block_bytes=bb), np.uint8)
-        assert np.array_equal(got, O.compress(data, O.default_params(strip_bytes=bb))), bb
+    for bb, effort, ekw in ((16 << 20, "default", {}), (3 * CHUNK, "default", {}), (16 << 20, "thorough", dict(stride2=0, step=512)),
+                            (5 * CHUNK, "fastest", dict(depth=1, use_near=0))):
+        got = np.frombuffer(compressor.compress(data, block_bytes=bb, effort=effort), np.uint8)
+        assert np.array_equal(got, O.compress(data, O.default_params(strip_bytes=bb, **ekw))), (bb, effort)
         back, st = compressor.decompress(got, compressor.last_index(), data.size, subindex=compressor.last_subindex(), block_bytes=bb)
-        assert st == 0 and back == data.tobytes(), bb
+        assert st == 0 and back == data.tobytes(), (bb, effort)
     with pytest.raises(Exception):
         compressor.compress(data[:CHUNK], block_bytes=(16 << 20) + CHUNK)  # beyond the maximum
 
