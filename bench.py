@@ -247,7 +247,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=1 << 30, help="input bytes per GPU")
     ap.add_argument("--workload", default="text", choices=["text", "random", "mixed", "runs"])
-    ap.add_argument("--effort", default="default", choices=["default", "fast", "fastest", "thorough"], help="sfh_options.effort of the timed steps")
+    ap.add_argument("--effort", default="default", choices=["default", "fast", "fastest", "thorough", "max"], help="sfh_options.effort of the timed steps")
     ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default, 256 KiB at this size)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -515,6 +515,9 @@ def main():
         # SFH_EFFORT_THOROUGH: every position searched, not every other one (the timed steps' effort is in config.effort)
         others["effort_thorough"] = secondary_workload(comp, args.workload, n, dev, bb, effort="thorough", data=data, wl=wl)
         others["mixed_effort_thorough"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort="thorough")
+        # SFH_EFFORT_MAX: thorough with a second hash table keyed by seven bytes
+        others["effort_max"] = secondary_workload(comp, args.workload, n, dev, bb, effort="max", data=data, wl=wl)
+        others["mixed_effort_max"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort="max")
 
     # ---- CPU baseline: oracle restatement of the reference decompress(), 1 thread ----
     cpu = None

@@ -38,6 +38,7 @@ struct compress_options {
   bool fast{false};              // sfh_options.effort = SFH_EFFORT_FAST: fewer candidates per position, about 3 % more output
   bool fastest{false};           // SFH_EFFORT_FASTEST: the newer history level only and no step-local candidate (wins over `fast`)
   bool thorough{false};          // SFH_EFFORT_THOROUGH: every position is searched, not only the even ones (wins over both)
+  bool max{false};               // SFH_EFFORT_MAX: that, with a second hash table keyed by seven bytes (wins over all)
   std::uint32_t block_bytes{0};  // bytes coded independently of what precedes them: a multiple of 32768, 0 = default
                                  // (sfh_options.block_bytes); larger compresses better, 32768 = independent DEFLATE blocks
 };
@@ -75,7 +76,7 @@ inline auto to_c(const compress_options& o) -> sfh_options {
   c.no_stored_fast_path = o.stored_fast_path ? 0U : 1U;
   c.container = static_cast<std::uint32_t>(o.container);
   c.block_bytes = o.block_bytes;
-  c.effort = o.thorough ? SFH_EFFORT_THOROUGH : o.fastest ? SFH_EFFORT_FASTEST : o.fast ? SFH_EFFORT_FAST : SFH_EFFORT_DEFAULT;
+  c.effort = o.max ? SFH_EFFORT_MAX : o.thorough ? SFH_EFFORT_THOROUGH : o.fastest ? SFH_EFFORT_FASTEST : o.fast ? SFH_EFFORT_FAST : SFH_EFFORT_DEFAULT;
   return c;
 }
 }  // namespace detail

@@ -367,10 +367,11 @@ static uint32_t match_len(const uint8_t* d, uint32_t i, uint32_t c, uint32_t max
 
 #define NONE 0xFFFFFFFFu
 
+/* hash of long_hash_bytes (5..8) bytes: two 32-bit multiplicative hashes, of the first four bytes and of the rest, xored */
 static inline uint32_t hash_long(const uint8_t* q, const sfo_params* p) {
-  uint64_t v = 0;
-  for (uint32_t k = 0; k < p->long_hash_bytes; k++) v |= (uint64_t)q[k] << (8 * k);
-  return (uint32_t)((v * 0x9E3779B185EBCA87ull) >> (64 - p->hash_bits));
+  uint32_t lo = load32(q), hi = 0;
+  for (uint32_t k = 4; k < p->long_hash_bytes; k++) hi |= (uint32_t)q[k] << (8 * (k - 4));
+  return ((lo * 2654435761u) ^ (hi * 0x85EBCA6Bu)) >> (32 - p->hash_bits);
 }
 
 /* step-table entry <-> position: ((step+1) << 12) | (4095 - t), t = pos - step*W */

@@ -106,6 +106,7 @@ struct Options {
   uint32_t depth2;       // 1: both history levels of a hash bucket are tried, 0: the newer one only
   uint32_t near;         // 1: the step-local candidate is tried as well (always with depth2)
   uint32_t stride2;      // 1: only even positions are searched, odd ones take over their successor's match (0: thorough)
+  uint32_t long_table;   // 1: two tables of 4096 buckets, keyed by four and by seven bytes (with stride2 = 0: SFH_EFFORT_MAX)
 };
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,

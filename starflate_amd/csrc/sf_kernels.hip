@@ -109,6 +109,7 @@ constexpr uint32_t kRSubs = kRound / kSubBytes;              // sub-index region
 constexpr uint32_t kRoundsPerChunk = kChunk / kRound;
 constexpr uint32_t kLook = 32;                               // bytes staged beyond the round (compare + alignment)
 constexpr uint32_t kRank = 8;                                // bytes that rank a position's candidates
+constexpr uint32_t kLongBytes = 7;                           // bytes the second table (SFH_EFFORT_MAX) is keyed by
 constexpr uint32_t kSkipSpan = 8192;                         // stored fast path: decided after this many positions of a chunk
 static_assert(kRound / 8 == K1_THREADS && kRegion == 8 * 64, "parse: eight positions per thread, one region per wave");
 static_assert(kSubBytes % kRegion == 0 && kRound % kSubBytes == 0, "sub-index regions are whole parse regions");
@@ -216,7 +217,9 @@ __device__ __forceinline__ uint32_t entry_addr(uint32_t v, uint32_t k1) {
 // STRIDE2: only the even positions are searched; an odd one takes over its successor's match when its own byte fits
 // in front of it (efforts 0..2; SFH_EFFORT_THOROUGH searches every position).  The search is then pipelined over the
 // two halves of the workgroup, see the match phase.
-template <bool STAMPS, bool DEPTH2, bool NEAR, bool STRIDE2>
+// LONG (SFH_EFFORT_MAX): the 32 KiB of table are TWO tables of 4096 buckets, one keyed by four bytes as ever, one by seven
+// (kLongBytes): a position has four far candidates; of equally ranked ones the nearest wins.
+template <bool STAMPS, bool DEPTH2, bool NEAR, bool STRIDE2, bool LONG>
 __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
     const uint8_t* __restrict__ src, uint64_t n_total, uint32_t strip_bytes, uint16_t* __restrict__ items,
     uint32_t* __restrict__ nitems_out, uint32_t* __restrict__ ntok_out, uint32_t* __restrict__ hist_out,
@@ -233,6 +236,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
   if constexpr (STAMPS) st_t = __builtin_amdgcn_s_memtime();
   // positions per insertion step: 1024 of which the even ones are searched, or 512 all of which are (thorough)
   constexpr uint32_t SH = STRIDE2 ? 10u : 9u, STEP = 1u << SH;
+  constexpr uint32_t HB = LONG ? kHashBits - 1 : kHashBits;  // bucket index bits of a table
+  static_assert(!LONG || (DEPTH2 && !STRIDE2), "the second table comes with the highest effort");
   // step codes in a 16-bit table half: ((step - epoch) + 1) << SH | (STEP - 1 - index in the step); the epoch advances by
   // kEpS steps whenever a round would reach kEpMax steps past it, entries older than that vanish
   constexpr uint32_t kEpS = (kEpochSteps << 10) >> SH, kEpMax = (kEpochMax << 10) >> SH;
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
   uint8_t* s_bytes = smem + L_DATA;
   uint32_t* s_len4 = reinterpret_cast<uint32_t*>(smem + L_LEN4);
   uint32_t* s_table = reinterpret_cast<uint32_t*>(smem + L_TABLE);
+  [[maybe_unused]] uint32_t* s_table2 = s_table + (1u << HB);  // LONG: the seven-byte table behind the four-byte one
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + L_HIST);
   uint32_t* s_wtot = reinterpret_cast<uint32_t*>(smem + L_WTOT);
 
@@ -371,9 +377,11 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         static_assert(STEP % kRegion == 0, "steps are whole regions");
         // an odd position takes over its successor's match only inside the step and the parse region
         [[maybe_unused]] const bool inh_here = tp != 0 && (tp & (kRegion / 2 - 1)) != 0;
-        uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;  // first part -> second part
+        // first part -> second part.  (LONG: f_m0.. f_q1 carry the four far candidates as KEYS rank << 16 | 0xFFFF - distance)
+        uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;
         for (uint32_t it = 0; it <= nsteps; ++it) {
           uint32_t ins_h = 0, ins_v = 0;
+          [[maybe_unused]] uint32_t ins2_h = 0, ins2_v = 0;  // LONG: the same for the seven-byte table
           bool has_ins = false;                           // (uniform) this wave inserts in this interval
           const uint32_t code_it = (rb / STEP + it - ebase + 1) << SH;  // (uniform) step code of step `it`
           if ((it & 1) == grp) {
@@ -384,8 +392,15 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               const uint32_t dw = ad >> 2, sh0 = ad & 3;
               const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2];
               const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
-              const uint32_t h = (a0 * 2654435761u) >> (32 - kHashBits);
+              const uint32_t hmul = a0 * 2654435761u;
+              const uint32_t h = hmul >> (32 - HB);
               const uint32_t farv = s_table[h];
+              [[maybe_unused]] uint32_t h2 = 0, farv2 = 0;
+              if constexpr (LONG) {
+                // bytes 4..6 join the hash (the specification's long hash: two multiplicative hashes xored)
+                h2 = (hmul ^ ((a1 & 0xFFFFFFu) * 0x85EBCA6Bu)) >> (32 - HB);
+                farv2 = s_table2[h2];
+              }
               const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
               const uint32_t c0 = entry_addr<SH>(f0, K - 1), c1 = entry_addr<SH>(f1, K - 1);
               // (a code below 1 << SH: empty.)  An empty or outdated entry decodes to some address that is not a candidate:
@@ -400,9 +415,24 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               uint32_t l0, l1 = 0;
               if constexpr (DEPTH2) rank8x2(s_data, a0, a1, c0, c1, maxlen, l0, l1);
               else l0 = rank8(s_data, a0, a1, c0, maxlen);
-              f_a0 = a0; f_a1 = a1; f_h = h; f_q0 = c0; f_q1 = c1; f_maxlen = maxlen;
-              f_m0 = ok0 ? l0 : 0u;
-              f_m1 = ok1 ? l1 : 0u;
+              f_a0 = a0; f_a1 = a1; f_h = h; f_maxlen = maxlen;
+              if constexpr (LONG) {
+                const uint32_t g0 = farv2 >> 16, g1 = farv2 & 0xFFFFu;
+                const uint32_t c2 = entry_addr<SH>(g0, K - 1), c3 = entry_addr<SH>(g1, K - 1);
+                // a position without kLongBytes bytes left in the strip reads nothing from the seven-byte table
+                const bool lng = rb + rel + kLongBytes <= n;
+                const bool ok2 = lng && g0 >= STEP && ad - c2 <= kWindow, ok3 = lng && g1 >= STEP && ad - c3 <= kWindow;
+                uint32_t l2, l3;
+                rank8x2(s_data, a0, a1, c2, c3, maxlen, l2, l3);
+                auto key = [&](bool ok, uint32_t l, uint32_t c) { return ok ? (l << 16) | (0xFFFFu - (ad - c)) : 0u; };
+                f_m0 = key(ok0, l0, c0); f_m1 = key(ok1, l1, c1); f_q0 = key(ok2, l2, c2); f_q1 = key(ok3, l3, c3);
+                ins2_h = h2;
+                ins2_v = __builtin_amdgcn_alignbit(code_it | (STEP - 1u - ps), farv2, 16);
+              } else {
+                f_q0 = c0; f_q1 = c1;
+                f_m0 = ok0 ? l0 : 0u;
+                f_m1 = ok1 ? l1 : 0u;
+              }
               ins_h = h;
               ins_v = __builtin_amdgcn_alignbit(code_it | (STEP - 1u - ps), farv, 16);
               has_ins = true;
@@ -442,8 +472,16 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 best = okn ? ln : 0u;
                 bq = qnr;
               }
-              if (f_m0 > best) { best = f_m0; bq = f_q0; }
-              if (f_m1 > best) { best = f_m1; bq = f_q1; }
+              if constexpr (LONG) {
+                // the largest key: the longest rank, the nearest of those
+                const uint32_t kn = best ? (best << 16) | (0xFFFFu - (ad - bq)) : 0u;
+                const uint32_t kb = max(max(max(f_m0, f_m1), max(f_q0, f_q1)), kn);
+                best = kb >> 16;
+                bq = best ? ad - (0xFFFFu - (kb & 0xFFFFu)) : ad;
+              } else {
+                if (f_m0 > best) { best = f_m0; bq = f_q0; }
+                if (f_m1 > best) { best = f_m1; bq = f_q1; }
+              }
               const uint32_t bd = ad - bq;
               const uint32_t cbyte = STRIDE2 ? s_bytes[(bq - 1) & 0xFFFFu] : 0u;  // the byte in front of the winner (any bq reads inside LDS)
               if (best == kRank) {
@@ -501,6 +539,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             // atomics)
             const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)~ins_h, (int)ins_h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
             if (hp != ins_h) atomicMax(&s_table[ins_h], ins_v);
+            if constexpr (LONG) {
+              const uint32_t hp2 = (uint32_t)__builtin_amdgcn_update_dpp((int)~ins2_h, (int)ins2_h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+              if (hp2 != ins2_h) atomicMax(&s_table2[ins2_h], ins2_v);
+            }
           }
           lds_barrier();  // insertions complete before the near reads
         }
@@ -1630,18 +1672,20 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
     hipLaunchKernelGGL(kernel, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items, ws.nitems, ws.ntok,
                        ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps);
   };
-  // effort: {every position, both levels + near} {even positions: both levels + near, newer level + near, newer level only}
-  const uint32_t kind = !opt.stride2 ? 3u : opt.depth2 ? 0u : (opt.near ? 1u : 2u);
+  // effort: {even positions: both levels + near, newer level + near, newer level only} {every position: one table, two tables}
+  const uint32_t kind = !opt.stride2 ? (opt.long_table ? 4u : 3u) : opt.depth2 ? 0u : (opt.near ? 1u : 2u);
   if (ws.stamps) {
-    if (kind == 0) launch(k_lz77<true, true, true, true>, ws.stamps);
-    else if (kind == 1) launch(k_lz77<true, false, true, true>, ws.stamps);
-    else if (kind == 2) launch(k_lz77<true, false, false, true>, ws.stamps);
-    else launch(k_lz77<true, true, true, false>, ws.stamps);
+    if (kind == 0) launch(k_lz77<true, true, true, true, false>, ws.stamps);
+    else if (kind == 1) launch(k_lz77<true, false, true, true, false>, ws.stamps);
+    else if (kind == 2) launch(k_lz77<true, false, false, true, false>, ws.stamps);
+    else if (kind == 3) launch(k_lz77<true, true, true, false, false>, ws.stamps);
+    else launch(k_lz77<true, true, true, false, true>, ws.stamps);
   } else {
-    if (kind == 0) launch(k_lz77<false, true, true, true>, (uint64_t*)nullptr);
-    else if (kind == 1) launch(k_lz77<false, false, true, true>, (uint64_t*)nullptr);
-    else if (kind == 2) launch(k_lz77<false, false, false, true>, (uint64_t*)nullptr);
-    else launch(k_lz77<false, true, true, false>, (uint64_t*)nullptr);
+    if (kind == 0) launch(k_lz77<false, true, true, true, false>, (uint64_t*)nullptr);
+    else if (kind == 1) launch(k_lz77<false, false, true, true, false>, (uint64_t*)nullptr);
+    else if (kind == 2) launch(k_lz77<false, false, false, true, false>, (uint64_t*)nullptr);
+    else if (kind == 3) launch(k_lz77<false, true, true, false, false>, (uint64_t*)nullptr);
+    else launch(k_lz77<false, true, true, false, true>, (uint64_t*)nullptr);
   }
   return hipGetLastError();
 }

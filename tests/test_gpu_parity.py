@@ -102,6 +102,11 @@ def test_effort_fast_bit_exact_vs_oracle(compressor, starfleet):
             want3 = O.compress(data, O.default_params(stride2=0, step=512, strip_bytes=bb))
             assert np.array_equal(got3, want3)
             _roundtrip(got3, data)
+            # SFH_EFFORT_MAX: that, with two tables of 4096 buckets keyed by four and by seven bytes
+            got4 = np.frombuffer(compressor.compress(data, effort="max", block_bytes=bb), np.uint8)
+            want4 = O.compress(data, O.default_params(stride2=0, step=512, hash_bits=12, long_hash_bytes=7, strip_bytes=bb))
+            assert np.array_equal(got4, want4)
+            _roundtrip(got4, data)
 
 
 def test_batches_give_the_stream_of_one_launch(monkeypatch):
@@ -127,7 +132,7 @@ def test_largest_and_odd_strips(compressor):
     """block_bytes at its maximum (16 MiB: the table's step codes are aged a thousand times, the decoder walks 512
     segments per strip) and at a non-power-of-two multiple of 32 KiB: bit-exact, and decodable on the GPU."""
     data = np.concatenate([synth.gen_text(20 << 20, seed=71), synth.gen_mixed(13 << 20, seed=72, stripe=1 << 18)[: (13 << 20) - 77]])
-    for bb, effort, ekw in ((16 << 20, "default", {}), (3 * CHUNK, "default", {}), (16 << 20, "thorough", dict(stride2=0, step=512)),
+    for bb, effort, ekw in ((16 << 20, "default", {}), (3 * CHUNK, "default", {}), (16 << 20, "thorough", dict(stride2=0, step=512)), (16 << 20, "max", dict(stride2=0, step=512, hash_bits=12, long_hash_bytes=7)),
                             (5 * CHUNK, "fastest", dict(depth=1, use_near=0))):
         got = np.frombuffer(compressor.compress(data, block_bytes=bb, effort=effort), np.uint8)
         assert np.array_equal(got, O.compress(data, O.default_params(strip_bytes=bb, **ekw))), (bb, effort)
@@ -523,7 +528,7 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
         bb = [0, 32768, 65536, 131072][it % 3 if it % 11 else 3]
         # every effort: default (even positions searched), thorough (all, steps of 512), fast (one level), fastest (no near)
         effort, ekw = [("default", {}), ("thorough", dict(stride2=0, step=512)), ("default", {}), ("fast", dict(depth=1)),
-                       ("fastest", dict(depth=1, use_near=0))][it % 5 if it % 13 else 1]
+                       ("fastest", dict(depth=1, use_near=0)), ("max", dict(stride2=0, step=512, hash_bits=12, long_hash_bytes=7))][it % 6 if it % 13 else 5]
         got = np.frombuffer(compressor.compress(data, strategy=strategy, lazy=lazy, stored_fast_path=fast, block_bytes=bb, effort=effort), np.uint8)
         want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=int(fast), strip_bytes=bb, **ekw))
         assert np.array_equal(got, want), (it, total, strategy, lazy, fast, bb, effort, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])

@@ -241,8 +241,8 @@ def test_stride2_searches_even_positions_and_inherits_from_the_successor(starfle
         assert (i + 1) % p2.step != 0 and (i + 1) % p2.region_bytes != 0  # same step, same parse region
     # every effort round-trips; thorough (all positions, steps of 512) is never larger on this text
     sizes = {}
-    for name, kw in (("thorough", dict(stride2=0, step=512)), ("default", {}), ("fast", dict(depth=1)), ("fastest", dict(depth=1, use_near=0))):
+    for name, kw in (("max", dict(stride2=0, step=512, hash_bits=12, long_hash_bytes=7)), ("thorough", dict(stride2=0, step=512)), ("default", {}), ("fast", dict(depth=1)), ("fastest", dict(depth=1, use_near=0))):
         s = O.compress(np.frombuffer(starfleet, np.uint8), O.default_params(**kw))
         _check(s, np.frombuffer(starfleet, np.uint8))
         sizes[name] = s.size
-    assert sizes["thorough"] <= sizes["default"] <= sizes["fast"] <= sizes["fastest"]
+    assert sizes["max"] <= sizes["thorough"] <= sizes["default"] <= sizes["fast"] <= sizes["fastest"]
