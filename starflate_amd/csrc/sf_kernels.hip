@@ -199,14 +199,14 @@ __device__ __forceinline__ void lds_barrier() {
 // keeps the same winner (the first position of the latest step)
 static_assert(kStep == 1024, "entry encoding");
 __device__ __forceinline__ uint32_t entry_pos(uint32_t v) { return v - 1u - 2u * (v & 1023u); }
-// entry_pos(v) + k1 + 1 in three instructions (the multiply-add is spelled out: left to itself the compiler
-// expands the expression into twice as many shifts and masks)
+// entry_pos(v) + 1 in two instructions (the multiply-add is spelled out: left to itself the compiler expands the
+// expression into twice as many shifts and masks); 0 for an empty half
 template <uint32_t SH>
-__device__ __forceinline__ uint32_t entry_addr(uint32_t v, uint32_t k1) {
+__device__ __forceinline__ uint32_t entry_rel(uint32_t v) {
   const uint32_t lo = v & ((1u << SH) - 1u);
   uint32_t c;
   asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(c) : "v"(lo), "v"(v));
-  return c + k1;
+  return c;
 }
 
 // STAMPS: diagnostic build only (SFH_K1_STAMPS=1), s_memtime at phase boundaries into `stamps`
@@ -285,7 +285,13 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
   stamp(0);
 
   const uint32_t nrounds = (n + kRound - 1) / kRound;
-  uint32_t ebase = 0;                    // first step of the table's epoch (uniform)
+  // First step of the table's epoch (uniform, mod 2^32).  It starts a window's worth of steps BEFORE the strip and
+  // stays at least that far behind the step in hand (ageing moves it by kEpS when it is kEpMax behind): a position is
+  // never less than kWindow past the epoch's start, so "within the window" is one compare of the coded
+  // position with a threshold, and an empty half (code 0 = the last position of the step before the epoch) fails it
+  // like any entry that is too old
+  static_assert(kEpMax - kEpS >= kWindow / STEP, "the epoch stays a window behind");
+  uint32_t ebase = 0u - kWindow / STEP;
   uint32_t tot_tok = 0, tot_items = 0;   // of the chunk in flight (uniform)
   bool skip = false;                     // stored fast path (uniform): set after kSkipSpan positions of a chunk
 
@@ -377,6 +383,17 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         static_assert(STEP % kRegion == 0, "steps are whole regions");
         // an odd position takes over its successor's match only inside the step and the parse region
         [[maybe_unused]] const bool inh_here = tp != 0 && (tp & (kRegion / 2 - 1)) != 0;
+        [[maybe_unused]] const uint32_t first_ad = kWindow - rb;  // (uniform) LDS address of the strip's first byte (no address at all after the first rounds)
+        // Addresses inside a step are a uniform part (the step's offset in the round) plus what never changes for the
+        // thread; constants ride in the LDS instructions' offset fields.  psw: the dword the position starts in (the
+        // odd position behind it starts in the same one), sh0: where in it; cv: the low bits of the position's step code
+        const uint32_t sh0 = ps & 3u, cv = STEP - 1u - ps;
+        const uint32_t pswK = kWindow + (ps & ~3u);   // LDS address of that dword in step 0
+        const uint32_t psK1 = kWindow - 1u + ps;      // LDS address of the byte before the position in step 0
+        const uint32_t mlen0 = to_rend < kCap ? to_rend : kCap;  // bytes a match may take from the position, the input's end aside
+        auto lds32 = [&](uint32_t at, uint32_t off) { return *reinterpret_cast<const uint32_t*>(smem + at + off); };
+        // (uniform) the round's staging slots, addressed by psK1 + the step's offset
+        uint8_t* const gst = reinterpret_cast<uint8_t*>(gi) + stage_off - (STRIDE2 ? 1u : 2u) * (kWindow - 1u);
         // first part -> second part.  (LONG: f_m0.. f_q1 carry the four far candidates as KEYS rank << 16 | 0xFFFF - distance)
         uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;
         for (uint32_t it = 0; it <= nsteps; ++it) {
@@ -384,13 +401,18 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           [[maybe_unused]] uint32_t ins2_h = 0, ins2_v = 0;  // LONG: the same for the seven-byte table
           bool has_ins = false;                           // (uniform) this wave inserts in this interval
           const uint32_t code_it = (rb / STEP + it - ebase + 1) << SH;  // (uniform) step code of step `it`
+          // ... | the position's low bits: ONE v_or (the compiler would derive it from an address it has at hand, in three)
+          auto code_of = [&](uint32_t low) {
+            uint32_t c;
+            asm("v_or_b32 %0, %1, %2" : "=v"(c) : "s"(code_it), "v"(low));
+            return c;
+          };
           if ((it & 1) == grp) {
             if (it < nsteps) {
               // ---- first part of the search at position ps of step `it` ----
-              const uint32_t rel = it * STEP + ps;
-              const uint32_t ad = kWindow + rel;
-              const uint32_t dw = ad >> 2, sh0 = ad & 3;
-              const uint32_t d0 = s_data[dw], d1 = s_data[dw + 1], d2 = s_data[dw + 2];
+              const uint32_t sb = it * STEP;            // (uniform) the step's first position, round-relative
+              const uint32_t wb = sb + pswK;
+              const uint32_t d0 = lds32(wb, 0), d1 = lds32(wb, 4), d2 = lds32(wb, 8);
               const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
               const uint32_t hmul = a0 * 2654435761u;
               const uint32_t h = hmul >> (32 - HB);
@@ -402,15 +424,18 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 farv2 = s_table2[h2];
               }
               const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
-              const uint32_t c0 = entry_addr<SH>(f0, K - 1), c1 = entry_addr<SH>(f1, K - 1);
-              // (a code below 1 << SH: empty.)  An empty or outdated entry decodes to some address that is not a candidate:
-              // it is still read (kept inside the LDS allocation by a 16-bit mask that leaves real candidates alone), its
-              // rank is dropped
+              const uint32_t m0 = entry_rel<SH>(f0), m1 = entry_rel<SH>(f1);  // coded positions + 1, from the epoch's start
+              const uint32_t c0 = m0 + (K - 1), c1 = m1 + (K - 1);
+              // An empty or outdated entry decodes to some address that is not a candidate: it is still read (kept inside
+              // the LDS allocation by a 16-bit mask that leaves real candidates alone), its rank is dropped.
+              // ad - c <= kWindow  <=>  m >= thr, as signed numbers: thr >= 1 (see ebase), m < 0 for what ageing left of a
+              // position in the step before the epoch
               static_assert(kWindow + kRound + kLook <= 0x10000 && 0x10000 + 16 <= K1_LDS, "candidate reads stay in LDS");
-              const bool ok0 = f0 >= STEP && ad - c0 <= kWindow, ok1 = DEPTH2 && f1 >= STEP && ad - c1 <= kWindow;
+              const int32_t thr = (int32_t)((sb - (K - 1)) + ps);
+              const bool ok0 = (int32_t)m0 >= thr, ok1 = DEPTH2 && (int32_t)m1 >= thr;
               // bytes a match may take from here: inside the round's valid part, the parse region and kCap (0 beyond qn).
               // (A step is a whole number of regions: the distance to the region's end does not depend on the step.)
-              const uint32_t maxlen = (uint32_t)max(min(min((int)(qn - rel), (int)to_rend), (int)kCap), 0);
+              const uint32_t maxlen = (uint32_t)max(min((int)((qn - sb) - ps), (int)mlen0), 0);
               // candidates are ranked by their first kRank bytes; only the winner is compared to kCap
               uint32_t l0, l1 = 0;
               if constexpr (DEPTH2) rank8x2(s_data, a0, a1, c0, c1, maxlen, l0, l1);
@@ -418,62 +443,69 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               f_a0 = a0; f_a1 = a1; f_h = h; f_maxlen = maxlen;
               if constexpr (LONG) {
                 const uint32_t g0 = farv2 >> 16, g1 = farv2 & 0xFFFFu;
-                const uint32_t c2 = entry_addr<SH>(g0, K - 1), c3 = entry_addr<SH>(g1, K - 1);
+                const uint32_t m2 = entry_rel<SH>(g0), m3 = entry_rel<SH>(g1);
+                const uint32_t c2 = m2 + (K - 1), c3 = m3 + (K - 1);
                 // a position without kLongBytes bytes left in the strip reads nothing from the seven-byte table
-                const bool lng = rb + rel + kLongBytes <= n;
-                const bool ok2 = lng && g0 >= STEP && ad - c2 <= kWindow, ok3 = lng && g1 >= STEP && ad - c3 <= kWindow;
+                const bool lng = rb + sb + ps + kLongBytes <= n;
+                const bool ok2 = lng && (int32_t)m2 >= thr, ok3 = lng && (int32_t)m3 >= thr;
                 uint32_t l2, l3;
                 rank8x2(s_data, a0, a1, c2, c3, maxlen, l2, l3);
+                const uint32_t ad = kWindow + sb + ps;
                 auto key = [&](bool ok, uint32_t l, uint32_t c) { return ok ? (l << 16) | (0xFFFFu - (ad - c)) : 0u; };
                 f_m0 = key(ok0, l0, c0); f_m1 = key(ok1, l1, c1); f_q0 = key(ok2, l2, c2); f_q1 = key(ok3, l3, c3);
                 ins2_h = h2;
-                ins2_v = __builtin_amdgcn_alignbit(code_it | (STEP - 1u - ps), farv2, 16);
+                ins2_v = __builtin_amdgcn_alignbit(code_of(cv), farv2, 16);
               } else {
                 f_q0 = c0; f_q1 = c1;
                 f_m0 = ok0 ? l0 : 0u;
                 f_m1 = ok1 ? l1 : 0u;
               }
               ins_h = h;
-              ins_v = __builtin_amdgcn_alignbit(code_it | (STEP - 1u - ps), farv, 16);
+              ins_v = __builtin_amdgcn_alignbit(code_of(cv), farv, 16);
               has_ins = true;
             }
           } else {
             // What this half reads for step `it`'s odd positions (which it will insert) does not depend on the search it
             // finishes: the loads are asked for first, so that their round trips run beside the search's
-            const bool prep = STRIDE2 && it < nsteps;
-            const uint32_t ado = kWindow + it * STEP + 2 * tp + 1;
+            // (also in the interval behind the last step, where nothing is inserted any more: the reads stay inside LDS,
+            // and a uniform condition here costs a branch and a set of register copies in every interval)
+            constexpr bool prep = STRIDE2;
+            static_assert(kWindow + kRound + STEP + 8 <= K1_LDS, "the reads for a step that is not there stay in LDS");
             uint32_t e0 = 0, e1 = 0;
             uint32_t ho = 0, oldo = 0;
             if (it >= 1) {
               // ---- second part of the search at position ps of step it - 1 ----
-              const uint32_t rel = (it - 1) * STEP + ps;
-              const uint32_t ad = kWindow + rel;
+              const uint32_t sb = (it - 1) * STEP;      // (uniform) that step's first position, round-relative
+              const uint32_t ad1 = sb + psK1;           // LDS address of the byte before the position
+              const uint32_t wb = sb + pswK;
               const uint32_t a0 = f_a0, a1 = f_a1, maxlen = f_maxlen;
               uint32_t neare = NEAR ? s_table[f_h] : 0u;
-              uint32_t pbyte = STRIDE2 ? s_bytes[ad - 1] : 0u;  // the odd position's byte (used if a match is found)
+              uint32_t pbyte = STRIDE2 ? smem[ad1] : 0u;  // the odd position's byte (used if a match is found)
               // this position's bytes 8..15 (for the winner's extension, if it comes to that)
-              uint32_t d2 = s_data[(ad >> 2) + 2], d3 = s_data[(ad >> 2) + 3], d4 = s_data[(ad >> 2) + 4];
-              if (prep) { e0 = s_data[ado >> 2]; e1 = s_data[(ado >> 2) + 1]; }
+              uint32_t d2 = lds32(wb, 8), d3 = lds32(wb, 12), d4 = lds32(wb, 16);
+              // (the odd position 2 tp + 1 of step `it` starts in the dword position 2 tp of that step does)
+              if (prep) { e0 = lds32(wb, STEP); e1 = lds32(wb, STEP + 4); }
               asm volatile("" : "+v"(neare), "+v"(pbyte), "+v"(e0), "+v"(e1), "+v"(d2), "+v"(d3), "+v"(d4));  // one round trip for all
               if (prep) {
-                ho = (__builtin_amdgcn_alignbyte(e1, e0, ado & 3) * 2654435761u) >> (32 - kHashBits);
+                ho = (__builtin_amdgcn_alignbyte(e1, e0, sh0 + 1) * 2654435761u) >> (32 - kHashBits);
                 oldo = s_table[ho];
               }
               // longest wins; ties go to the smaller distance: near, then the newer far level
-              uint32_t best = 0, bq = ad;
+              uint32_t best = 0, bq = ad1 + 1u;
               if constexpr (NEAR) {
                 // the step's first position with this hash: this one's own entry at the latest, so the bucket is not empty
                 // (and it is of this very step: only its index in the step has to be decoded)
                 uint32_t nc;
-                asm("v_sub_u32 %0, %1, %2" : "=v"(nc) : "s"(kWindow + (it - 1) * STEP + STEP - 1u), "v"((neare >> 16) & (STEP - 1u)));
-                const bool okn = nc < ad;
-                const uint32_t qnr = okn ? nc : ad;
-                const uint32_t ln = rank8(s_data, a0, a1, qnr, maxlen);
+                const uint32_t nlow = (neare >> 16) & (STEP - 1u);
+                asm("v_sub_u32 %0, %1, %2" : "=v"(nc) : "s"(kWindow + sb + STEP - 1u), "v"(nlow));
+                const bool okn = nlow > cv;  // nc < ad (nc == ad: this position is the first, it has no near candidate)
+                const uint32_t ln = rank8(s_data, a0, a1, nc, maxlen);
                 best = okn ? ln : 0u;
-                bq = qnr;
+                bq = nc;
               }
               if constexpr (LONG) {
                 // the largest key: the longest rank, the nearest of those
+                const uint32_t ad = ad1 + 1u;
                 const uint32_t kn = best ? (best << 16) | (0xFFFFu - (ad - bq)) : 0u;
                 const uint32_t kb = max(max(max(f_m0, f_m1), max(f_q0, f_q1)), kn);
                 best = kb >> 16;
@@ -482,31 +514,30 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 if (f_m0 > best) { best = f_m0; bq = f_q0; }
                 if (f_m1 > best) { best = f_m1; bq = f_q1; }
               }
-              const uint32_t bd = ad - bq;
+              const uint32_t bd1 = ad1 - bq;  // distance - 1 (what is staged; nothing reads it where there is no match)
               const uint32_t cbyte = STRIDE2 ? s_bytes[(bq - 1) & 0xFFFFu] : 0u;  // the byte in front of the winner (any bq reads inside LDS)
               if (best == kRank) {
                 // the winner's next eight bytes, only where its first kRank all matched
-                const uint32_t sh0 = ad & 3;
                 const uint32_t a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0), a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
                 const uint32_t lx = kRank + cmp8<kRank / 4>(s_data, a2, a3, bq);  // maxlen <= kCap does the capping
                 best = lx < maxlen ? lx : maxlen;
               }
               // a 4-byte match farther than kFar4 costs more bits than four literals: drop it.  (maxlen <= n - p, so a
               // position without kMinMatch bytes left cannot reach kMinMatch.)
-              const bool ok = best >= (bd > kFar4 ? kMinMatch + 1 : kMinMatch);
+              const bool ok = best >= (bd1 >= kFar4 ? kMinMatch + 1 : kMinMatch);
               const uint32_t len4 = ok ? best - 3 : 0u;
               if constexpr (STRIDE2) {
                 // the odd position in front: the same match one byte longer if its byte fits too (and the candidate is
                 // not the strip's first byte: the copy would start before the strip)
-                const bool inh = ok && inh_here && pbyte == cbyte && bq + rb > kWindow;
+                const bool inh = ok && inh_here && pbyte == cbyte && bq != first_ad;
                 const uint32_t len4o = inh ? (best < kCap ? best - 2 : kCap - 3) : 0u;
                 // one staging slot per EVEN position (an odd position that has a match has its successor's distance)
-                *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + rel)) = (uint16_t)bd;  // only read where the length says there is a match
+                *reinterpret_cast<uint16_t*>(gst + ad1) = (uint16_t)bd1;  // only read where the length says there is a match
                 // 4-bit lengths, SHIFTED by one position: byte j = {position 2j - 1, position 2j} of the round -- the pair
                 // this thread knows
-                smem[L_LEN4 + (rel >> 1)] = (uint8_t)(len4o | (len4 << 4));
+                smem[L_LEN4 + ((sb >> 1) + tp)] = (uint8_t)(len4o | (len4 << 4));
               } else {
-                *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)(stage_off + 2u * rel)) = (uint16_t)bd;
+                *reinterpret_cast<uint16_t*>(gst + 2u * ad1) = (uint16_t)bd1;
                 // two lanes' 4-bit lengths -> one byte (the odd lane's value comes over the DPP network), stored by the
                 // even lanes.  All 64 lanes of the wave are active here, so the execution mask is switched and restored by
                 // hand: two scalar moves instead of the save / branch / restore a divergent `if` compiles to (smem sits at
@@ -514,18 +545,18 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 uint32_t v = len4;
                 v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
                 asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
-                             :: "v"(rel >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
+                             :: "v"((sb + tp) >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
               }
             } else if (prep) {
-              e0 = s_data[ado >> 2];
-              e1 = s_data[(ado >> 2) + 1];
-              ho = (__builtin_amdgcn_alignbyte(e1, e0, ado & 3) * 2654435761u) >> (32 - kHashBits);
+              e0 = lds32(pswK, 0);  // step 0's odd positions
+              e1 = lds32(pswK, 4);
+              ho = (__builtin_amdgcn_alignbyte(e1, e0, sh0 + 1) * 2654435761u) >> (32 - kHashBits);
               oldo = s_table[ho];
             }
             if (prep) {
               // ---- the odd position 2 tp + 1 of step `it`: only inserted, by this thread ----
               ins_h = ho;
-              ins_v = __builtin_amdgcn_alignbit(code_it | (STEP - 2u - 2 * tp), oldo, 16);
+              ins_v = __builtin_amdgcn_alignbit(code_of(cv - 1u), oldo, 16);
               has_ins = true;
             }
           }
@@ -567,7 +598,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         D0 = D.x; D1 = D.y; D2 = D.z; D3 = D.w;
         asm volatile("" : "+v"(D0), "+v"(D1), "+v"(D2), "+v"(D3));  // four registers, not an indexable vector (scratch)
       }
-      auto dist_of = [&](uint32_t k) {  // distance of the lane's position k (0..7)
+      auto dm1_of = [&](uint32_t k) {  // distance - 1 of the lane's position k (0..7)
         if constexpr (STRIDE2) {
           const uint32_t e = (k + 1u) >> 1;            // even position 2e holds it (an odd k: its successor's); e = 0..4
           const uint32_t w = (e & 4u) ? D2 : ((e & 2u) ? D1 : D0);
@@ -688,7 +719,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             uint32_t len;
             if (cap_mp != mp) {
               cap_run = false;
-              const uint32_t xpa = kWindow + pb + mp, xca = xpa - dist_of(mp);
+              const uint32_t xpa = kWindow + pb + mp, xca = xpa - 1u - dm1_of(mp);
               const uint32_t xmax = rend - (pb + mp) < 258u ? rend - (pb + mp) : 258u;
               // the next kLaneExt bytes of both strings, straight-line (bytes past xmax are cut off below)
               static_assert(kLaneExt == 16, "four dwords per string");
@@ -733,7 +764,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           if (need == 0) return false;
           const uint32_t src_lane = (uint32_t)__builtin_ctzll(need);
           const uint32_t xat = (uint32_t)__builtin_amdgcn_readlane((int)(pb + cap_mp - 16), (int)src_lane);  // round-relative position
-          const uint32_t xd = (uint32_t)__builtin_amdgcn_readlane((int)dist_of((cap_mp - 16) & 7), (int)src_lane);
+          const uint32_t xd = (uint32_t)__builtin_amdgcn_readlane((int)dm1_of((cap_mp - 16) & 7), (int)src_lane) + 1u;
           const uint32_t xmax = rend - xat < 258u ? rend - xat : 258u;  // (rend is the same for the whole wave)
           const uint32_t ia = kWindow + xat + kCap + kLaneExt + 4 * lane, ja = ia - xd;
           const uint32_t i0 = s_data[ia >> 2], i1 = s_data[(ia >> 2) + 1];
@@ -855,7 +886,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             rest &= rest - 1u;
             const uint32_t at = item_at((1u << k) - 1u);
             uint32_t l3 = (N >> (4 * k)) & 15u;      // capped len-3 from the match phase
-            uint32_t d1 = dist_of(k) - 1u;
+            uint32_t d1 = dm1_of(k);
             if (l3 == kCap - 3) {                    // capped match: the walk extended it
               l3 = cap_len - 3;
               d1 = cap_run ? 0u : d1;
