@@ -373,9 +373,9 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         // INTERVAL before step `it` is inserted, the half whose turn it is does the first part of step `it` -- bytes,
         // hash, the far levels as the table holds them before the step, their ranks -- while the other half does the
         // second part of step it - 1, whose first part it did an interval ago -- the near candidate as the table stands
-        // after that step's insertions, the winner, its extension, the results -- and, with STRIDE2, reads the buckets of
-        // step `it`'s ODD positions, which it will insert.  Every thread is busy in every interval; a search costs one
-        // thread two.
+        // after that step's insertions, the winner, its extension, the results.  The half that did the first part
+        // inserts the step: its position and, with STRIDE2, the odd position behind it (whose bytes it has in registers
+        // anyway).  Every thread is busy in every interval; a search costs one thread two.
         const uint32_t grp = wave >> 3;                   // (uniform) this wave's half
         const uint32_t tp = t & 511u;                     // index in the half
         const uint32_t ps = STRIDE2 ? 2 * tp : tp;        // the thread's searched position within a step
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;
         for (uint32_t it = 0; it <= nsteps; ++it) {
           uint32_t ins_h = 0, ins_v = 0;
-          [[maybe_unused]] uint32_t ins2_h = 0, ins2_v = 0;  // LONG: the same for the seven-byte table
+          [[maybe_unused]] uint32_t ins2_h = 0, ins2_v = 0;  // LONG: the same for the seven-byte table; STRIDE2: for the odd position behind
           bool has_ins = false;                           // (uniform) this wave inserts in this interval
           const uint32_t code_it = (rb / STEP + it - ebase + 1) << SH;  // (uniform) step code of step `it`
           // ... | the position's low bits: ONE v_or (the compiler would derive it from an address it has at hand, in three)
@@ -417,6 +417,12 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               const uint32_t hmul = a0 * 2654435761u;
               const uint32_t h = hmul >> (32 - HB);
               const uint32_t farv = s_table[h];
+              if constexpr (STRIDE2) {
+                // the odd position behind this one is only inserted: its four bytes are in the registers already, its
+                // bucket is read beside this one's
+                ins2_h = (__builtin_amdgcn_alignbyte(a1, a0, 1) * 2654435761u) >> (32 - kHashBits);
+                ins2_v = s_table[ins2_h];
+              }
               [[maybe_unused]] uint32_t h2 = 0, farv2 = 0;
               if constexpr (LONG) {
                 // bytes 4..6 join the hash (the specification's long hash: two multiplicative hashes xored)
@@ -462,17 +468,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               }
               ins_h = h;
               ins_v = __builtin_amdgcn_alignbit(code_of(cv), farv, 16);
+              if constexpr (STRIDE2) ins2_v = __builtin_amdgcn_alignbit(code_of(cv - 1u), ins2_v, 16);
               has_ins = true;
             }
           } else {
-            // What this half reads for step `it`'s odd positions (which it will insert) does not depend on the search it
-            // finishes: the loads are asked for first, so that their round trips run beside the search's
-            // (also in the interval behind the last step, where nothing is inserted any more: the reads stay inside LDS,
-            // and a uniform condition here costs a branch and a set of register copies in every interval)
-            constexpr bool prep = STRIDE2;
-            static_assert(kWindow + kRound + STEP + 8 <= K1_LDS, "the reads for a step that is not there stay in LDS");
-            uint32_t e0 = 0, e1 = 0;
-            uint32_t ho = 0, oldo = 0;
             if (it >= 1) {
               // ---- second part of the search at position ps of step it - 1 ----
               const uint32_t sb = (it - 1) * STEP;      // (uniform) that step's first position, round-relative
@@ -483,13 +482,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
               uint32_t pbyte = STRIDE2 ? smem[ad1] : 0u;  // the odd position's byte (used if a match is found)
               // this position's bytes 8..15 (for the winner's extension, if it comes to that)
               uint32_t d2 = lds32(wb, 8), d3 = lds32(wb, 12), d4 = lds32(wb, 16);
-              // (the odd position 2 tp + 1 of step `it` starts in the dword position 2 tp of that step does)
-              if (prep) { e0 = lds32(wb, STEP); e1 = lds32(wb, STEP + 4); }
-              asm volatile("" : "+v"(neare), "+v"(pbyte), "+v"(e0), "+v"(e1), "+v"(d2), "+v"(d3), "+v"(d4));  // one round trip for all
-              if (prep) {
-                ho = (__builtin_amdgcn_alignbyte(e1, e0, sh0 + 1) * 2654435761u) >> (32 - kHashBits);
-                oldo = s_table[ho];
-              }
+              asm volatile("" : "+v"(neare), "+v"(pbyte), "+v"(d2), "+v"(d3), "+v"(d4));  // one round trip for all
               // longest wins; ties go to the smaller distance: near, then the newer far level
               uint32_t best = 0, bq = ad1 + 1u;
               if constexpr (NEAR) {
@@ -547,22 +540,11 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
                              :: "v"((sb + tp) >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
               }
-            } else if (prep) {
-              e0 = lds32(pswK, 0);  // step 0's odd positions
-              e1 = lds32(pswK, 4);
-              ho = (__builtin_amdgcn_alignbyte(e1, e0, sh0 + 1) * 2654435761u) >> (32 - kHashBits);
-              oldo = s_table[ho];
-            }
-            if (prep) {
-              // ---- the odd position 2 tp + 1 of step `it`: only inserted, by this thread ----
-              ins_h = ho;
-              ins_v = __builtin_amdgcn_alignbit(code_of(cv - 1u), oldo, 16);
-              has_ins = true;
             }
           }
           if (it == nsteps) break;
           lds_barrier();  // every read of the table as it stands before step `it` precedes the step's insertions
-          if (STRIDE2 || has_ins) {  // (STRIDE2: every wave inserts, its even or its odd positions)
+          if (has_ins) {  // (the half that did the step's first part)
             // {code, old newest}: the upper half of code:bucket.  (Positions without kMinMatch bytes left insert like the
             // rest, which nothing can observe: every position after them in the strip is such a position too and takes no
             // match, the next strip starts from an empty table.)  A lane whose predecessor in the wave has the same bucket
@@ -573,6 +555,12 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             if constexpr (LONG) {
               const uint32_t hp2 = (uint32_t)__builtin_amdgcn_update_dpp((int)~ins2_h, (int)ins2_h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
               if (hp2 != ins2_h) atomicMax(&s_table2[ins2_h], ins2_v);
+            }
+            if constexpr (STRIDE2) {
+              // the odd position behind: the same, among the wave's odd positions (and its own even position's bucket has
+              // the larger code already)
+              const uint32_t hp2 = (uint32_t)__builtin_amdgcn_update_dpp((int)~ins2_h, (int)ins2_h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+              if (hp2 != ins2_h && ins2_h != ins_h) atomicMax(&s_table[ins2_h], ins2_v);
             }
           }
           lds_barrier();  // insertions complete before the near reads
@@ -586,18 +574,26 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       stamp(1);
       // the lane's eight staged distances: asked for now, used by the extensions and the emit.  Every wave has them
       // before any wave writes an item (the barrier between walk and emit waits for outstanding loads)
+      // (the load is only waited for behind the take pass and the transfer functions, which do not need it)
       uint32_t D0, D1, D2 = 0, D3 = 0;
+      uint4 Dld = make_uint4(0, 0, 0, 0);
       if constexpr (STRIDE2) {
         // four slots: the lane's even positions; position 7's successor is the next lane's position 0
         const uint2 D = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(gi) + (uint64_t)(stage_off + 8u * t));
-        D0 = D.x; D1 = D.y;
-        asm volatile("" : "+v"(D0), "+v"(D1));
-        D2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)D0, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);  // (lane 63: its position 7 ends the region, never inherits)
+        Dld.x = D.x; Dld.y = D.y;
       } else {
-        const uint4 D = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(gi) + (uint64_t)(stage_off + 16u * t));
-        D0 = D.x; D1 = D.y; D2 = D.z; D3 = D.w;
-        asm volatile("" : "+v"(D0), "+v"(D1), "+v"(D2), "+v"(D3));  // four registers, not an indexable vector (scratch)
+        Dld = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(gi) + (uint64_t)(stage_off + 16u * t));
       }
+      auto staged_arrive = [&]() {
+        D0 = Dld.x; D1 = Dld.y;
+        if constexpr (STRIDE2) {
+          asm volatile("" : "+v"(D0), "+v"(D1));
+          D2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)D0, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);  // (lane 63: its position 7 ends the region, never inherits)
+        } else {
+          D2 = Dld.z; D3 = Dld.w;
+          asm volatile("" : "+v"(D0), "+v"(D1), "+v"(D2), "+v"(D3));  // four registers, not an indexable vector (scratch)
+        }
+      };
       auto dm1_of = [&](uint32_t k) {  // distance - 1 of the lane's position k (0..7)
         if constexpr (STRIDE2) {
           const uint32_t e = (k + 1u) >> 1;            // even position 2e holds it (an odd k: its successor's); e = 0..4
@@ -810,6 +806,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           }
           return true;
         };
+        staged_arrive();
         uint32_t entry = 0;
         if (nv) walk(0);
 #pragma unroll 1
