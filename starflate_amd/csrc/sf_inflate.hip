@@ -28,7 +28,10 @@ namespace sf {
 
 namespace {
 
-constexpr uint32_t KT_LANES = 64;
+// k_inflate_tokens: segments (lanes) per workgroup.  A lane's decode is one long dependent chain and the CU holds the tables
+// of 64 lanes at most (LDS), so what counts is how many waves those lanes are spread over: 4 lanes per wave = 16 waves
+// per CU measured best (1 GiB of text: 23.4 ms; 64 lanes in one wave 28.8, 32: 24.9, 16: 27.2, 8: 24.4, 2: 29.7, 1: 56.4)
+constexpr uint32_t KT_LANES = 4;
 constexpr uint32_t KT_LDS = KT_LANES * inflate::LaneLayout::kBytes;
 constexpr uint32_t KB_THREADS = 512;
 constexpr uint32_t KB_TPT = 2;     // tokens per thread per step

@@ -45,7 +45,7 @@ constexpr uint32_t kTokMatchBit = 0x80000000u;
 // (code bits, symbol) and `cnt` u16[16] codes per length for the bit-serial walk of longer codes; `lens` u8[320]
 // code lengths (literal/length at 0, distance at 288).  While a dynamic header is parsed the literal/length
 // fast table is not built yet and lends its first 160 bytes to the code-length code.
-struct LaneLayout {  // k_inflate_tokens: one segment per LANE, 64 of these per workgroup
+struct LaneLayout {  // k_inflate_tokens: one segment per LANE (KT_LANES of these per workgroup)
   static constexpr uint32_t kFastL = 9, kFastD = 7;
   static constexpr uint32_t kOffFastL = 0, kOffSymL = 1024, kOffCntL = 1600, kOffFastD = 1632, kOffSymD = 1888,
                             kOffCntD = 1952, kOffLens = 1984;
