@@ -392,8 +392,10 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         const uint32_t psK1 = kWindow - 1u + ps;      // LDS address of the byte before the position in step 0
         const uint32_t mlen0 = to_rend < kCap ? to_rend : kCap;  // bytes a match may take from the position, the input's end aside
         auto lds32 = [&](uint32_t at, uint32_t off) { return *reinterpret_cast<const uint32_t*>(smem + at + off); };
-        // (uniform) the round's staging slots, addressed by psK1 + the step's offset
-        uint8_t* const gst = reinterpret_cast<uint8_t*>(gi) + stage_off - (STRIDE2 ? 1u : 2u) * (kWindow - 1u);
+        // (uniform) the round's staging slots.  (Addressed as base + the position's offset in the round: with the
+        // constant folded into the base -- an odd base below the array, odd offsets -- the same stores cost 1 GiB of
+        // extra HBM reads per GiB of input: FETCH_SIZE 274 against 145 MiB per 256 MiB, tools/exp/pmc_fetch_variants.sh)
+        uint8_t* const gst = reinterpret_cast<uint8_t*>(gi) + stage_off;
         // first part -> second part.  (LONG: f_m0.. f_q1 carry the four far candidates as KEYS rank << 16 | 0xFFFF - distance)
         uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;
         for (uint32_t it = 0; it <= nsteps; ++it) {
@@ -525,12 +527,12 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 const bool inh = ok && inh_here && pbyte == cbyte && bq != first_ad;
                 const uint32_t len4o = inh ? (best < kCap ? best - 2 : kCap - 3) : 0u;
                 // one staging slot per EVEN position (an odd position that has a match has its successor's distance)
-                *reinterpret_cast<uint16_t*>(gst + ad1) = (uint16_t)bd1;  // only read where the length says there is a match
+                *reinterpret_cast<uint16_t*>(gst + (ad1 - (kWindow - 1u))) = (uint16_t)bd1;  // only read where the length says there is a match
                 // 4-bit lengths, SHIFTED by one position: byte j = {position 2j - 1, position 2j} of the round -- the pair
                 // this thread knows
                 smem[L_LEN4 + ((sb >> 1) + tp)] = (uint8_t)(len4o | (len4 << 4));
               } else {
-                *reinterpret_cast<uint16_t*>(gst + 2u * ad1) = (uint16_t)bd1;
+                *reinterpret_cast<uint16_t*>(gst + 2u * (ad1 - (kWindow - 1u))) = (uint16_t)bd1;
                 // two lanes' 4-bit lengths -> one byte (the odd lane's value comes over the DPP network), stored by the
                 // even lanes.  All 64 lanes of the wave are active here, so the execution mask is switched and restored by
                 // hand: two scalar moves instead of the save / branch / restore a divergent `if` compiles to (smem sits at
