@@ -152,9 +152,11 @@ def traffic_from_profile(kernel):
 
 
 def issue_from_profile(kernel, kernel_ms, n):
-    """What bounds the kernels is the vector ALU's issue rate, not HBM: vector instructions per launch
-    from the last committed PMC profile (SQ_INSTS_VALU of the same 1 GiB workload -- NOT counted in this run) over this run's
-    kernel time, as cycles per wave-instruction per SIMD; profiles/r03_valu_ops.log has what the instructions cost."""
+    """The dominant kernel is nowhere near the HBM roofline; what it spends instead: vector
+    instructions per launch from the last committed PMC profile (SQ_INSTS_VALU of the same 1 GiB workload -- NOT counted in
+    this run) over this run's kernel time, as cycles per wave-instruction per SIMD, and the share of the CU's cycles its LDS
+    is busy.  The round's experiments (profiles/r03_notes.md) show the match phase bound by its chain of LDS round trips
+    between barriers and the parse by vector issue, not the kernel as a whole by either."""
     path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
     try:
         with open(path) as f:
@@ -162,11 +164,15 @@ def issue_from_profile(kernel, kernel_ms, n):
         for name, v in d.items():
             if kernel in name and "SQ_INSTS_VALU" in v:
                 insts = v["SQ_INSTS_VALU"] / max(v.get("pmc_dispatches", 1), 1) * (n / 2**30)
-                simds, ghz = 1024, 2.4
-                return {"bound": "valu-issue", "valu_wave_instructions_per_launch": int(insts), "simds": simds, "clock_ghz": ghz,
-                        "cycles_per_instruction_per_simd": round(kernel_ms * 1e-3 * ghz * 1e9 / (insts / simds), 2),
+                simds, cus, ghz = 1024, 256, 2.4
+                cycles = kernel_ms * 1e-3 * ghz * 1e9
+                lds = v.get("SQ_LDS_IDX_ACTIVE")
+                return {"bound": "mixed: LDS round trips between barriers (match phase), vector issue (parse, emit); not HBM",
+                        "valu_wave_instructions_per_launch": int(insts), "simds": simds, "clock_ghz": ghz,
+                        "cycles_per_instruction_per_simd": round(cycles / (insts / simds), 2),
                         "instruction_cost_cycles": "2.3-2.9 (and/or/xor/add/sub/lshr/mov/bitop3), 4.1-4.5 (all other integer VALU) at 8 waves per SIMD: tools/micro/valu_ops.hip",
-                        "source": "profiles/r03_pmc_summary.json (instruction count; not collected live) / this run's kernel time"}
+                        "lds_busy_frac": round(lds / max(v.get("pmc_dispatches", 1), 1) * (n / 2**30) / cus / cycles, 3) if lds else None,
+                        "source": "profiles/r03_pmc_summary.json (instruction and LDS-cycle counts; not collected live) / this run's kernel time"}
     except Exception:  # noqa: BLE001
         pass
     return None

@@ -22,6 +22,7 @@ struct sfh_ctx {
   uint32_t last_block_bytes = 0; // strip size the last compress call used
   bool index_valid = false;      // ws.offsets holds the index of the last compress call
   uint64_t* d_total = nullptr;   // own result slot for the synchronous entry points
+  uint64_t* h_total = nullptr;   // ... and the pinned word it is copied to (a pageable target is staged by the runtime)
   uint32_t* d_value = nullptr;   // result slot of sfh_checksum_device; [2] for the decoder's status
   uint64_t* d_index = nullptr;   // staging for the host-buffer decoder
   size_t d_index_cap = 0;
@@ -338,6 +339,7 @@ int sfh_create(sfh_ctx** out, int device) {
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
       (e = hipMalloc(&ctx->d_total, sizeof(uint64_t))) != hipSuccess ||
+      (e = hipHostMalloc((void**)&ctx->h_total, sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess ||
       (e = hipMalloc(&ctx->d_value, 2 * sizeof(uint32_t))) != hipSuccess || (e = sf::init_kernels()) != hipSuccess ||
       (e = sf::init_inflate_kernels()) != hipSuccess) {
     sfh_destroy(ctx);
@@ -363,6 +365,7 @@ void sfh_destroy(sfh_ctx* ctx) {
   free_ws(ctx);
   (void)hipFree(ctx->ws.sums);
   (void)hipFree(ctx->d_total);
+  if (ctx->h_total) (void)hipHostFree(ctx->h_total);
   (void)hipFree(ctx->d_value);
   (void)hipFree(ctx->d_index);
   (void)hipFree(ctx->d_sub);
@@ -404,10 +407,9 @@ int sfh_compress_device(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, 
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int rc = enqueue(ctx, d_src, n, d_dst, cap, ctx->d_total, opt, s);
   if (rc) return rc;
-  uint64_t total = 0;
-  SF_HIP(hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, s), "copy size");
+  SF_HIP(hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, s), "copy size");
   SF_HIP(hipStreamSynchronize(s), "stream sync");
-  *out_n = (size_t)total;
+  *out_n = (size_t)*ctx->h_total;
   return SFH_OK;
 }
 
