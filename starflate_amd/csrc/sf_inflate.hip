@@ -34,7 +34,10 @@ namespace {
 constexpr uint32_t KT_LANES = 4;
 constexpr uint32_t KT_LDS = KT_LANES * inflate::LaneLayout::kBytes;
 constexpr uint32_t KB_THREADS = 512;
-constexpr uint32_t KB_TPT = 2;     // tokens per thread per step
+#ifndef X_KB_TPT
+#define X_KB_TPT 3
+#endif
+constexpr uint32_t KB_TPT = X_KB_TPT;     // tokens per thread per step
 constexpr uint32_t KB_SPAN = 3968;  // output bytes per step (pointer array)
 constexpr uint32_t KB_AUX = 2 * KB_SPAN + 4 * KB_THREADS * KB_TPT + 8 * (KB_SPAN / 32) + 64;
 constexpr uint32_t KB_RING = kWindow + 4096;             // the window + the step in flight (KB_SPAN bytes at most)
@@ -446,13 +449,22 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __r
   }
 }
 
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (uint32_t o = 1; o < 64; o <<= 1) {
-    const uint32_t u = __shfl_up(v, o);
-    if (lane >= o) v += u;
-  }
+// inclusive wave scan on the DPP network (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_from(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t /*lane*/) {
+  v = dpp_add_from<0x111, 0xF>(v);
+  v = dpp_add_from<0x112, 0xF>(v);
+  v = dpp_add_from<0x114, 0xF>(v);
+  v = dpp_add_from<0x118, 0xF>(v);
+  v = dpp_add_from<0x142, 0xA>(v);
+  v = dpp_add_from<0x143, 0xC>(v);
   return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v, 0), 63);
 }
 
 __device__ __forceinline__ uint32_t load_word_guarded(const uint8_t* base, uint64_t src_n, uint64_t w) {
@@ -543,55 +555,67 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     s_next[1] = 0;  // where its output ends
   }
   if (t < kWords) s_mark[t] = 0;
-  uint32_t nextA = KB_TPT * t < ntok ? tk[KB_TPT * t] : 0u, nextB = KB_TPT * t + 1 < ntok ? tk[KB_TPT * t + 1] : 0u;
+  uint32_t next[KB_TPT];
+#pragma unroll
+  for (uint32_t k = 0; k < KB_TPT; ++k) next[k] = KB_TPT * t + k < ntok ? tk[KB_TPT * t + k] : 0u;
   while (tok_base < ntok) {
-    // ---- place up to two tokens per thread (loaded while the previous step was being resolved) ----
+    // ---- place up to KB_TPT tokens per thread (loaded while the previous step was being resolved) ----
     const uint32_t i0 = tok_base + KB_TPT * t;
-    const bool vA = i0 < ntok, vB = i0 + 1 < ntok;
-    const uint32_t tokA = nextA, tokB = nextB;
-    const bool mA = vA && (tokA >> 31), mB = vB && (tokB >> 31);
-    const uint32_t lenA = vA ? (mA ? ((tokA >> 16) & 0xFFu) + 3u : 1u) : 0u;
-    const uint32_t lenB = vB ? (mB ? ((tokB >> 16) & 0xFFu) + 3u : 1u) : 0u;
-    const uint32_t incl = wave_scan_incl(lenA + lenB, lane);
+    uint32_t tok[KB_TPT], len[KB_TPT], start[KB_TPT];
+    bool val[KB_TPT], mat[KB_TPT], fit[KB_TPT];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < KB_TPT; ++k) {
+      tok[k] = next[k];
+      val[k] = i0 + k < ntok;
+      mat[k] = val[k] && (tok[k] >> 31);
+      len[k] = val[k] ? (mat[k] ? ((tok[k] >> 16) & 0xFFu) + 3u : 1u) : 0u;
+      mine += len[k];
+    }
+    const uint32_t incl = wave_scan_incl(mine, lane);
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
     uint32_t pre = 0;
 #pragma unroll
     for (uint32_t w = 0; w < KB_THREADS / 64; ++w)
       if (w < wave) pre += s_w[w];
-    const uint32_t startA = pos0 + pre + incl - lenA - lenB, startB = startA + lenA;
     const uint32_t limit = pos0 + KB_SPAN < out_n ? pos0 + KB_SPAN : out_n;
     // the tokens that end inside the span form a prefix of the step (the first always fits: 258 <= KB_SPAN)
-    const bool fA = vA && startA + lenA <= limit, fB = vB && startB + lenB <= limit;
-    const uint32_t distA = (tokA & 0x7FFFu) + 1u, distB = (tokB & 0x7FFFu) + 1u;
-    // k_inflate_tokens has validated every token; this keeps a corrupted token buffer inside the window
-    if ((fA && mA && distA > startA + segbase) || (fB && mB && distB > startB + segbase) || (vA && startA + lenA > out_n) ||
-        (vB && startB + lenB > out_n))
-      bad = true;
+    // k_inflate_tokens has validated every token; the checks keep a corrupted token buffer inside the window
+    uint32_t nfit = 0, fmax = 0;
+    {
+      uint32_t at = pos0 + pre + incl - mine;
+#pragma unroll
+      for (uint32_t k = 0; k < KB_TPT; ++k) {
+        start[k] = at;
+        at += len[k];
+        fit[k] = val[k] && at <= limit;
+        const uint32_t dist = (tok[k] & 0x7FFFu) + 1u;
+        if ((fit[k] && mat[k] && dist > start[k] + segbase) || (val[k] && at > out_n)) bad = true;
+        if (fit[k]) { fmax = at; ++nfit; }
+      }
+    }
     {
       // where the next step starts: the fitting tokens are a prefix, so their count and the largest end say it
-      const uint32_t nfit_w = (uint32_t)__popcll(__ballot(fA)) + (uint32_t)__popcll(__ballot(fB));
-      uint32_t fmax = fB ? startB + lenB : (fA ? startA + lenA : 0u);
-#pragma unroll
-      for (uint32_t o2 = 32; o2; o2 >>= 1) {
-        const uint32_t u = __shfl_xor(fmax, o2);
-        fmax = u > fmax ? u : fmax;
-      }
-      if (lane == 0 && nfit_w) {
-        atomicAdd(&s_next[0], nfit_w);
-        atomicMax(&s_next[1], fmax);
+      const uint32_t nfit_w = wave_sum_u32(nfit);
+      const uint64_t fitting = __ballot(nfit != 0);
+      if (fitting) {
+        // (a prefix of the tokens fits: the wave's last fitting lane knows the largest end)
+        const uint32_t fmax_w = (uint32_t)__builtin_amdgcn_readlane((int)fmax, 63 - __builtin_clzll(fitting));
+        if (lane == 0) {
+          atomicAdd(&s_next[0], nfit_w);
+          atomicMax(&s_next[1], fmax_w);
+        }
       }
     }
     // token records and the bitmap of token starts (step-relative)
-    if (fA && !bad) {
-      const uint32_t r = startA - pos0;
-      s_tinfo[KB_TPT * t] = r | (mA ? 0x1000u | ((distA - 1u) << 16) : (tokA & 0xFFu) << 16);
-      atomicOr(&s_mark[r >> 5], 1u << (r & 31));
-    }
-    if (fB && !bad) {
-      const uint32_t r = startB - pos0;
-      s_tinfo[KB_TPT * t + 1] = r | (mB ? 0x1000u | ((distB - 1u) << 16) : (tokB & 0xFFu) << 16);
-      atomicOr(&s_mark[r >> 5], 1u << (r & 31));
+#pragma unroll
+    for (uint32_t k = 0; k < KB_TPT; ++k) {
+      if (fit[k] && !bad) {
+        const uint32_t r = start[k] - pos0;
+        s_tinfo[KB_TPT * t + k] = r | (mat[k] ? 0x1000u | ((tok[k] & 0x7FFFu) << 16) : (tok[k] & 0xFFu) << 16);
+        atomicOr(&s_mark[r >> 5], 1u << (r & 31));
+      }
     }
     if (__syncthreads_or(bad)) {
       if (t == 0) info[seg].status = inflate::kError;
@@ -601,8 +625,8 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     const uint32_t span_n = next_pos - pos0;
     {
       const uint32_t n0 = next_tok + KB_TPT * t;  // the next step's tokens: in flight during paint and jumping
-      nextA = n0 < ntok ? tk[n0] : 0u;
-      nextB = n0 + 1 < ntok ? tk[n0 + 1] : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < KB_TPT; ++k) next[k] = n0 + k < ntok ? tk[n0 + k] : 0u;
     }
     if (wave == 0) {
       // tokens starting before each bitmap word: one wave, two words per lane
