@@ -41,7 +41,8 @@ constexpr uint32_t KB_TPT = X_KB_TPT;     // tokens per thread per step
 constexpr uint32_t KB_SPAN = 3968;  // output bytes per step (pointer array)
 constexpr uint32_t KB_AUX = 2 * KB_SPAN + 4 * KB_THREADS * KB_TPT + 8 * (KB_SPAN / 32) + 64;
 constexpr uint32_t KB_RING = kWindow + 4096;             // the window + the step in flight (KB_SPAN bytes at most)
-constexpr uint32_t KB_LDS = KB_RING + KB_AUX;            // 49,952 B: three workgroups per CU
+constexpr uint32_t KB_LDS = KB_RING + KB_AUX;            // 52,000 B: three workgroups per CU
+static_assert(3 * KB_LDS <= 160 * 1024, "k_inflate_bytes: three workgroups per CU");
 static_assert(KB_SPAN <= KB_RING - kWindow && KB_RING % 16 == 0 && kChunk % 4 == 0, "ring geometry");
 
 __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __restrict__ src, uint64_t src_n,
@@ -476,13 +477,13 @@ __device__ __forceinline__ uint32_t load_word_guarded(const uint8_t* base, uint6
   return v;
 }
 
-// The byte-copy half (src/decompress.cpp:157-187,388-398).  Tokens are placed in steps of up to 1024 tokens /
+// The byte-copy half (src/decompress.cpp:157-187,388-398).  Tokens are placed in steps of up to 1536 tokens (three per thread) /
 // 3968 output bytes by a workgroup prefix sum; a bitmap of token starts plus per-word popcount prefixes then
 // lets every THREAD TAKE BYTES, not tokens: byte j finds its token with two broadcast reads and a popcount, so
 // all lanes work whatever the match lengths are.  A match byte whose source lies before the step is final
 // already and is copied at once; one whose source lies inside the step gets a 16-bit pointer to it, and pointer
 // jumping (ptr[j] = ptr[ptr[j]], barrier-separated rounds, at most log2(3968)) takes every such byte to a final
-// one, however the matches of the step nest or overlap themselves; then the byte is fetched.  45 KiB of LDS (the
+// one, however the matches of the step nest or overlap themselves; then the byte is fetched.  51 KiB of LDS (the
 // 32 KiB window + one step of pointers and token records): three workgroups share a CU and hide each other's
 // barriers.
 // One segment.  The output window is a ring of KB_RING bytes in LDS: the 32 KiB a match may reach back plus the
