@@ -638,9 +638,13 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
           const uint32_t wn = lane == 63 ? 0u : s_len4[t + 1];
           W = (uint64_t)s_len4[t] | ((uint64_t)wn << 32);
         }
-        // positions at or beyond qn carry stale lengths of an earlier round: clear them
-        const uint32_t left = qn > pb ? qn - pb : 0u;  // valid positions from this dword's first on
-        if (left < 16) W &= left ? ((1ull << (4 * left)) - 1ull) : 0ull;
+        // positions at or beyond qn carry stale lengths of an earlier round: clear them.  (Only a strip's last round can be
+        // short -- uniform; in a full round the one dword that reaches past the round belongs to a lane 63, whose high half
+        // is masked above.)
+        if (qn < kRound) {
+          const uint32_t left = qn > pb ? qn - pb : 0u;  // valid positions from this dword's first on
+          if (left < 16) W &= left ? ((1ull << (4 * left)) - 1ull) : 0ull;
+        }
         N = (uint32_t)W;
         // All eight positions at once, a byte per position (SWAR): the 4-bit lengths of positions 0..10 are spread into
         // the bytes of three dwords; b > a + j for bytes a, b <= 15 is bit 7 of (b + 0x7F - j) - a, and no byte borrows from
