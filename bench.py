@@ -136,43 +136,59 @@ def zlib6_size(host_bytes):
     return len(co.compress(host_bytes)) + len(co.flush())
 
 
-def traffic_from_profile(kernel):
-    """HBM bytes per launch of `kernel` from the last committed PMC profile -- NOT measured in this run."""
+def traffic_from_profile(kernel, n):
+    """HBM bytes per launch of `kernel` (FETCH_SIZE x 2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) from the
+    committed rocprofv3 --pmc passes of this very command (tools/prof_round.sh -> profiles/pmc_traffic.json), scaled to this
+    run's bytes.  The profile carries the commit and a SHA-256 of the kernel sources it measured; `current` says whether
+    those are the sources that are running now (a number from other sources is still reported, flagged)."""
+    from starflate_amd.build import source_stamp
+
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        e = d.get(kernel)
+        e, meta, now = d.get(kernel), d.get("_meta", {}), source_stamp()
         if not e:
-            return None
-        return {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "source": "profiles/pmc_traffic.json",
-                "profiled_at": d.get("_meta", {}).get("commit", "see profiles/"), "note": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of an earlier run; not collected live"}
+            return None, None
+        scale = n / float(meta.get("bytes_per_launch", 1 << 30))
+        info = {"source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not collected in this run)",
+                "commit": meta.get("commit", "unknown"), "csrc_sha256": meta.get("csrc_sha256"),
+                "running": now, "current": meta.get("csrc_sha256") == now["csrc_sha256"],
+                "read_bytes": int(e.get("read_bytes", 0) * scale), "write_bytes": int(e.get("write_bytes", 0) * scale)}
+        return int(e["hbm_bytes_per_launch"] * scale), info
     except Exception:  # noqa: BLE001
-        return None
+        return None, None
 
 
-def issue_from_profile(kernel, kernel_ms, n):
+def issue_from_profile(kernel, kernel_ms, n, props):
     """The dominant kernel is nowhere near the HBM roofline; what it spends instead: vector
-    instructions per launch from the last committed PMC profile (SQ_INSTS_VALU of the same 1 GiB workload -- NOT counted in
-    this run) over this run's kernel time, as cycles per wave-instruction per SIMD, and the share of the CU's cycles its LDS
-    is busy.  The round's experiments (profiles/r03_notes.md) show the match phase bound by its chain of LDS round trips
-    between barriers and the parse by vector issue, not the kernel as a whole by either."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    instructions per launch from the committed PMC profile (SQ_INSTS_VALU of the same workload -- NOT counted in this run) over
+    this run's kernel time, as cycles per wave-instruction per SIMD, and the share of the CU's cycles its LDS is busy.
+    Dropped (None) when the profile was taken from other kernel sources than the ones running."""
+    from starflate_amd.build import source_stamp
+
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            meta = json.load(f).get("_meta", {})
+        if meta.get("csrc_sha256") != source_stamp()["csrc_sha256"] or not meta.get("pmc_summary"):
+            return None
+        with open(os.path.join(ROOT, "profiles", meta["pmc_summary"])) as f:
             d = json.load(f)
         for name, v in d.items():
             if kernel in name and "SQ_INSTS_VALU" in v:
-                insts = v["SQ_INSTS_VALU"] / max(v.get("pmc_dispatches", 1), 1) * (n / 2**30)
-                simds, cus, ghz = 1024, 256, 2.4
+                nd = max(v.get("pmc_dispatches", 1), 1)
+                insts = v["SQ_INSTS_VALU"] / nd * (n / 2**30)
+                cus = int(props["compute_units"])
+                simds, ghz = 4 * cus, props["clock_khz"] / 1e6
                 cycles = kernel_ms * 1e-3 * ghz * 1e9
-                lds = v.get("SQ_LDS_IDX_ACTIVE")
+                lds, conf = v.get("SQ_LDS_IDX_ACTIVE"), v.get("SQ_LDS_BANK_CONFLICT")
                 return {"bound": "mixed: LDS round trips between barriers (match phase), vector issue (parse, emit); not HBM",
-                        "valu_wave_instructions_per_launch": int(insts), "simds": simds, "clock_ghz": ghz,
+                        "valu_wave_instructions_per_launch": int(insts), "simds": simds, "clock_ghz": round(ghz, 3),
                         "cycles_per_instruction_per_simd": round(cycles / (insts / simds), 2),
-                        "instruction_cost_cycles": "2.3-2.9 (and/or/xor/add/sub/lshr/mov/bitop3), 4.1-4.5 (all other integer VALU) at 8 waves per SIMD: tools/micro/valu_ops.hip",
-                        "lds_busy_frac": round(lds / max(v.get("pmc_dispatches", 1), 1) * (n / 2**30) / cus / cycles, 3) if lds else None,
-                        "source": "profiles/r03_pmc_summary.json (instruction and LDS-cycle counts; not collected live) / this run's kernel time"}
+                        "lds_busy_frac": round(lds / nd * (n / 2**30) / cus / cycles, 3) if lds else None,
+                        "lds_bank_conflict_frac": round(conf / lds, 3) if lds and conf is not None else None,
+                        "commit": meta.get("commit"),
+                        "source": f"profiles/{meta['pmc_summary']} (instruction and LDS-cycle counts; not collected live) / this run's kernel time"}
     except Exception:  # noqa: BLE001
         pass
     return None
@@ -217,32 +233,77 @@ def self_launch(gpus):
     import socket
     import subprocess
 
+    import signal
+
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # only rank 0 prints the line; the other ranks' stdout goes to stderr so stdout stays one JSON line
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc, live = 0, set(range(gpus))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                print(f"bench.py: rank {r} exited with {code}; stopping the others", file=sys.stderr)
-                for o in live:  # exactly the processes started here
-                    procs[o].terminate()
-        if live:
-            time.sleep(0.05)
+    limit = float(os.environ.get("STARFLATE_BENCH_LAUNCH_TIMEOUT", "1500"))  # the parent never waits longer than this
+    grace = float(os.environ.get("STARFLATE_BENCH_KILL_GRACE", "5"))         # SIGTERM -> SIGKILL
+
+    def stop_all():
+        """terminate() exactly the rank processes started here, kill() what ignores it, reap everything."""
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        t_end = time.monotonic() + grace
+        for p in alive:
+            try:
+                p.wait(max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for p in alive:
+            try:
+                p.wait(grace)
+            except subprocess.TimeoutExpired:  # unkillable (stuck in the driver): nothing more a parent can do
+                print(f"bench.py: rank process {p.pid} did not exit after SIGKILL", file=sys.stderr)
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Stop(signum)
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
+    rc = 0
+    try:
+        for r in range(gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # only rank 0 prints the line; the other ranks' stdout goes to stderr so stdout stays one JSON line
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else sys.stderr))
+        live, t_end = set(range(gpus)), time.monotonic() + limit
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the others", file=sys.stderr)
+                    stop_all()
+                    live.clear()
+                    break
+            if live and time.monotonic() > t_end:
+                print(f"bench.py: ranks {sorted(live)} still running after {limit:.0f} s; stopping them", file=sys.stderr)
+                rc = 124
+                break
+            if live:
+                time.sleep(0.05)
+    except _Stop as e:
+        print(f"bench.py: signal {e.args[0]}; stopping the rank processes", file=sys.stderr)
+        rc = 128 + int(e.args[0])
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, signal.SIG_IGN)  # a second signal must not interrupt the clean-up
+        stop_all()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
 
 
@@ -449,19 +510,27 @@ def main():
     dom = max(stage_ms, key=stage_ms.get)
     alg_bytes = n + local_n  # read N + write C per launch of the path
     achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+    try:  # what hipDeviceProp_t says; `peak` stays the guide's figure
+        dp = _capi.device_props(local_rank)
+    except Exception as e:  # noqa: BLE001
+        dp = {"error": str(e)}
+    traffic, traffic_info = traffic_from_profile(dom, n)
+    text_default = args.effort == "default" and args.workload == "text" and not corpus and args.container == "raw" and not multi
+    if not text_default:  # the profile is of the default command: another workload's traffic is not in it
+        traffic, traffic_info = None, None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_from_profile": traffic_from_profile(dom),
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None, "traffic_info": traffic_info,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
                 "read_frac": round(n / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "issue": issue_from_profile(dom, stage_ms[dom], n) if args.effort == "default" and args.workload == "text" else None}
-    try:  # what hipDeviceProp_t implies; `peak` above stays the guide's figure
-        dp = _capi.device_props(local_rank)
-        roofline["device"] = {"name": dp["name"], "arch": dp["arch"], "compute_units": dp["compute_units"],
+                "issue": issue_from_profile(dom, stage_ms[dom], n, dp) if text_default and "error" not in dp else None}
+    if "error" in dp:
+        roofline["device"] = dp
+    else:
+        roofline["device"] = {"name": dp["name"], "arch": dp["arch"], "compute_units": dp["compute_units"], "clock_khz": dp.get("clock_khz"),
                               "memory_clock_khz": dp["memory_clock_khz"], "memory_bus_bits": dp["memory_bus_bits"],
                               # HBM3E moves 8 Gb/s per pin = 4 transfers per reported 2 GHz memory clock
                               "hbm_peak_from_props_GBs": round(4 * dp["memory_clock_khz"] * 1e3 * dp["memory_bus_bits"] / 8 / 1e9, 1)}
-    except Exception as e:  # noqa: BLE001
-        roofline["device"] = {"error": str(e)}
     kern_total_ms = sum(stage_ms.values())
 
     # ---- GPU decompress of the stream just made: the reference's own function, on the GPU ----

@@ -28,6 +28,20 @@ enum class CompressStatus : std::uint8_t {
 
 enum class BlockStrategy : std::uint8_t { Auto, Stored, Fixed, Dynamic };
 
+/// How hard the match finder looks (== enum sfh_effort of the C-ABI, value for value).
+///   Default : every other position searched, two history levels per hash bucket + the step-local candidate
+///   Fast    : the newer history level only, about 3 % more output
+///   Fastest : that, and no step-local candidate
+///   Thorough: every position searched
+///   Max     : Thorough with a second hash table keyed by seven bytes
+enum class Effort : std::uint8_t {
+  Default = SFH_EFFORT_DEFAULT,
+  Fast = SFH_EFFORT_FAST,
+  Fastest = SFH_EFFORT_FASTEST,
+  Thorough = SFH_EFFORT_THOROUGH,
+  Max = SFH_EFFORT_MAX,
+};
+
 struct compress_options {
   BlockStrategy strategy{BlockStrategy::Auto};
   bool final_stream{true};  // false: byte-aligned, non-final stream (a shard that is not the last)
@@ -35,10 +49,7 @@ struct compress_options {
   bool stored_fast_path{true};  // skip the search of a chunk whose first 8 KiB are (almost) all literals
   Container container{Container::Raw};  // Zlib / Gzip: wrapper + GPU-computed Adler-32 / CRC-32 (needs final_stream)
   int device{0};
-  bool fast{false};              // sfh_options.effort = SFH_EFFORT_FAST: fewer candidates per position, about 3 % more output
-  bool fastest{false};           // SFH_EFFORT_FASTEST: the newer history level only and no step-local candidate (wins over `fast`)
-  bool thorough{false};          // SFH_EFFORT_THOROUGH: every position is searched, not only the even ones (wins over both)
-  bool max{false};               // SFH_EFFORT_MAX: that, with a second hash table keyed by seven bytes (wins over all)
+  Effort effort{Effort::Default};  // sfh_options.effort
   std::uint32_t block_bytes{0};  // bytes coded independently of what precedes them: a multiple of 32768, 0 = default
                                  // (sfh_options.block_bytes); larger compresses better, 32768 = independent DEFLATE blocks
 };
@@ -76,7 +87,7 @@ inline auto to_c(const compress_options& o) -> sfh_options {
   c.no_stored_fast_path = o.stored_fast_path ? 0U : 1U;
   c.container = static_cast<std::uint32_t>(o.container);
   c.block_bytes = o.block_bytes;
-  c.effort = o.max ? SFH_EFFORT_MAX : o.thorough ? SFH_EFFORT_THOROUGH : o.fastest ? SFH_EFFORT_FASTEST : o.fast ? SFH_EFFORT_FAST : SFH_EFFORT_DEFAULT;
+  c.effort = static_cast<std::uint32_t>(o.effort);
   return c;
 }
 }  // namespace detail

@@ -101,7 +101,7 @@ typedef struct sfh_device_props {
   uint32_t l2_bytes;
   uint32_t memory_clock_khz;
   uint32_t memory_bus_bits;
-  uint32_t reserved;
+  uint32_t clock_khz;        /* clockRate: the shader clock bench.py turns kernel times into cycles with */
   uint64_t total_memory;
 } sfh_device_props;
 int sfh_get_device_props(int device, sfh_device_props* out);
@@ -110,7 +110,9 @@ void sfh_destroy(sfh_ctx* ctx);
 const char* sfh_last_error(const sfh_ctx* ctx);
 
 /* worst-case output bytes for n input bytes (any strategy, any container); block_bytes as in sfh_options
- * (SURVEY.md 8(b) signature; the bound is per 32 KiB DEFLATE block, so today it does not depend on it) */
+ * (SURVEY.md 8(b) signature).  The bound is per 32 KiB DEFLATE block and a strip is a whole number of those, so every
+ * valid block_bytes gives the same figure; a block_bytes the compress calls reject (not a multiple of 32768, or above
+ * 16 MiB) returns 0. */
 size_t sfh_compress_bound(size_t n, uint32_t block_bytes);
 
 /* Host buffers, synchronous.  *out_n = stream bytes.  Inside the call the input goes up, through the kernels and the

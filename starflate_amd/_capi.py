@@ -38,7 +38,7 @@ class Options(C.Structure):
 class DeviceProps(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("arch", C.c_char * 32), ("compute_units", C.c_uint32),
                 ("lds_bytes_per_cu", C.c_uint32), ("l2_bytes", C.c_uint32), ("memory_clock_khz", C.c_uint32),
-                ("memory_bus_bits", C.c_uint32), ("reserved", C.c_uint32), ("total_memory", C.c_uint64)]
+                ("memory_bus_bits", C.c_uint32), ("clock_khz", C.c_uint32), ("total_memory", C.c_uint64)]
 
 
 _LIB = None

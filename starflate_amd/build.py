@@ -44,3 +44,31 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+
+
+def source_stamp():
+    """What ties a measurement to the code it measured: the commit (git here; on a GPU box, which has no .git, the
+    `.commit_stamp` file the post-commit hook / tools/stamp_commit.sh leaves at the repo root) and a SHA-256 over the
+    kernel sources and the C-ABI header -- the same on both sides whatever the commit is called."""
+    import hashlib
+
+    root = os.path.dirname(PKG_DIR)
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(root, "include", "starflate_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    commit, dirty = None, None
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "starflate_amd/csrc", "include"],
+                                             stderr=subprocess.DEVNULL).decode().strip())
+    except Exception:  # noqa: BLE001  (no .git on the GPU box)
+        try:
+            with open(os.path.join(root, ".commit_stamp")) as fh:
+                commit = fh.read().strip() or None
+        except OSError:
+            pass
+    return {"commit": commit or "unknown", "dirty": dirty, "csrc_sha256": h.hexdigest()[:16]}

@@ -318,6 +318,7 @@ int sfh_get_device_props(int device, sfh_device_props* out) {
   out->l2_bytes = (uint32_t)p.l2CacheSize;
   out->memory_clock_khz = (uint32_t)p.memoryClockRate;
   out->memory_bus_bits = (uint32_t)p.memoryBusWidth;
+  out->clock_khz = (uint32_t)p.clockRate;
   out->total_memory = (uint64_t)p.totalGlobalMem;
   return SFH_OK;
 }
@@ -388,9 +389,11 @@ void sfh_destroy(sfh_ctx* ctx) {
 
 const char* sfh_last_error(const sfh_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
 
-size_t sfh_compress_bound(size_t n, uint32_t /*block_bytes*/) {
-  // per 32 KiB DEFLATE block: fixed-Huffman worst case (9 bits per literal) + headers + alignment block;
-  // the strip size does not enter (a strip is a whole number of such blocks)
+size_t sfh_compress_bound(size_t n, uint32_t block_bytes) {
+  // per 32 KiB DEFLATE block: fixed-Huffman worst case (9 bits per literal) + headers + alignment block.  A strip is a
+  // whole number of such blocks whatever block_bytes is, so a VALID block_bytes does not change the bound; one that
+  // sfh_compress would reject (not a multiple of 32 KiB, above 16 MiB) gives 0: no buffer size makes that call succeed
+  if (block_bytes && (block_bytes % sf::kChunk || block_bytes > sf::kMaxStrip)) return 0;
   const size_t nchunks = n ? (n + sf::kChunk - 1) / sf::kChunk : 1;
   return nchunks * (size_t)(sf::kChunk + sf::kChunk / 8 + 640);
 }

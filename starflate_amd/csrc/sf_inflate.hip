@@ -34,10 +34,7 @@ namespace {
 constexpr uint32_t KT_LANES = 4;
 constexpr uint32_t KT_LDS = KT_LANES * inflate::LaneLayout::kBytes;
 constexpr uint32_t KB_THREADS = 512;
-#ifndef X_KB_TPT
-#define X_KB_TPT 3
-#endif
-constexpr uint32_t KB_TPT = X_KB_TPT;     // tokens per thread per step
+constexpr uint32_t KB_TPT = 3;      // tokens per thread per step (2: 4.5 ms per GiB, 3: 3.75, 4: scratch)
 constexpr uint32_t KB_SPAN = 3968;  // output bytes per step (pointer array)
 constexpr uint32_t KB_AUX = 2 * KB_SPAN + 4 * KB_THREADS * KB_TPT + 8 * (KB_SPAN / 32) + 64;
 constexpr uint32_t KB_RING = kWindow + 4096;             // the window + the step in flight (KB_SPAN bytes at most)

@@ -130,6 +130,9 @@ constexpr uint32_t K1_LDS = L_DSYM + 512;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
 static_assert(L_WTOT % 16 == 0 && L_TABLE % 16 == 0 && L_LEN4 % 16 == 0 && L_HIST % 16 == 0, "LDS alignment");
 static_assert(kCap - 3 <= 15, "capped len-3 fits four bits");
+// the round's distances are staged in the chunk's own item array (k_lz77, match phase): a chunk never holds more items
+// than positions, because a literal is one item and a match, two items, covers at least two positions
+static_assert(kMinMatch >= 2, "distance staging: items <= positions");
 static_assert((kWindow + kLook) % 16 == 0 && kRound % 16 == 0, "window shift in 16-byte units");
 
 // v_ffbl_b32 as the hardware defines it: the lowest set bit, 0xFFFFFFFF for 0 (spelled out, because the C
@@ -539,7 +542,8 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
                 // LDS address 0: it is the kernel's only __shared__ object)
                 uint32_t v = len4;
                 v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
-                asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
+                // (the store is invisible to the compiler's counter tracking: waited for here, ahead of the barrier behind it)
+                asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
                              :: "v"((sb + tp) >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
               }
             }

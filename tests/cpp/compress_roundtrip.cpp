@@ -178,6 +178,26 @@ auto main(int argc, char** argv) -> int {
     bad.block_bytes = 1000;
     const auto nb = gpu.compress(html, comp, bad);
     if (nb || nb.error() != CompressStatus::InvalidArgument) { std::printf("expected InvalidArgument for block_bytes\n"); ++fail; }
+    if (compress_bound(html.size(), 1000) != 0) { std::printf("compress_bound of an invalid block_bytes\n"); ++fail; }
+    // compress_options::effort mirrors enum sfh_effort: every level round-trips; Max is the smallest, Fastest the largest
+    static_assert(static_cast<int>(Effort::Max) == SFH_EFFORT_MAX && static_cast<int>(Effort::Fastest) == SFH_EFFORT_FASTEST);
+    std::size_t size_of[5] = {};
+    for (const Effort e : {Effort::Default, Effort::Fast, Effort::Fastest, Effort::Thorough, Effort::Max}) {
+      compress_options eo;
+      eo.effort = e;
+      const auto ne = gpu.compress(html, comp, eo);
+      std::vector<std::byte> eb(html.size());
+      if (!ne || decompress(std::span{comp}.first(*ne), eb) != DecompressStatus::Success || eb != html) {
+        std::printf("effort %d: round trip\n", static_cast<int>(e));
+        ++fail;
+      } else {
+        size_of[static_cast<int>(e)] = *ne;
+      }
+    }
+    if (!(size_of[SFH_EFFORT_MAX] <= size_of[SFH_EFFORT_DEFAULT] && size_of[SFH_EFFORT_DEFAULT] <= size_of[SFH_EFFORT_FASTEST])) {
+      std::printf("effort: sizes out of order\n");
+      ++fail;
+    }
   }
   std::printf("compress_roundtrip: %d failures\n", fail);
   return fail ? 1 : 0;

@@ -49,3 +49,53 @@ def test_bench_input_file(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip())
     assert "alice29.txt" in d["config"]["workload"] and d["roundtrip_ok"] is True
+
+
+def _children(pid):
+    import psutil
+
+    try:
+        return psutil.Process(pid).children(recursive=True)
+    except psutil.NoSuchProcess:
+        return []
+
+
+def test_bench_self_launch_stops_its_ranks_when_signalled():
+    """The launcher must not leave rank processes behind (on a GPU box they would sit on the GPUs, possibly inside an RCCL
+    collective): SIGTERM to the parent terminates every rank it started, and it exits non-zero."""
+    import signal
+    import time
+
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--bytes", str(1 << 20), "--rounds", "2",
+                          "--steps", "1000000", "--warmup", "0"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        t_end = time.monotonic() + 60
+        kids = []
+        while time.monotonic() < t_end and len(kids) < 2:
+            time.sleep(0.2)
+            kids = _children(p.pid)
+        assert len(kids) >= 2, "the launcher did not start its ranks"
+        time.sleep(2.0)  # let them get into the step loop
+        p.send_signal(signal.SIGTERM)
+        rc = p.wait(timeout=60)
+        assert rc == 128 + signal.SIGTERM
+        t_end = time.monotonic() + 10
+        while time.monotonic() < t_end and any(k.is_running() and k.status() != "zombie" for k in kids):
+            time.sleep(0.1)
+        assert not any(k.is_running() and k.status() != "zombie" for k in kids), "rank processes survived the launcher"
+    finally:
+        for k in _children(p.pid):
+            k.kill()
+        if p.poll() is None:
+            p.kill()
+
+
+def test_bench_self_launch_has_a_deadline():
+    """A rank that never finishes (stuck in the driver, say) must not make the parent spin for ever."""
+    r = _run("--gpus", "2", "--backend", "gloo", "--bytes", str(1 << 20), "--rounds", "2", "--steps", "1000000", "--warmup", "0",
+             env={"STARFLATE_BENCH_LAUNCH_TIMEOUT": "8", "STARFLATE_BENCH_KILL_GRACE": "2"})
+    assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
+    assert "still running" in r.stderr

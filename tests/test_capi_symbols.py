@@ -36,6 +36,9 @@ def test_host_side_entry_points_without_gpu():
         assert lib.sfh_compress_bound(0, bb) == 32768 + 4096 + 640
         assert lib.sfh_compress_bound(32768, bb) == 32768 + 4096 + 640
         assert lib.sfh_compress_bound(32769, bb) == 2 * (32768 + 4096 + 640)
+    for bb in (1000, 32768 + 1, (16 << 20) + 32768):  # what sfh_compress rejects has no bound
+        assert lib.sfh_compress_bound(32768, bb) == 0
+    assert lib.sfh_compress_bound(1 << 20, 16 << 20) == 32 * (32768 + 4096 + 640)
     assert _capi.resolve_block_bytes(0, 1 << 30) == 262144 and _capi.resolve_block_bytes(0, 1 << 20) == 32768
     import oracle_lib as O  # the specification's rule for strip_bytes = 0 is the library's for block_bytes = 0
 

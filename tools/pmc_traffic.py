@@ -2,19 +2,20 @@
 """profiles/<tag>_pmc_summary.json -> profiles/pmc_traffic.json (HBM bytes per launch per kernel).
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide
 (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM section), so reads are doubled.
-Every dispatch of the profiled command processes the same 1 GiB, so per launch = sum / dispatches."""
+Every dispatch of the profiled command processes the same 1 GiB, so per launch = sum / dispatches.
+_meta ties the numbers to the code: the commit (.commit_stamp on the GPU box) and a SHA-256 over the kernel
+sources, which bench.py recomputes and compares before it quotes the traffic."""
 import json
+import os
 import sys
 
-import subprocess
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from starflate_amd.build import source_stamp  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
 d = json.load(open(src))
-try:
-    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-except Exception:  # noqa: BLE001  (the GPU box has no .git: the caller fills it in)
-    commit = "unknown"
-out = {"_meta": {"commit": commit, "source": src, "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary"}}
+out = {"_meta": dict(source_stamp(), source=src, bytes_per_launch=1 << 30,
+                     command="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary")}
 for name, v in d.items():
     if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue
