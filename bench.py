@@ -583,6 +583,21 @@ def main():
                        "H2D of batch b beside the kernels of batch b-1 beside the D2H of batch b-2's stream bytes"}
         del hin, hout
         others = {w: secondary_workload(comp, w, args.secondary_bytes, dev, 0) for w in ("text", "mixed", "random", "runs") if w != args.workload}
+        # REAL bytes (starflate_amd/realbytes.py): source text and x86-64 machine code from files of this image -- the
+        # generators above have no long-range structure, these do (ratio_vs_zlib6 on real data is what a user will see)
+        from starflate_amd import realbytes
+
+        for key, buf, what in (("real_source", realbytes.source(96 << 20), "Python / C++ source text (stdlib, torch, ROCm headers)"),
+                               ("real_binary", realbytes.binary(min(args.secondary_bytes, 256 << 20)), "x86-64 code + data (head of libtorch_cpu.so)")):
+            nb = buf.size // (1 << 20) * (1 << 20)  # whole MiB: a multiple of every strip size the default rule picks here
+            if nb < (8 << 20):
+                others[key] = {"skipped": f"{what}: not in this image"}
+                continue
+            t = torch.from_numpy(buf[:nb]).to(dev)
+            for eff in ("default", "thorough", "max"):
+                others[key if eff == "default" else f"{key}_effort_{eff}"] = secondary_workload(
+                    comp, key, nb, dev, 0, effort=eff, data=t, wl=realbytes.describe(buf[:nb], what))
+            del t
         # the same bytes at sfh_options.effort = SFH_EFFORT_FAST (one history level per hash bucket)
         others["effort_fast"] = secondary_workload(comp, args.workload, n, dev, bb, effort="fast", data=data, wl=wl)
         # and at SFH_EFFORT_FASTEST (that, and no step-local candidate)

@@ -110,3 +110,52 @@ def test_bench_generators_under_stage_parity(compressor, workload):
     assert np.array_equal(got, want)
     st, w, back = O.decompress(got, n)
     assert st == 0 and w == n and np.array_equal(back, data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["source", "binary"])
+def test_real_bytes_bit_exact(compressor, kind):
+    """Real bytes, not a generator's (starflate_amd/realbytes.py; the reference's precedent is its one real file,
+    /root/reference/src/test/decompress_test.cpp:136-174): a 4 MiB slice of source text and of machine code, bit-exact
+    against the oracle's encoder specification at two efforts, round-tripped through the oracle's restatement of the
+    reference decoder and through zlib, and through the GPU decoder."""
+    import zlib
+
+    import numpy as np
+
+    import oracle_lib as O
+    from starflate_amd import realbytes
+
+    buf = realbytes.source(24 << 20) if kind == "source" else realbytes.binary(40 << 20)
+    if buf.size < (8 << 20):
+        pytest.skip(f"no {kind} corpus in this image")
+    off = (buf.size // 2) & ~0xFFFF
+    data = buf[off: off + (4 << 20) + 4321]  # ragged tail
+    for effort, kw in (("default", {}), ("thorough", dict(stride2=0, step=512))):
+        got = np.frombuffer(compressor.compress(data, effort=effort), np.uint8)
+        want = O.compress(data, O.default_params(**kw))
+        assert got.size == want.size and np.array_equal(got, want), (kind, effort)
+        st, w, back = O.decompress(got, data.size)
+        assert st == 0 and w == data.size and np.array_equal(back, data)
+        assert zlib.decompress(bytes(got), -15) == data.tobytes()
+        gback, gst = compressor.decompress(got, compressor.last_index(), data.size, subindex=compressor.last_subindex(),
+                                           block_bytes=compressor.last_block_bytes())
+        assert gst == 0 and gback == data.tobytes()
+
+
+def test_real_bytes_are_deterministic():
+    """The corpus builder gives the same bytes twice (sorted walk), and they are not a generator's: source text is mostly
+    printable, machine code starts with the ELF magic."""
+    import numpy as np
+
+    from starflate_amd import realbytes
+
+    a = realbytes.source(2 << 20)
+    realbytes._CACHE.clear()
+    b = realbytes.source(2 << 20)
+    assert a.size == b.size and np.array_equal(a, b)
+    if a.size:
+        assert a[:4].tobytes() == b"==> " and np.mean((a >= 9) & (a < 127)) > 0.95
+    e = realbytes.binary(1 << 20)
+    if e.size:
+        assert e[:4].tobytes() == b"\x7fELF"

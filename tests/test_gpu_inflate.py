@@ -166,6 +166,34 @@ def test_inflate_zlib_made_indexed_streams(compressor, starfleet, level, strateg
         assert status == 0 and got == data.tobytes(), (name, "strips")
 
 
+@pytest.mark.parametrize("name", ["starfleet.html.dynamic.flushed", "starfleet.html.fixed.flushed"])
+def test_inflate_reference_made_fixture(compressor, starfleet, name):
+    """Reference-held bytes through the HIP decoder: the file the reference's own test decodes
+    (/root/reference/src/test/decompress_test.cpp:136-174), compressed with its fixture tool's zlib settings and a
+    Z_FULL_FLUSH every 32 KiB (tests/golden/make_golden.py; committed with its index).  The GPU decoder must return what the
+    oracle's restatement of the reference decoder returns for the same stream: the file."""
+    import os
+
+    from conftest import GOLDEN
+
+    with open(os.path.join(GOLDEN, name), "rb") as f:
+        stream = f.read()
+    index = np.fromfile(os.path.join(GOLDEN, name + ".index"), dtype="<u8").astype(np.uint64)
+    st, w, want = O.decompress(np.frombuffer(stream, np.uint8), len(starfleet))
+    assert st == 0 and w == len(starfleet) and want.tobytes() == starfleet
+    got, status = compressor.decompress(stream, index, len(starfleet), block_bytes=32768)
+    assert status == 0 and got == starfleet
+    # device-resident call, and a truncated segment reports an error instead of bytes
+    import torch
+
+    gback, gst = compressor.decompress_tensor(torch.frombuffer(bytearray(stream), dtype=torch.uint8).cuda(),
+                                              torch.from_numpy(index.astype(np.int64)).cuda(), len(starfleet), block_bytes=32768)
+    assert gst == 0 and gback.cpu().numpy().tobytes() == starfleet
+    cut = index.copy()
+    cut[-1] -= np.uint64(40)
+    assert compressor.decompress(stream[:-40], cut, len(starfleet), block_bytes=32768)[1] != 0
+
+
 def test_malformed_segments_report_reference_statuses(compressor, starfleet):
     data = np.frombuffer(starfleet, np.uint8)
     nseg = (data.size + CHUNK - 1) // CHUNK

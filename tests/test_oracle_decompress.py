@@ -112,6 +112,21 @@ def test_reference_fixtures(starfleet, name, btype):
 
 
 # ---- :176-181 ----
+@pytest.mark.parametrize("name", ["starfleet.html.dynamic.flushed", "starfleet.html.fixed.flushed"])
+def test_reference_fixtures_flushed(starfleet, name):
+    """The reference's fixture settings with Z_FULL_FLUSH every 32 KiB (tests/golden/make_golden.py): one valid stream for
+    the serial decoder, and every indexed segment decodes on its own to its 32 KiB of the file."""
+    with open(os.path.join(GOLDEN, name), "rb") as f:
+        stream = np.frombuffer(f.read(), np.uint8)
+    index = np.fromfile(os.path.join(GOLDEN, name + ".index"), dtype="<u8")
+    assert index[0] == 0 and index[-1] == stream.size and index.size == (len(starfleet) + 32767) // 32768 + 1
+    st, w, out = O.decompress(stream, len(starfleet))
+    assert st == 0 and w == len(starfleet) and out.tobytes() == starfleet
+    for k in range(index.size - 1):
+        seg = starfleet[k * 32768:(k + 1) * 32768]
+        assert zlib.decompressobj(-15).decompress(stream[int(index[k]):int(index[k + 1])].tobytes()) == seg
+
+
 def test_copy_from_before():
     buf = np.array([1, 2, 0, 0, 0, 0], np.uint8)
     O.lib().sfo_copy_from_before(2, buf.ctypes.data + 2, 3)

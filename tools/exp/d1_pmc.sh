@@ -2,8 +2,8 @@
 # PMC counters of the decoder kernels (development aid): bash tools/exp/d1_pmc.sh
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 out=gpurun_out/d1pmc; rm -rf $out; mkdir -p $out
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $out/p1 -- python tools/d1_time.py > $out/p1.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $out/p2 -- python tools/d1_time.py > $out/p2.log 2>&1
+bash tools/pmc_run.sh $out/p1 300 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" -- python tools/d1_time.py > $out/p1.log 2>&1
+bash tools/pmc_run.sh $out/p2 300 "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SMEM SQ_WAVES" -- python tools/d1_time.py > $out/p2.log 2>&1
 python - <<'P'
 import csv,glob,collections,re
 for d in ('p1','p2'):

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 for name in "$@"; do
   out=gpurun_out/pmcf_$name; rm -rf $out; mkdir -p $out
   export SFH_LIB="$PWD/build/variants/lib_$name.so"
-  timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/p -- python bench.py --bytes 268435456 --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --no-decompress > $out/log 2>&1
+  bash tools/pmc_run.sh $out/p 150 "FETCH_SIZE" -- python bench.py --bytes 268435456 --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --no-decompress > $out/log 2>&1
   python - "$out" "$name" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(float); cnt = 0

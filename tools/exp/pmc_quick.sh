@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 out=gpurun_out/pmcq_$tag
 rm -rf $out; mkdir -p $out
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/p -- python bench.py --bytes 268435456 --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --no-decompress "$@" > $out/log 2>&1
+bash tools/pmc_run.sh $out/p 300 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" -- python bench.py --bytes 268435456 --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --no-decompress "$@" > $out/log 2>&1
 python - "$out" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()

@@ -14,7 +14,7 @@ from starflate_amd.build import source_stamp  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
 d = json.load(open(src))
-out = {"_meta": dict(source_stamp(), source=src, bytes_per_launch=1 << 30,
+out = {"_meta": dict(source_stamp(), source=src, bytes_per_launch=1 << 30, pmc_summary=(sys.argv[3] if len(sys.argv) > 3 else os.path.basename(src)),
                      command="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary")}
 for name, v in d.items():
     if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
