@@ -24,6 +24,7 @@ enum class CompressStatus : std::uint8_t {
   NoDevice,     // no MI355X visible: there is no CPU fallback
   DeviceError,
   OutOfMemory,
+  CommError,    // RCCL not loadable, or an RCCL call failed (gather_streams)
 };
 
 enum class BlockStrategy : std::uint8_t { Auto, Stored, Fixed, Dynamic };
@@ -75,6 +76,7 @@ inline auto to_status(int rc) -> CompressStatus {
     case SFH_E_NO_DEVICE: return CompressStatus::NoDevice;
     case SFH_E_HIP: return CompressStatus::DeviceError;
     case SFH_E_NOMEM: return CompressStatus::OutOfMemory;
+    case SFH_E_COMM: return CompressStatus::CommError;
     default: return CompressStatus::InvalidArgument;
   }
 }
@@ -161,6 +163,34 @@ class compressor {
     const int rc = sfh_compress_device(ctx_, d_src, n, d_dst, cap, &out, &c, stream);
     if (rc != SFH_OK) return compat::unexpected{detail::to_status(rc)};
     return out;
+  }
+  /// enqueue only: the stream size is left in *d_out_n, a device word (what gather_streams reads)
+  auto compress_device_async(const void* d_src, std::size_t n, void* d_dst, std::size_t cap, std::uint64_t* d_out_n,
+                             const compress_options& opt = {}, void* stream = nullptr) -> CompressStatus {
+    if (!ctx_) return init_;
+    const auto c = detail::to_c(opt);
+    return detail::to_status(sfh_compress_device_async(ctx_, d_src, n, d_dst, cap, d_out_n, &c, stream));
+  }
+
+  /// One process per GPU: what every rank of an RCCL communicator calls after compressing its shard (whole strips,
+  /// final_stream = false on every rank but the last).  The byte-aligned streams are put back to back, in rank order, at
+  /// d_out + base on `root`: one ncclAllGather of the sizes, then one point-to-point transfer per peer (no ring, no
+  /// all-reduce) -- legal because a match only has to stay inside the bytes already written
+  /// (/root/reference/src/decompress.cpp:178) and blocks simply follow one another until BFINAL (:410-415).
+  /// nccl_comm: an ncclComm_t.  base / cap: the root's (bytes already in d_out, its capacity), the same on every rank.
+  /// Returns the end of the concatenation; `sizes` (optional) receives every rank's stream size.
+  auto gather_streams(void* nccl_comm, int root, const void* d_stream, const std::uint64_t* d_size, void* d_out, std::uint64_t base,
+                      std::uint64_t cap, void* stream = nullptr, std::vector<std::uint64_t>* sizes = nullptr)
+      -> compat::expected<std::uint64_t, CompressStatus> {
+    if (!ctx_) return compat::unexpected{init_};
+    int nranks = 0, rank = 0;
+    if (const int rc = sfh_comm_ranks(nccl_comm, &nranks, &rank); rc != SFH_OK) return compat::unexpected{detail::to_status(rc)};
+    std::vector<std::uint64_t> local(static_cast<std::size_t>(nranks));
+    std::uint64_t end = 0;
+    const int rc = sfh_gather_streams(ctx_, nccl_comm, root, d_stream, d_size, d_out, base, cap, local.data(), &end, stream);
+    if (rc != SFH_OK) return compat::unexpected{detail::to_status(rc)};
+    if (sizes != nullptr) *sizes = std::move(local);
+    return end;
   }
 };
 

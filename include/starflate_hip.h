@@ -36,7 +36,8 @@ enum sfh_status {
   SFH_E_DST_TOO_SMALL = -2, /* cap < sfh_compress_bound(n) -- mirrors DecompressStatus::DstTooSmall */
   SFH_E_NO_DEVICE = -3,     /* no HIP device / device index out of range */
   SFH_E_HIP = -4,           /* a HIP runtime call failed; see sfh_last_error() */
-  SFH_E_NOMEM = -5          /* device scratch allocation failed */
+  SFH_E_NOMEM = -5,         /* device scratch allocation failed */
+  SFH_E_COMM = -6           /* RCCL not loadable, or an RCCL call failed; see sfh_last_error() */
 };
 
 /* block strategy (inverse of src/decompress.cpp:416-458 dispatch) */
@@ -129,6 +130,31 @@ int sfh_compress(sfh_ctx* ctx, const void* src, size_t n, void* dst, size_t cap,
  * devices and combined).  The block index of the whole stream is not assembled (use the per-ctx ones). */
 int sfh_compress_multi(sfh_ctx* const* ctxs, int nctx, const void* src, size_t n, void* dst, size_t cap,
                        size_t* out_n, const sfh_options* opt);
+
+/* One process PER GPU (north_star: "RCCL over xGMI only to concatenate the independently-encoded
+ * block streams"): every rank compresses its own shard -- whole strips, final_stream = 0 on every rank but the last -- and
+ * the byte-aligned streams are put back to back on rank `root`.  No data-path collective: shard legality is
+ * /root/reference/src/decompress.cpp:178 (a match only has to stay inside the bytes already written) and :410-415
+ * (blocks until BFINAL).
+ *
+ * sfh_gather_offsets: the host arithmetic.  offsets[r] = first byte of rank r's stream in the concatenation that starts
+ * at `base`, offsets[nranks] = its end; SFH_E_DST_TOO_SMALL when that exceeds cap, SFH_E_INVALID_ARG on overflow.
+ *
+ * sfh_gather_streams: called by EVERY rank of `nccl_comm` (an ncclComm_t of RCCL, passed as a plain pointer; RCCL is bound
+ * with dlopen at the first call, so the library itself does not link it).  d_stream / d_size: this rank's stream and its
+ * byte count ON THE DEVICE, as sfh_compress_device_async leaves them.  One ncclAllGather of the u64 sizes, one read-back of
+ * them (h_sizes[nranks], every rank: the transfers need host counts), then ONE grouped round of ncclSend / ncclRecv --
+ * each peer's bytes travel once, point to point over their own xGMI link, straight to d_out + offsets[peer] on the
+ * root; the root's own stream is a device copy (none when it already lies at its place).  Everything is enqueued on
+ * `stream`, which is synchronised once, for the sizes; the call returns with the transfers in flight.  *out_end (every
+ * rank) = end of the concatenation.  d_out is only read on the root; `base` and `cap` (the root's: bytes already in d_out,
+ * its capacity) are passed alike by every rank, so that all ranks refuse together -- before anything is posted -- when the
+ * streams do not fit. */
+int sfh_gather_offsets(const uint64_t* sizes, int nranks, uint64_t base, uint64_t cap, uint64_t* offsets);
+/* ranks of the communicator and this process's rank in it (ncclCommCount / ncclCommUserRank through the same binding) */
+int sfh_comm_ranks(void* nccl_comm, int* nranks, int* rank);
+int sfh_gather_streams(sfh_ctx* ctx, void* nccl_comm, int root, const void* d_stream, const uint64_t* d_size, void* d_out,
+                       uint64_t base, uint64_t cap, uint64_t* h_sizes, uint64_t* out_end, void* stream);
 
 /* Device buffers (d_src 16-byte aligned), enqueued on `stream` (a hipStream_t,
  * NULL = the ctx's own stream); synchronises the stream and returns the size. */

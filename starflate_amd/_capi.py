@@ -26,6 +26,7 @@ EXPORTS = [
     "sfh_last_block_bytes", "sfh_index_entries", "sfh_copy_index", "sfh_copy_subindex", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms",
     "sfh_inflate_stage_name", "sfh_checksum_device", "sfh_crc32_combine", "sfh_adler32_combine",
     "sfh_set_profiling", "sfh_last_stage_ms", "sfh_stage_name", "sfh_debug_read",
+    "sfh_gather_offsets", "sfh_gather_streams", "sfh_comm_ranks",
 ]
 
 
@@ -86,6 +87,12 @@ def lib():
     L.sfh_compress_device.restype = C.c_int
     L.sfh_compress_device_async.argtypes = [vp, vp, sz, vp, sz, vp, C.POINTER(Options), vp]
     L.sfh_compress_device_async.restype = C.c_int
+    L.sfh_gather_offsets.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sfh_gather_offsets.restype = C.c_int
+    L.sfh_comm_ranks.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.sfh_comm_ranks.restype = C.c_int
+    L.sfh_gather_streams.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
+    L.sfh_gather_streams.restype = C.c_int
     L.sfh_last_block_bytes.argtypes = [vp]
     L.sfh_last_block_bytes.restype = C.c_uint32
     L.sfh_index_entries.argtypes = [vp]

@@ -3,6 +3,7 @@
 #include "../../include/starflate_hip.h"
 #include "sf_device.h"
 
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -50,6 +51,9 @@ struct sfh_ctx {
   hipEvent_t ev_done = nullptr;  // end of the last call's device work: the next call, on any stream, starts behind it
   bool busy = false;             // (the device scratch is shared by all calls on this ctx)
   hipStream_t last_stream = nullptr;
+  uint64_t* d_sizes = nullptr;   // sfh_gather_streams: the ranks' sizes on the device and in pinned memory
+  uint64_t* h_sizes = nullptr;
+  int sizes_cap = 0;
   char err[256] = {0};
 };
 
@@ -289,6 +293,61 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
 
 }  // namespace
 
+// ---- one process per GPU: concatenation over RCCL (bound at run time: a host without RCCL still loads the library) ----
+namespace {
+struct Rccl {
+  // the subset of rccl.h this file calls (ncclResult_t is an int, ncclComm_t an opaque pointer, ncclUint8 = 1, ncclUint64 = 5)
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*CommCount)(const void*, int*) = nullptr;
+  int (*CommUserRank)(const void*, int*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  char why[160] = {0};
+};
+const Rccl& rccl() {
+  static const Rccl r = [] {
+    Rccl x;
+    void* h = nullptr;
+    // the copy that is in the process already wins (a torch process has loaded its own librccl.so): two RCCLs, like two
+    // HIP runtimes, must not serve one communicator
+    const char* env = getenv("SFH_RCCL_LIB");
+    const char* names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names)
+      if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names)
+      if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      snprintf(x.why, sizeof x.why, "librccl.so not found (%s)", dlerror());
+      return x;
+    }
+    auto sym = [&](const char* s) { return dlsym(h, s); };
+    x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
+    x.Send = (decltype(x.Send))sym("ncclSend");
+    x.Recv = (decltype(x.Recv))sym("ncclRecv");
+    x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");
+    x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
+    x.CommCount = (decltype(x.CommCount))sym("ncclCommCount");
+    x.CommUserRank = (decltype(x.CommUserRank))sym("ncclCommUserRank");
+    x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+    x.ok = x.AllGather && x.Send && x.Recv && x.GroupStart && x.GroupEnd && x.CommCount && x.CommUserRank;
+    if (!x.ok) snprintf(x.why, sizeof x.why, "librccl.so lacks an ncclAllGather / ncclSend / ncclRecv / ncclGroup* symbol");
+    return x;
+  }();
+  return r;
+}
+int comm_fail(sfh_ctx* ctx, const char* what, int code) {
+  const Rccl& R = rccl();
+  if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, R.GetErrorString ? R.GetErrorString(code) : "RCCL error");
+  return SFH_E_COMM;
+}
+constexpr int kNcclUint8 = 1, kNcclUint64 = 5;
+}  // namespace
+
+
 extern "C" {
 
 void sfh_default_options(sfh_options* o) {
@@ -383,6 +442,8 @@ void sfh_destroy(sfh_ctx* ctx) {
   if (ctx->s_in) (void)hipStreamDestroy(ctx->s_in);
   if (ctx->s_out) (void)hipStreamDestroy(ctx->s_out);
   if (ctx->h_tot) (void)hipHostFree(ctx->h_tot);
+  (void)hipFree(ctx->d_sizes);
+  if (ctx->h_sizes) (void)hipHostFree(ctx->h_sizes);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -678,6 +739,81 @@ int sfh_compress_multi(sfh_ctx* const* ctxs, int nctx, const void* src, size_t n
     pos += 8;
   }
   *out_n = pos;
+  return SFH_OK;
+}
+
+// ---- one process per GPU: concatenation over RCCL (binding: struct Rccl above) ----
+int sfh_gather_offsets(const uint64_t* sizes, int nranks, uint64_t base, uint64_t cap, uint64_t* offsets) {
+  if (!sizes || !offsets || nranks <= 0) return SFH_E_INVALID_ARG;
+  uint64_t at = base;
+  for (int r = 0; r < nranks; ++r) {
+    offsets[r] = at;
+    if (sizes[r] > UINT64_MAX - at) return SFH_E_INVALID_ARG;
+    at += sizes[r];
+  }
+  offsets[nranks] = at;
+  return at > cap ? SFH_E_DST_TOO_SMALL : SFH_OK;
+}
+
+int sfh_comm_ranks(void* nccl_comm, int* nranks, int* rank) {
+  if (!nccl_comm || !nranks || !rank) return SFH_E_INVALID_ARG;
+  const Rccl& R = rccl();
+  if (!R.ok || R.CommCount(nccl_comm, nranks) != 0 || R.CommUserRank(nccl_comm, rank) != 0) return SFH_E_COMM;
+  return SFH_OK;
+}
+
+int sfh_gather_streams(sfh_ctx* ctx, void* nccl_comm, int root, const void* d_stream, const uint64_t* d_size, void* d_out,
+                       uint64_t base, uint64_t cap, uint64_t* h_sizes, uint64_t* out_end, void* stream) {
+  if (!ctx || !nccl_comm || !d_stream || !d_size || !h_sizes || !out_end) return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
+  const Rccl& R = rccl();
+  if (!R.ok) {
+    snprintf(ctx->err, sizeof ctx->err, "%s", R.why);
+    return SFH_E_COMM;
+  }
+  int nranks = 0, rank = -1, rc;
+  if ((rc = R.CommCount(nccl_comm, &nranks)) != 0) return comm_fail(ctx, "ncclCommCount", rc);
+  if ((rc = R.CommUserRank(nccl_comm, &rank)) != 0) return comm_fail(ctx, "ncclCommUserRank", rc);
+  if (root < 0 || root >= nranks || (rank == root && !d_out)) return fail(ctx, SFH_E_INVALID_ARG, "root / d_out", hipSuccess);
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  if (ctx->sizes_cap < nranks) {
+    (void)hipFree(ctx->d_sizes);
+    (void)hipHostFree(ctx->h_sizes);
+    ctx->d_sizes = ctx->h_sizes = nullptr;
+    ctx->sizes_cap = 0;
+    SF_HIP(hipMalloc(&ctx->d_sizes, (size_t)nranks * sizeof(uint64_t)), "sizes");
+    SF_HIP(hipHostMalloc((void**)&ctx->h_sizes, (size_t)nranks * sizeof(uint64_t), hipHostMallocDefault), "pinned sizes");
+    ctx->sizes_cap = nranks;
+  }
+  // the compressor may have run on another stream of this ctx: its size word is final behind ev_done
+  rc = order_behind_last_call(ctx, s);
+  if (rc) return rc;
+  if ((rc = R.AllGather(d_size, ctx->d_sizes, 1, kNcclUint64, nccl_comm, s)) != 0) return comm_fail(ctx, "ncclAllGather", rc);
+  SF_HIP(hipMemcpyAsync(ctx->h_sizes, ctx->d_sizes, (size_t)nranks * sizeof(uint64_t), hipMemcpyDeviceToHost, s), "sizes read-back");
+  SF_HIP(hipStreamSynchronize(s), "stream sync");
+  std::vector<uint64_t> off((size_t)nranks + 1);
+  for (int r = 0; r < nranks; ++r) h_sizes[r] = ctx->h_sizes[r];
+  // every rank judges the same numbers (base and cap are the root's, passed alike by all), so every rank returns the same
+  // verdict BEFORE any transfer is posted: nobody is left waiting in a send whose receive was refused
+  rc = sfh_gather_offsets(h_sizes, nranks, base, cap, off.data());
+  *out_end = off[(size_t)nranks];
+  if (rc != SFH_OK) return fail(ctx, rc, "sfh_gather_streams: the gathered streams do not fit cap", hipSuccess);
+  if (rank != root) {
+    if (h_sizes[rank] && (rc = R.Send(d_stream, (size_t)h_sizes[rank], kNcclUint8, root, nccl_comm, s)) != 0) return comm_fail(ctx, "ncclSend", rc);
+    return SFH_OK;
+  }
+  uint8_t* out = (uint8_t*)d_out;
+  if ((rc = R.GroupStart()) != 0) return comm_fail(ctx, "ncclGroupStart", rc);
+  for (int r = 0; r < nranks; ++r) {
+    if (r == root || !h_sizes[r]) continue;
+    if ((rc = R.Recv(out + off[(size_t)r], (size_t)h_sizes[r], kNcclUint8, r, nccl_comm, s)) != 0) {
+      (void)R.GroupEnd();
+      return comm_fail(ctx, "ncclRecv", rc);
+    }
+  }
+  if ((rc = R.GroupEnd()) != 0) return comm_fail(ctx, "ncclGroupEnd", rc);
+  if (h_sizes[root] && (const uint8_t*)d_stream != out + off[(size_t)root])
+    SF_HIP(hipMemcpyAsync(out + off[(size_t)root], d_stream, (size_t)h_sizes[root], hipMemcpyDeviceToDevice, s), "own stream");
   return SFH_OK;
 }
 

@@ -44,6 +44,14 @@ def test_host_side_entry_points_without_gpu():
 
     for n in (0, 1, 32768, 8 << 20, (8 << 20) + 1, 16 << 20, 64 << 20, (64 << 20) - 1, 1 << 30, 5 << 30):
         assert _capi.resolve_block_bytes(0, n) == O.resolve_strip_bytes(O.default_params(), n), n
+    # sfh_gather_offsets: where every rank's stream lands on the root (host arithmetic of sfh_gather_streams)
+    sizes, off = (C.c_uint64 * 4)(10, 0, 7, 3), (C.c_uint64 * 5)()
+    assert lib.sfh_gather_offsets(sizes, 4, 5, 25, off) == 0 and list(off) == [5, 15, 15, 22, 25]
+    assert lib.sfh_gather_offsets(sizes, 4, 5, 24, off) == -2  # SFH_E_DST_TOO_SMALL, the same on every rank
+    assert lib.sfh_gather_offsets(sizes, 1, 0, 10, off) == 0 and list(off)[:2] == [0, 10]
+    big = (C.c_uint64 * 2)(2**64 - 1, 5)
+    assert lib.sfh_gather_offsets(big, 2, 1, 2**64 - 1, off) == -1  # overflow
+    assert lib.sfh_gather_offsets(None, 2, 0, 0, off) == -1 and lib.sfh_gather_offsets(sizes, 0, 0, 0, off) == -1
     assert lib.sfh_stage_name(0) == b"k_lz77" and lib.sfh_stage_name(3) == b"k_emit" and lib.sfh_stage_name(9) == b""
     import zlib
     a, b = bytes(range(256)) * 300, b"starflate" * 5000  # host-side checksum combine rules against zlib

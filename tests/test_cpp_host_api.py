@@ -56,3 +56,22 @@ def test_compress_roundtrip_cpp(tmp_path):
                                                    "-L" + libdir, "-lstarflate_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
     out = subprocess.run([str(exe), GOLDEN], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_gather_streams_cpp(tmp_path):
+    """The C++23 multi-GPU binding (compress_device_async + gather_streams) over a 1-rank RCCL communicator."""
+    import torch  # where the image keeps librccl.so / libamdhip64.so
+
+    from starflate_amd import build
+
+    lib = build.build()
+    exe = tmp_path / "gather_streams"
+    libdir, tlib = os.path.dirname(lib), os.path.join(os.path.dirname(torch.__file__), "lib")
+    subprocess.check_call([CLANG, "-O2"] + FLAGS + [os.path.join(ROOT, "tests", "cpp", "gather_streams.cpp"),
+                                                   "-L" + libdir, "-lstarflate_hip", "-ldl", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    env = dict(os.environ)
+    if os.path.exists(os.path.join(tlib, "librccl.so")) and not os.path.exists("/opt/rocm/lib/librccl.so"):
+        env["SFH_RCCL_LIB"] = os.path.join(tlib, "librccl.so")
+    out = subprocess.run([str(exe), GOLDEN], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
