@@ -10,9 +10,24 @@ import torch
 
 from starflate_amd import Compressor, _capi, synth
 
+def _input(n):
+    """SF_WORKLOAD = text (default) | mixed | source | binary: the bench generators or the real bytes of
+    starflate_amd/realbytes.py (tiled to n: the window is 32 KiB and strips are independent, so tiling a corpus far longer
+    than that changes neither the parse nor the ratio)."""
+    import numpy as np
+    from starflate_amd import realbytes
+    w = os.environ.get("SF_WORKLOAD", "text")
+    if w == "text":
+        return synth.gen_text_torch(n, seed=3, device="cuda")
+    if w == "mixed":
+        return torch.from_numpy(synth.gen_mixed(n, seed=4)).cuda()
+    buf = realbytes.source(96 << 20) if w == "source" else realbytes.binary(min(n, 256 << 20))
+    return torch.from_numpy(np.resize(buf, n)).cuda()
+
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256 << 20
 bb = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-data = synth.gen_text_torch(n, seed=3, device="cuda")
+data = _input(n)
 c = Compressor(0)
 for _ in range(2):
     c.compress_tensor(data, block_bytes=bb, effort=os.environ.get("SF_EFFORT", "default"))
@@ -21,7 +36,7 @@ per = c.last_block_bytes() // 32768  # k_lz77 stamps one row per strip: scale to
 st = both[0][: (n // 32768 + per - 1) // per] / per
 names = ["stage", "match", "take", "walk", "segpre", "emit", "flush"]
 med = np.median(st[:, :7], axis=0)
-print("median cycles per chunk:", {k: int(v) for k, v in zip(names, med)}, "sum", int(med.sum()))
+print(os.environ.get("SF_WORKLOAD", "text"), "median cycles per chunk:", {k: int(v) for k, v in zip(names, med)}, "sum", int(med.sum()))
 print("reconcile rounds per wave-round (wave 0):", round(float(np.mean(st[:, 7])) * per / (per * 4), 2), "max", float(np.max(both[0][: st.shape[0], 7])) / (per * 4))
 print("shares:", {k: round(v / med.sum(), 3) for k, v in zip(names, med)})
 k2 = both[1]

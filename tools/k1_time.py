@@ -4,10 +4,25 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from starflate_amd import Compressor, synth
+def _input(n):
+    """SF_WORKLOAD = text (default) | mixed | source | binary: the bench generators or the real bytes of
+    starflate_amd/realbytes.py (tiled to n: the window is 32 KiB and strips are independent, so tiling a corpus far longer
+    than that changes neither the parse nor the ratio)."""
+    import numpy as np
+    from starflate_amd import realbytes
+    w = os.environ.get("SF_WORKLOAD", "text")
+    if w == "text":
+        return synth.gen_text_torch(n, seed=3, device="cuda")
+    if w == "mixed":
+        return torch.from_numpy(synth.gen_mixed(n, seed=4)).cuda()
+    buf = realbytes.source(96 << 20) if w == "source" else realbytes.binary(min(n, 256 << 20))
+    return torch.from_numpy(np.resize(buf, n)).cuda()
+
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256 << 20
 bb = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 effort = os.environ.get("SF_EFFORT", "default")
-data = synth.gen_text_torch(n, seed=3, device="cuda")
+data = _input(n)
 c = Compressor(0)
 c.set_profiling(True)
 acc = {}
@@ -16,4 +31,4 @@ for i in range(6):
     if i >= 2:
         for k, v in c.stage_ms().items():
             acc[k] = acc.get(k, 0.0) + v / 4
-print(effort, {k: round(v * (1 << 30) / n, 3) for k, v in acc.items()}, "ratio", round(n / nb, 4))
+print(os.environ.get("SF_WORKLOAD", "text"), effort, {k: round(v * (1 << 30) / n, 3) for k, v in acc.items()}, "ratio", round(n / nb, 4))
