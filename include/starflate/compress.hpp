@@ -35,12 +35,15 @@ enum class BlockStrategy : std::uint8_t { Auto, Stored, Fixed, Dynamic };
 ///   Fastest : that, and no step-local candidate
 ///   Thorough: every position searched
 ///   Max     : Thorough with a second hash table keyed by seven bytes
+///   Best / Ultra: exact hash chains of depth 8 / 16 (zlib's structure) instead of the step tables
 enum class Effort : std::uint8_t {
   Default = SFH_EFFORT_DEFAULT,
   Fast = SFH_EFFORT_FAST,
   Fastest = SFH_EFFORT_FASTEST,
   Thorough = SFH_EFFORT_THOROUGH,
   Max = SFH_EFFORT_MAX,
+  Best = SFH_EFFORT_BEST,    // exact hash chains, the 8 most recent positions with the hash
+  Ultra = SFH_EFFORT_ULTRA,  // ... the 16 most recent
 };
 
 struct compress_options {

@@ -400,7 +400,12 @@ static inline uint32_t ent_pos(uint32_t v, uint32_t W) { return ((v >> 12) - 1) 
  * insertions if it names a position < i ("near": first same-hash position of
  * this step).  Candidates farther back than SFO_WINDOW are ignored.
  * Best = longest; ties -> smallest distance.
- * chain_depth > 0 (analysis only, not on the GPU): exact serial hash chains.
+ * chain_depth > 0 (SFH_EFFORT_BEST / _ULTRA on the GPU): exact hash chains, zlib's structure -- H[hash] is the latest
+ * position with that hash, prev[i] the one before i; EVERY position is inserted and searched, most recent candidate
+ * first, at most chain_depth of them and none farther back than SFO_WINDOW.  Every candidate is compared up to `cap`
+ * bytes (0: up to the longest match); the longest wins, the first found (the nearest) on ties -- so the walk may stop
+ * at the first candidate that reaches `cap`, which changes nothing.  far4_dist applies; depth / use_near / stride2 /
+ * long_hash_bytes / rank_bytes do not.  A capped match is extended by the parse, like any other.
  */
 typedef struct {
   const sfo_params* p;
@@ -456,11 +461,14 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
       uint32_t rend = (i / R + 1) * R;
       uint32_t maxlen = n - i < 258 ? n - i : 258;
       if (rend - i < maxlen) maxlen = rend - i;
+      uint32_t cmplen = (p->cap && p->cap < maxlen) ? p->cap : maxlen;
       uint32_t best = 0, bc = 0, c = H[h];
       for (uint32_t k = 0; k < p->chain_depth && c != NONE && i - c <= (p->x_window ? p->x_window : SFO_WINDOW); k++, c = prev[c]) {
-        uint32_t l = match_len(d, i, c, maxlen);
+        uint32_t l = match_len(d, i, c, cmplen);
         if (l > best) { best = l; bc = c; }
+        if (p->cap && best == p->cap) break; /* nothing later can be longer at match time, and the first found wins ties */
       }
+      if (p->far4_dist && best == 4 && i - bc > p->far4_dist) best = 0;
       if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)(i - bc); }
       prev[i] = H[h];
       H[h] = i;

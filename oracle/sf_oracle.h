@@ -90,7 +90,7 @@ typedef struct sfo_params {
   uint32_t depth;        /* history levels per hash table (1..3) */
   uint32_t use_near;     /* 1: also try the first same-hash position of the current step */
   uint32_t long_hash_bytes; /* 0: off; 5..8: second table keyed by that many bytes */
-  uint32_t chain_depth;  /* analysis only (not on the GPU): >0 = exact hash chains */
+  uint32_t chain_depth;  /* >0: exact hash chains of this depth instead of the step tables (SFH_EFFORT_BEST: 8, _ULTRA: 16) */
   uint32_t cap;          /* >0: match-time compare is capped at `cap` bytes; the parse extends
                             a capped match to its full length at chain positions only */
   uint32_t fast_skip;    /* 1: stored fast path -- a chunk whose first SFO_SKIP_SPAN positions are (almost)

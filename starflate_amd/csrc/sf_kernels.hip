@@ -128,6 +128,20 @@ constexpr uint32_t L_WTOT = L_HIST + 4 * kHistStride;        // u32[16] tokens |
 constexpr uint32_t L_DSYM = L_WTOT + 4 * K1_WAVES;            // u8[512] distance - 1 -> symbol: [d] below 256, [256 + (d >> 7)] from there on
 constexpr uint32_t K1_LDS = L_DSYM + 512;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
+// CHAIN (SFH_EFFORT_BEST / _ULTRA): exact hash chains.  One workgroup per CU: behind the 4-bit lengths come the chain
+// HEADS (u16 step codes, one per hash: the LATEST position with it), the LINKS (u16 per position of window + round, a
+// ring indexed by strip position mod kChainRing: the distance to the previous position with the same hash, 0: none),
+// then histogram, wave totals and the distance-symbol table as before
+constexpr uint32_t kChainRing = kWindow + kRound;            // positions that have a link
+constexpr uint32_t C_L_HEAD = L_TABLE;                       // u16[1<<kHashBits]
+constexpr uint32_t C_L_PREV = C_L_HEAD + (2u << kHashBits);  // u16[kChainRing]
+constexpr uint32_t C_L_POST = C_L_PREV + 2 * kChainRing;     // u16[2][kStep]: what the slices post for the serial pass, and what it answers
+constexpr uint32_t C_L_HIST = C_L_POST + 4 * kStep;
+constexpr uint32_t C_L_WTOT = C_L_HIST + 4 * kHistStride;
+constexpr uint32_t C_L_DSYM = C_L_WTOT + 4 * K1_WAVES;
+constexpr uint32_t C_K1_LDS = C_L_DSYM + 512;
+static_assert(C_K1_LDS <= 160 * 1024 && C_L_PREV % 16 == 0 && C_L_HIST % 16 == 0 && C_L_WTOT % 16 == 0, "K1 (chains): one workgroup per CU");
+static_assert(kRound * 5 == kChainRing, "the ring index of a round's first position is (round mod 5) * kRound");
 static_assert(L_WTOT % 16 == 0 && L_TABLE % 16 == 0 && L_LEN4 % 16 == 0 && L_HIST % 16 == 0, "LDS alignment");
 static_assert(kCap - 3 <= 15, "capped len-3 fits four bits");
 // the round's distances are staged in the chunk's own item array (k_lz77, match phase): a chunk never holds more items
@@ -222,11 +236,17 @@ __device__ __forceinline__ uint32_t entry_rel(uint32_t v) {
 // two halves of the workgroup, see the match phase.
 // LONG (SFH_EFFORT_MAX): the 32 KiB of table are TWO tables of 4096 buckets, one keyed by four bytes as ever, one by seven
 // (kLongBytes): a position has four far candidates; of equally ranked ones the nearest wins.
-template <bool STAMPS, bool DEPTH2, bool NEAR, bool STRIDE2, bool LONG>
-__global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
+// CHAIN (SFH_EFFORT_BEST / _ULTRA): exact hash chains instead of the step tables -- every position is inserted and
+// searched, most recent candidate first, `chain_depth` of them at most (the specification's chain_depth; zlib's
+// structure).  One workgroup per CU (the links take 80 KiB of LDS), 128 vector registers.
+template <bool STAMPS, bool DEPTH2, bool NEAR, bool STRIDE2, bool LONG, bool CHAIN = false>
+__global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREADS / 256) void k_lz77(
     const uint8_t* __restrict__ src, uint64_t n_total, uint32_t strip_bytes, uint16_t* __restrict__ items,
     uint32_t* __restrict__ nitems_out, uint32_t* __restrict__ ntok_out, uint32_t* __restrict__ hist_out,
-    uint32_t* __restrict__ rtok_out, uint32_t lazy, uint32_t fast_skip, uint64_t* __restrict__ stamps) {
+    uint32_t* __restrict__ rtok_out, uint32_t lazy, uint32_t fast_skip, uint64_t* __restrict__ stamps,
+    uint32_t chain_depth) {
+  static_assert(!CHAIN || (!STRIDE2 && !LONG && DEPTH2 && NEAR), "chains: every position searched, no step tables");
+  constexpr uint32_t LH = CHAIN ? C_L_HIST : L_HIST, LW = CHAIN ? C_L_WTOT : L_WTOT, LD = CHAIN ? C_L_DSYM : L_DSYM;
   uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t st_t = 0;
   auto stamp = [&](int slot) {
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
   };
   if constexpr (STAMPS) st_t = __builtin_amdgcn_s_memtime();
   // positions per insertion step: 1024 of which the even ones are searched, or 512 all of which are (thorough)
-  constexpr uint32_t SH = STRIDE2 ? 10u : 9u, STEP = 1u << SH;
+  constexpr uint32_t SH = (STRIDE2 || CHAIN) ? 10u : 9u, STEP = 1u << SH;
   constexpr uint32_t HB = LONG ? kHashBits - 1 : kHashBits;  // bucket index bits of a table
   static_assert(!LONG || (DEPTH2 && !STRIDE2), "the second table comes with the highest effort");
   // step codes in a 16-bit table half: ((step - epoch) + 1) << SH | (STEP - 1 - index in the step); the epoch advances by
@@ -247,14 +267,16 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
   static_assert(((kEpMax + 1) << SH) <= 65536 && kRound % STEP == 0, "step codes");
 
   // static LDS (its address is a compile-time constant: no base register, no add per access)
-  __shared__ __attribute__((aligned(16))) uint8_t smem[K1_LDS];
+  __shared__ __attribute__((aligned(16))) uint8_t smem[CHAIN ? C_K1_LDS : K1_LDS];
   uint32_t* s_data = reinterpret_cast<uint32_t*>(smem + L_DATA);
   uint8_t* s_bytes = smem + L_DATA;
   uint32_t* s_len4 = reinterpret_cast<uint32_t*>(smem + L_LEN4);
   uint32_t* s_table = reinterpret_cast<uint32_t*>(smem + L_TABLE);
   [[maybe_unused]] uint32_t* s_table2 = s_table + (1u << HB);  // LONG: the seven-byte table behind the four-byte one
-  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + L_HIST);
-  uint32_t* s_wtot = reinterpret_cast<uint32_t*>(smem + L_WTOT);
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + LH);
+  uint32_t* s_wtot = reinterpret_cast<uint32_t*>(smem + LW);
+  [[maybe_unused]] uint16_t* s_head = reinterpret_cast<uint16_t*>(smem + C_L_HEAD);
+  [[maybe_unused]] uint16_t* s_prev = reinterpret_cast<uint16_t*>(smem + C_L_PREV);
 
   const uint32_t t = threadIdx.x;
   // t >> 6 is wave-uniform, but only readfirstlane tells the compiler so
@@ -276,11 +298,11 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
   // ---- prologue: empty table and histogram; the strip's first kLook bytes where the first shift finds them ----
   {
     uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
-    for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) t4[idx] = make_uint4(0, 0, 0, 0);
+    for (uint32_t idx = t; idx < (CHAIN ? 2u : 4u) * (1u << kHashBits) / 16; idx += K1_THREADS) t4[idx] = make_uint4(0, 0, 0, 0);
     for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) s_hist[idx] = (idx == 256) ? 1u : 0u;
     if (t < kLook / 4) s_data[(kWindow + kRound) / 4 + t] = load4(4 * t);
     if (t < 4) s_len4[kRound / 8 + t] = 0;  // pad read by the take pass
-    if (t < 512) smem[L_DSYM + t] = (uint8_t)dist_symbol_of(t < 256 ? t : (t - 256) << 7);
+    if (t < 512) smem[LD + t] = (uint8_t)dist_symbol_of(t < 256 ? t : (t - 256) << 7);
   }
   // this thread's eight bytes of round 0 (positions kLook + 8t ..)
   uint32_t pre_lo = load4(kLook + 8 * t), pre_hi = load4(kLook + 8 * t + 4);
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
         constexpr uint32_t kSub2 = (kEpS << SH) * 0x00010001u;
         uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
         static_assert((1u << kHashBits) % (4 * K1_THREADS) == 0, "ageing: whole 16-byte units per thread");
-        for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) {
+        for (uint32_t idx = t; idx < (CHAIN ? 2u : 4u) * (1u << kHashBits) / 16; idx += K1_THREADS) {
           uint4 e = t4[idx];
           asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.x) : "s"(kSub2));
           asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.y) : "s"(kSub2));
@@ -370,7 +392,144 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
       // positions searched only, one slot per even position: an odd position's distance is its successor's.)
       const uint32_t stage_off = 2u * rc * kRound;  // byte offset of the round's slots in the chunk's item array
       __builtin_amdgcn_s_setprio(2);
-      {
+      if constexpr (CHAIN) {
+        // ---- exact hash chains (the specification's chain_depth > 0) ----
+        // A step is 1024 positions, one per thread.  INSERTION is serial in the position, but only where hashes meet:
+        // every wave finds the equal hashes inside its own 64-position slice by ballots (a lane's predecessor is the
+        // nearest lower lane with its hash) and posts, per position, the hash and whether it is the first / the last of
+        // its hash in the slice.  ONE wave (they take turns) then runs through the sixteen slices in order -- a first reads
+        // its predecessor from the heads, a last writes the head; one wave's LDS operations execute in order, so no
+        // barrier is needed between slices -- while the others WALK the chains of the step before, whose links are
+        // complete (the links a walk follows are older than anything being inserted).  Three barriers per step.
+        static_assert(STEP == K1_THREADS && K1_WAVES == 16, "one position per thread and step, sixteen slices");
+        uint16_t* const s_post = reinterpret_cast<uint16_t*>(smem + C_L_POST);  // [STEP] hash | first << 13 | last << 14
+        uint16_t* const s_hv = s_post + STEP;                                    // [STEP] what the heads held for a first
+        static_assert(kHashBits == 13, "posted entry layout");
+        const uint32_t ringb = (r % 5u) * kRound;            // (uniform) ring index of the round's first position
+        uint8_t* const gst = reinterpret_cast<uint8_t*>(gi) + stage_off;
+        const uint32_t sh0 = t & 3u;
+        const uint64_t below = (1ull << lane) - 1ull;        // the lanes before this one
+        const uint32_t to_rend = kRegion - (t & (kRegion - 1));
+        const uint32_t mlen0 = to_rend < kCap ? to_rend : kCap;
+        // the walk of the position this thread owns in the step before
+        uint32_t w_a0 = 0, w_a1 = 0, w_a2 = 0, w_a3 = 0, w_maxlen = 0, w_tot = 0, w_best = 0, w_bdist = 0, w_q = 0;
+        bool w_act = false;
+        // One candidate of a walk: the 16 bytes at distance `tot` behind the position (five dwords, whatever its alignment)
+        // and its own link.  (Measured and not kept: the same bytes as three aligned ds_read_b64 + selects, 21.8 against
+        // 19.9 ms per GiB at depth 8 -- random 8-byte gathers cost the LDS more than their bank model says, as in the
+        // table path; and the second eight bytes fetched only where the first eight are equal: no faster.)  A lane that has nothing to look at asks for distance 0 -- its own position -- and ignores the
+        // answer, so the loads are straight-line code and the next candidate's can be in flight while this one is compared:
+        // a walk is a chain of dependent LDS round trips (link -> address -> link), the comparing is not on it.
+        struct Cand { uint32_t p0, p1, p2, p3, p4, dn, csh; };
+        auto fetch = [&](uint32_t tot) -> Cand {
+          const uint32_t c = (kWindow + w_q) - tot;            // the candidate's LDS byte address (inside the window)
+          int32_t ci = (int32_t)(ringb + w_q) - (int32_t)tot;
+          ci += (ci >> 31) & (int32_t)kChainRing;              // ... and its ring index
+          const uint32_t cw = c >> 2;
+          Cand k;
+          k.dn = s_prev[ci];                                   // (asked for first: the next address only waits for this one)
+          k.p0 = s_data[cw]; k.p1 = s_data[cw + 1]; k.p2 = s_data[cw + 2]; k.p3 = s_data[cw + 3]; k.p4 = s_data[cw + 4];
+          k.csh = c & 3u;
+          return k;
+        };
+        auto walk_chain = [&]() {
+          uint32_t tot = w_act ? w_tot : 0u;
+          bool act = w_act;
+          Cand cur = fetch(tot);
+          for (uint32_t k = 0; k < chain_depth; ++k) {
+            if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+            const uint32_t nt = tot + cur.dn;
+            const bool actn = act && cur.dn != 0 && nt <= kWindow;  // the chain goes on, inside the window
+            const Cand nxt = fetch(actn ? nt : 0u);
+            const uint32_t x0 = w_a0 ^ __builtin_amdgcn_alignbyte(cur.p1, cur.p0, cur.csh), x1 = w_a1 ^ __builtin_amdgcn_alignbyte(cur.p2, cur.p1, cur.csh);
+            const uint32_t x2 = w_a2 ^ __builtin_amdgcn_alignbyte(cur.p3, cur.p2, cur.csh), x3 = w_a3 ^ __builtin_amdgcn_alignbyte(cur.p4, cur.p3, cur.csh);
+            // first differing bit of x3:x2:x1:x0 (all ones when there is none: ffbl(0) = 0xFFFFFFFF survives the ORs)
+            const uint32_t fb = min(min(ffbl(x0), ffbl(x1) | 32u), min(ffbl(x2) | 64u, ffbl(x3) | 96u));
+            const uint32_t l = min(fb >> 3, w_maxlen);         // equal bytes, kCap and the region's end at most
+            if (act && l > w_best) { w_best = l; w_bdist = tot; }  // the longest; the first found (the nearest) on ties
+            act = actn && w_best < kCap;                       // (nothing later can beat a capped match: it would only tie)
+            tot = actn ? nt : 0u;
+            cur = nxt;
+          }
+        };
+        for (uint32_t it = 0; it <= nsteps; ++it) {
+          const uint32_t sb = it * STEP;                       // (uniform) the step's first position, round-relative
+          const uint32_t q = sb + t;
+          bool ins = false, isfirst = false, islast = false;
+          uint32_t h = 0, dl = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+          const uint32_t code = ((rb / STEP + it - ebase + 1) << SH) | t;  // step code | index in the step: ascending in the position
+          if (it < nsteps) {
+            const uint32_t wb = kWindow + (q & ~3u);
+            const uint32_t d0 = *reinterpret_cast<const uint32_t*>(smem + wb), d1 = *reinterpret_cast<const uint32_t*>(smem + wb + 4),
+                           d2 = *reinterpret_cast<const uint32_t*>(smem + wb + 8), d3 = *reinterpret_cast<const uint32_t*>(smem + wb + 12),
+                           d4 = *reinterpret_cast<const uint32_t*>(smem + wb + 16);
+            a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0); a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
+            a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0); a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
+            h = (a0 * 2654435761u) >> (32 - kHashBits);
+            ins = rb + q + kMinMatch <= n;                     // the specification inserts and searches what has four bytes left
+            // the lanes of this wave with the same hash, one ballot per hash bit
+            // (in 32-bit halves, the ballot and its complement as scalars: a compare, two selects and two ANDs per bit)
+            const uint64_t all = __builtin_amdgcn_ballot_w64(ins);
+            uint32_t slo = (uint32_t)all, shi = (uint32_t)(all >> 32);
+#pragma unroll
+            for (uint32_t b = 0; b < kHashBits; ++b) {
+              const bool bit = (h & (1u << b)) != 0;
+              const uint64_t bb = __builtin_amdgcn_ballot_w64(bit), nb = ~bb;
+              slo &= bit ? (uint32_t)bb : (uint32_t)nb;
+              shi &= bit ? (uint32_t)(bb >> 32) : (uint32_t)(nb >> 32);
+            }
+            const uint32_t llo = slo & (uint32_t)below, lhi = shi & (uint32_t)(below >> 32);   // the lanes before this one
+            const uint32_t ulo = slo & ~(uint32_t)below, uhi = shi & ~(uint32_t)(below >> 32); // this one and those behind it
+            isfirst = ins && (llo | lhi) == 0;
+            islast = ins && __builtin_popcount(ulo) + __builtin_popcount(uhi) == 1;
+            dl = lhi ? lane - (63u - (uint32_t)__builtin_clz(lhi)) : llo ? lane - (31u - (uint32_t)__builtin_clz(llo)) : 0u;
+          }
+          if (it < nsteps) s_post[t] = (uint16_t)(h | (isfirst ? 1u << 13 : 0u) | (islast ? 1u << 14 : 0u));
+          lds_barrier();
+          if (it < nsteps && wave == (it & (K1_WAVES - 1))) {  // (uniform) this wave's turn: the step's heads, slice by slice
+            // Nothing here waits for an answer before the next request goes out: the sixteen posted entries are fetched
+            // together, then read-head / write-head pairs follow one another slice by slice -- the LDS executes a wave's
+            // operations in the order they were issued, which is all the heads need -- and the answers are stored at the end
+            const uint32_t code0 = ((rb / STEP + it - ebase + 1) << SH) | lane;
+            uint32_t e[K1_WAVES], old[K1_WAVES];
+#pragma unroll
+            for (uint32_t sl = 0; sl < K1_WAVES; ++sl) e[sl] = s_post[sl * 64 + lane];
+#pragma unroll
+            for (uint32_t sl = 0; sl < K1_WAVES; ++sl) {
+              const uint32_t hh = e[sl] & ((1u << kHashBits) - 1u);
+              // (every lane reads, a lane that is no first ignores the answer: no divergent branch between the LDS operations)
+              old[sl] = s_head[hh];
+              if (e[sl] & (1u << 14)) s_head[hh] = (uint16_t)(code0 + sl * 64);
+            }
+#pragma unroll
+            for (uint32_t sl = 0; sl < K1_WAVES; ++sl) s_hv[sl * 64 + lane] = (uint16_t)old[sl];
+          }
+          if (it >= 1) walk_chain();
+          lds_barrier();
+          const uint32_t hv = (it < nsteps && isfirst) ? s_hv[t] : 0u;
+          if (it >= 1) {
+            // ---- the position of the step before is settled: its length and distance go where the parse finds them ----
+            const uint32_t bd1 = w_bdist - 1u;                 // distance - 1 (what is staged; only read where there is a match)
+            const bool ok = w_best >= (bd1 >= kFar4 ? kMinMatch + 1 : kMinMatch);
+            uint32_t v = ok ? w_best - 3u : 0u;
+            *reinterpret_cast<uint16_t*>(gst + 2u * w_q) = (uint16_t)bd1;
+            // two lanes' 4-bit lengths -> one byte, stored by the even lanes (see the thorough path below)
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
+            asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
+                         :: "v"(w_q >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
+          }
+          if (it < nsteps) {
+            // the position's link: the nearest lower lane with its hash, or what the heads held (empty, or aged out: none)
+            const uint32_t d = !ins ? 0u : (!isfirst ? dl : (hv >= STEP ? code - hv : 0u));
+            s_prev[ringb + q] = (uint16_t)d;
+            w_a0 = a0; w_a1 = a1; w_a2 = a2; w_a3 = a3; w_q = q;
+            w_maxlen = (uint32_t)max(min((int)(qn - sb) - (int)t, (int)mlen0), 0);
+            w_tot = d; w_best = 0; w_bdist = 0;
+            w_act = d != 0 && d <= kWindow && w_maxlen >= kMinMatch;
+          }
+          lds_barrier();  // the step's links are in place before anything walks over them
+        }
+      } else {
         // A step has 512 searches for 1024 threads: the even positions of 1024 (STRIDE2), or all of 512 (thorough).  The
         // two halves of the workgroup (waves 0..7 and 8..15) take the steps in turn and split a search in two: in the
         // INTERVAL before step `it` is inserted, the half whose turn it is does the first part of step `it` -- bytes,
@@ -901,7 +1060,7 @@ __global__ __launch_bounds__(K1_THREADS, 2 * K1_THREADS / 256) void k_lz77(
             put_item(at, (kItemMatch | l3) | (k == 0 ? flag : 0u));
             put_item(at + 2, d1);
             atomicAdd(&s_hist[kHistLen + l3], 1u);
-            atomicAdd(&s_hist[kHistD + smem[L_DSYM + (d1 < 256 ? d1 : 256 + (d1 >> 7))]], 1u);
+            atomicAdd(&s_hist[kHistD + smem[LD + (d1 < 256 ? d1 : 256 + (d1 >> 7))]], 1u);
           }
         }
       }
@@ -1708,8 +1867,14 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
   const uint32_t nstrips = (nchunks + per - 1) / per;
   const auto launch = [&](auto kernel, uint64_t* stamps) {
     hipLaunchKernelGGL(kernel, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items, ws.nitems, ws.ntok,
-                       ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps);
+                       ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps, opt.chain_depth);
   };
+  if (opt.chain_depth) {  // exact hash chains (SFH_EFFORT_BEST / _ULTRA): a walk has one hop per slot of a step
+    if (opt.chain_depth > K1_WAVES) return hipErrorInvalidValue;
+    if (ws.stamps) launch(k_lz77<true, true, true, false, false, true>, ws.stamps);
+    else launch(k_lz77<false, true, true, false, false, true>, (uint64_t*)nullptr);
+    return hipGetLastError();
+  }
   // effort: {even positions: both levels + near, newer level + near, newer level only} {every position: one table, two tables}
   const uint32_t kind = !opt.stride2 ? (opt.long_table ? 4u : 3u) : opt.depth2 ? 0u : (opt.near ? 1u : 2u);
   if (ws.stamps) {

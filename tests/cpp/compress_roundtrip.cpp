@@ -181,8 +181,9 @@ auto main(int argc, char** argv) -> int {
     if (compress_bound(html.size(), 1000) != 0) { std::printf("compress_bound of an invalid block_bytes\n"); ++fail; }
     // compress_options::effort mirrors enum sfh_effort: every level round-trips; Max is the smallest, Fastest the largest
     static_assert(static_cast<int>(Effort::Max) == SFH_EFFORT_MAX && static_cast<int>(Effort::Fastest) == SFH_EFFORT_FASTEST);
-    std::size_t size_of[5] = {};
-    for (const Effort e : {Effort::Default, Effort::Fast, Effort::Fastest, Effort::Thorough, Effort::Max}) {
+    static_assert(static_cast<int>(Effort::Best) == SFH_EFFORT_BEST && static_cast<int>(Effort::Ultra) == SFH_EFFORT_ULTRA);
+    std::size_t size_of[7] = {};
+    for (const Effort e : {Effort::Default, Effort::Fast, Effort::Fastest, Effort::Thorough, Effort::Max, Effort::Best, Effort::Ultra}) {
       compress_options eo;
       eo.effort = e;
       const auto ne = gpu.compress(html, comp, eo);
@@ -194,7 +195,8 @@ auto main(int argc, char** argv) -> int {
         size_of[static_cast<int>(e)] = *ne;
       }
     }
-    if (!(size_of[SFH_EFFORT_MAX] <= size_of[SFH_EFFORT_DEFAULT] && size_of[SFH_EFFORT_DEFAULT] <= size_of[SFH_EFFORT_FASTEST])) {
+    if (!(size_of[SFH_EFFORT_ULTRA] <= size_of[SFH_EFFORT_BEST] && size_of[SFH_EFFORT_BEST] <= size_of[SFH_EFFORT_MAX] &&
+          size_of[SFH_EFFORT_MAX] <= size_of[SFH_EFFORT_DEFAULT] && size_of[SFH_EFFORT_DEFAULT] <= size_of[SFH_EFFORT_FASTEST])) {
       std::printf("effort: sizes out of order\n");
       ++fail;
     }

@@ -109,6 +109,39 @@ def test_effort_fast_bit_exact_vs_oracle(compressor, starfleet):
             _roundtrip(got4, data)
 
 
+@pytest.mark.parametrize("effort", ["best", "ultra"])
+def test_effort_chains_bit_exact_vs_oracle(compressor, starfleet, effort):
+    """SFH_EFFORT_BEST / _ULTRA: exact hash chains of depth 8 / 16 (the specification's chain_depth: every position inserted
+    and searched, most recent candidate first) -- bit-exact like every other effort, over inputs whose chains look very
+    different (text, the reference's HTML file, mixed stripes, one value, short periods, noise), strips that reach past one
+    batch of the links' ring, ragged tails, every strategy and lazy level; never larger than the default effort's stream
+    on the compressible ones."""
+    rng = np.random.default_rng(5)
+    text = synth.gen_text(44 * CHUNK + 77, seed=14)
+    cases = {"text": text, "starfleet": np.frombuffer(starfleet, np.uint8), "mixed": synth.gen_mixed(1 << 20, seed=4, stripe=1 << 15),
+             "zeros": np.zeros(5 * CHUNK + 333, np.uint8), "period7": np.tile(np.arange(7, dtype=np.uint8), 30000),
+             "period300": np.tile(rng.integers(0, 256, 300, dtype=np.uint8), 700), "random": rng.integers(0, 256, 3 * CHUNK + 5, dtype=np.uint8),
+             "low_entropy": rng.integers(0, 3, 2 * CHUNK + 99, dtype=np.uint8), "tiny": np.frombuffer(b"abcabcabcabcabcabc", np.uint8),
+             "empty": np.zeros(0, np.uint8), "three": np.frombuffer(b"xyz", np.uint8)}
+    for name, data in cases.items():
+        for bb in (0, 32768, 131072, 1 << 20):
+            got = np.frombuffer(compressor.compress(data, effort=effort, block_bytes=bb), np.uint8)
+            want = O.compress(data, O.default_params(strip_bytes=bb, **EFFORT_PARAMS[effort]))
+            assert got.size == want.size and np.array_equal(got, want), (name, bb, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
+            _roundtrip(got, data)
+        if name in ("text", "starfleet", "mixed"):
+            assert len(compressor.compress(data, effort=effort)) < len(compressor.compress(data))
+    for strategy in ("fixed", "dynamic", "stored"):
+        for lazy in (0, 1, 3):
+            got = np.frombuffer(compressor.compress(text, effort=effort, strategy=strategy, lazy=lazy, stored_fast_path=False), np.uint8)
+            want = O.compress(text, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=0, **EFFORT_PARAMS[effort]))
+            assert np.array_equal(got, want), (strategy, lazy)
+    # the GPU decoder reads these streams like any other (index + sub-index)
+    got = compressor.compress(text, effort=effort)
+    back, st = compressor.decompress(got, compressor.last_index(), text.size, subindex=compressor.last_subindex(), block_bytes=compressor.last_block_bytes())
+    assert st == 0 and back == text.tobytes()
+
+
 def test_batches_give_the_stream_of_one_launch(monkeypatch):
     """Inputs beyond one batch (1 GiB) run the four kernels batch after batch with bounded scratch; a small batch
     size (SFH_BATCH_CHUNKS, read at sfh_create) exercises the loop: same stream, same index, wrapped or not."""
@@ -213,7 +246,8 @@ def test_stored_fast_path(compressor):
 
 
 EFFORT_PARAMS = {"default": {}, "fast": {"depth": 1}, "fastest": {"depth": 1, "use_near": 0}, "thorough": {"stride2": 0, "step": 512},
-                 "max": {"stride2": 0, "step": 512, "hash_bits": 12, "long_hash_bytes": 7}}
+                 "max": {"stride2": 0, "step": 512, "hash_bits": 12, "long_hash_bytes": 7},
+                 "best": {"chain_depth": 8}, "ultra": {"chain_depth": 16}}
 
 
 @pytest.mark.parametrize("effort", sorted(EFFORT_PARAMS))
@@ -553,8 +587,9 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
         fast = it % 7 != 0
         bb = [0, 32768, 65536, 131072][it % 3 if it % 11 else 3]
         # every effort: default (even positions searched), thorough (all, steps of 512), fast (one level), fastest (no near)
-        effort, ekw = [("default", {}), ("thorough", dict(stride2=0, step=512)), ("default", {}), ("fast", dict(depth=1)),
-                       ("fastest", dict(depth=1, use_near=0)), ("max", dict(stride2=0, step=512, hash_bits=12, long_hash_bytes=7))][it % 6 if it % 13 else 5]
+        effort, ekw = [("default", {}), ("thorough", dict(stride2=0, step=512)), ("best", dict(chain_depth=8)), ("fast", dict(depth=1)),
+                       ("fastest", dict(depth=1, use_near=0)), ("max", dict(stride2=0, step=512, hash_bits=12, long_hash_bytes=7)),
+                       ("ultra", dict(chain_depth=16)), ("default", {})][it % 8 if it % 13 else 5]
         got = np.frombuffer(compressor.compress(data, strategy=strategy, lazy=lazy, stored_fast_path=fast, block_bytes=bb, effort=effort), np.uint8)
         want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=int(fast), strip_bytes=bb, **ekw))
         assert np.array_equal(got, want), (it, total, strategy, lazy, fast, bb, effort, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])

@@ -246,3 +246,48 @@ def test_stride2_searches_even_positions_and_inherits_from_the_successor(starfle
         _check(s, np.frombuffer(starfleet, np.uint8))
         sizes[name] = s.size
     assert sizes["max"] <= sizes["thorough"] <= sizes["default"] <= sizes["fast"] <= sizes["fastest"]
+
+
+def test_hash_chains_are_exact_and_most_recent_first(starfleet):
+    """chain_depth > 0 (SFH_EFFORT_BEST / _ULTRA): the match of a position is what a brute-force walk over the most recent
+    earlier positions with the same 13-bit hash finds -- at most chain_depth of them, none farther back than 32 KiB, every
+    one compared up to `cap` bytes, the longest winning and the nearest on ties -- and deeper chains never compress worse."""
+    data = np.frombuffer(starfleet, np.uint8)[:32768].copy()
+    p = O.default_params(chain_depth=8)
+    ln, ds = O.match_chunk(data, p)
+    v = data.astype(np.uint32)
+    w = v[:-3] | (v[1:-2] << 8) | (v[2:-1] << 16) | (v[3:] << 24)
+    h = ((w.astype(np.uint64) * 2654435761) & 0xFFFFFFFF) >> (32 - p.hash_bits)
+    seen = {}
+    checked = 0
+    for i in range(data.size - 3):
+        hist = seen.setdefault(int(h[i]), [])
+        if i % 7 == 0:  # a sample of positions, every one of them inserted
+            maxlen = min(data.size - i, 258, (i // p.region_bytes + 1) * p.region_bytes - i, p.cap)
+            best, bd = 0, 0
+            for c in hist[-1:-9:-1]:
+                if i - c > 32768:
+                    break
+                ln_c = 0
+                while ln_c < maxlen and data[i + ln_c] == data[c + ln_c]:
+                    ln_c += 1
+                if ln_c > best:
+                    best, bd = ln_c, i - c
+                if best == p.cap:
+                    break
+            if best == 4 and bd > p.far4_dist:
+                best = 0
+            if best >= 4:
+                assert (int(ln[i]), int(ds[i])) == (best, bd), i
+            else:
+                assert ln[i] == 0, i
+            checked += 1
+        hist.append(i)
+    assert checked > 4000
+    whole = np.frombuffer(starfleet, np.uint8)
+    sizes = []
+    for depth in (0, 4, 8, 16):
+        s = O.compress(whole, O.default_params(chain_depth=depth))
+        _check(s, whole)
+        sizes.append(s.size)
+    assert sizes[3] <= sizes[2] <= sizes[1] and sizes[2] < sizes[0]
