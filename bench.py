@@ -314,7 +314,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=1 << 30, help="input bytes per GPU")
     ap.add_argument("--workload", default="text", choices=["text", "random", "mixed", "runs"])
-    ap.add_argument("--effort", default="default", choices=["default", "fast", "fastest", "thorough", "max", "best", "ultra"], help="sfh_options.effort of the timed steps")
+    ap.add_argument("--effort", default="default", choices=["default", "fast", "fastest", "thorough", "max", "best", "ultra", "extreme"], help="sfh_options.effort of the timed steps")
     ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default, 256 KiB at this size)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -603,7 +603,7 @@ def main():
                 t = t.repeat(reps)
                 desc += f", repeated x{reps} for throughput"
                 nb *= reps
-            for eff in ("default", "thorough", "max", "best", "ultra"):
+            for eff in ("default", "thorough", "max", "best", "ultra", "extreme"):
                 others[key if eff == "default" else f"{key}_effort_{eff}"] = secondary_workload(
                     comp, key, nb, dev, 0, effort=eff, data=t, wl=desc)
             del t
@@ -617,8 +617,8 @@ def main():
         # SFH_EFFORT_MAX: thorough with a second hash table keyed by seven bytes
         others["effort_max"] = secondary_workload(comp, args.workload, n, dev, bb, effort="max", data=data, wl=wl)
         others["mixed_effort_max"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort="max")
-        # SFH_EFFORT_BEST / _ULTRA: exact hash chains of depth 8 / 16 (zlib's structure) instead of the step tables
-        for eff in ("best", "ultra"):
+        # SFH_EFFORT_BEST / _ULTRA / _EXTREME: exact hash chains of depth 8 / 16 / 32 (zlib's structure) instead of the step tables
+        for eff in ("best", "ultra", "extreme"):
             others[f"effort_{eff}"] = secondary_workload(comp, args.workload, n, dev, bb, effort=eff, data=data, wl=wl)
             others[f"mixed_effort_{eff}"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort=eff)
 

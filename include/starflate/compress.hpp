@@ -35,7 +35,7 @@ enum class BlockStrategy : std::uint8_t { Auto, Stored, Fixed, Dynamic };
 ///   Fastest : that, and no step-local candidate
 ///   Thorough: every position searched
 ///   Max     : Thorough with a second hash table keyed by seven bytes
-///   Best / Ultra: exact hash chains of depth 8 / 16 (zlib's structure) instead of the step tables
+///   Best / Ultra / Extreme: exact hash chains of depth 8 / 16 / 32 (zlib's structure) instead of the step tables
 enum class Effort : std::uint8_t {
   Default = SFH_EFFORT_DEFAULT,
   Fast = SFH_EFFORT_FAST,
@@ -44,6 +44,7 @@ enum class Effort : std::uint8_t {
   Max = SFH_EFFORT_MAX,
   Best = SFH_EFFORT_BEST,    // exact hash chains, the 8 most recent positions with the hash
   Ultra = SFH_EFFORT_ULTRA,  // ... the 16 most recent
+  Extreme = SFH_EFFORT_EXTREME,  // ... the 32 most recent: zlib -6's own ratio
 };
 
 struct compress_options {

@@ -81,15 +81,16 @@ typedef struct sfh_options {
                             on mixed data, for a quarter more time); SFH_EFFORT_MAX adds a second hash table keyed by seven
                             bytes to that (two tables of 4096 buckets instead of one of 8192: four far candidates per
                             position; 2.7 % less output than thorough on text, for a third more time);
-                            SFH_EFFORT_BEST / SFH_EFFORT_ULTRA replace the step tables by exact HASH CHAINS, zlib's own
-                            structure (every position inserted and searched, the 8 / 16 most recent positions with its
-                            hash tried, nearest first): what closes the gap to zlib -6 on real data, where recency
-                            counts for more than on the synthetic text, at a third to a quarter of the default's speed */
+                            SFH_EFFORT_BEST / _ULTRA / _EXTREME replace the step tables by exact HASH CHAINS, zlib's own
+                            structure (every position inserted and searched, the 8 / 16 / 32 most recent positions with
+                            its hash tried, nearest first): what closes the gap to zlib -6 on real data, where recency
+                            counts for more than on the synthetic text, at a quarter to a tenth of the default's speed;
+                            EXTREME is zlib -6's own ratio on the text workload */
   uint32_t reserved;     /* must be 0 */
 } sfh_options;
 
 enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1, SFH_EFFORT_FASTEST = 2, SFH_EFFORT_THOROUGH = 3, SFH_EFFORT_MAX = 4,
-                  SFH_EFFORT_BEST = 5, SFH_EFFORT_ULTRA = 6 };
+                  SFH_EFFORT_BEST = 5, SFH_EFFORT_ULTRA = 6, SFH_EFFORT_EXTREME = 7 };
 
 #define SFH_DEFAULT_BLOCK_BYTES 262144u
 

@@ -135,7 +135,7 @@ def device_props(device=0):
     return {k: (getattr(p, k).decode() if isinstance(getattr(p, k), bytes) else getattr(p, k)) for k, _ in p._fields_ if k != "reserved"}
 
 
-EFFORT = {"default": 0, "fast": 1, "fastest": 2, "thorough": 3, "max": 4, "best": 5, "ultra": 6}
+EFFORT = {"default": 0, "fast": 1, "fastest": 2, "thorough": 3, "max": 4, "best": 5, "ultra": 6, "extreme": 7}
 
 
 def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw", block_bytes=0,

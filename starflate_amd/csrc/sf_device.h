@@ -107,7 +107,7 @@ struct Options {
   uint32_t near;         // 1: the step-local candidate is tried as well (always with depth2)
   uint32_t stride2;      // 1: only even positions are searched, odd ones take over their successor's match (0: thorough)
   uint32_t long_table;   // 1: two tables of 4096 buckets, keyed by four and by seven bytes (with stride2 = 0: SFH_EFFORT_MAX)
-  uint32_t chain_depth;  // > 0: exact hash chains of this depth (<= 16) instead of the step tables (SFH_EFFORT_BEST 8, _ULTRA 16)
+  uint32_t chain_depth;  // > 0: exact hash chains of this depth instead of the step tables (SFH_EFFORT_BEST 8, _ULTRA 16, _EXTREME 32)
 };
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,

@@ -1869,8 +1869,7 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
     hipLaunchKernelGGL(kernel, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items, ws.nitems, ws.ntok,
                        ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps, opt.chain_depth);
   };
-  if (opt.chain_depth) {  // exact hash chains (SFH_EFFORT_BEST / _ULTRA): a walk has one hop per slot of a step
-    if (opt.chain_depth > K1_WAVES) return hipErrorInvalidValue;
+  if (opt.chain_depth) {  // exact hash chains (SFH_EFFORT_BEST / _ULTRA / _EXTREME)
     if (ws.stamps) launch(k_lz77<true, true, true, false, false, true>, ws.stamps);
     else launch(k_lz77<false, true, true, false, false, true>, (uint64_t*)nullptr);
     return hipGetLastError();

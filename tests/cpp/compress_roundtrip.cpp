@@ -182,8 +182,8 @@ auto main(int argc, char** argv) -> int {
     // compress_options::effort mirrors enum sfh_effort: every level round-trips; Max is the smallest, Fastest the largest
     static_assert(static_cast<int>(Effort::Max) == SFH_EFFORT_MAX && static_cast<int>(Effort::Fastest) == SFH_EFFORT_FASTEST);
     static_assert(static_cast<int>(Effort::Best) == SFH_EFFORT_BEST && static_cast<int>(Effort::Ultra) == SFH_EFFORT_ULTRA);
-    std::size_t size_of[7] = {};
-    for (const Effort e : {Effort::Default, Effort::Fast, Effort::Fastest, Effort::Thorough, Effort::Max, Effort::Best, Effort::Ultra}) {
+    std::size_t size_of[8] = {};
+    for (const Effort e : {Effort::Default, Effort::Fast, Effort::Fastest, Effort::Thorough, Effort::Max, Effort::Best, Effort::Ultra, Effort::Extreme}) {
       compress_options eo;
       eo.effort = e;
       const auto ne = gpu.compress(html, comp, eo);
@@ -195,7 +195,7 @@ auto main(int argc, char** argv) -> int {
         size_of[static_cast<int>(e)] = *ne;
       }
     }
-    if (!(size_of[SFH_EFFORT_ULTRA] <= size_of[SFH_EFFORT_BEST] && size_of[SFH_EFFORT_BEST] <= size_of[SFH_EFFORT_MAX] &&
+    if (!(size_of[SFH_EFFORT_EXTREME] <= size_of[SFH_EFFORT_ULTRA] && size_of[SFH_EFFORT_ULTRA] <= size_of[SFH_EFFORT_BEST] && size_of[SFH_EFFORT_BEST] <= size_of[SFH_EFFORT_MAX] &&
           size_of[SFH_EFFORT_MAX] <= size_of[SFH_EFFORT_DEFAULT] && size_of[SFH_EFFORT_DEFAULT] <= size_of[SFH_EFFORT_FASTEST])) {
       std::printf("effort: sizes out of order\n");
       ++fail;

@@ -52,7 +52,7 @@ def test_host_side_entry_points_without_gpu():
     big = (C.c_uint64 * 2)(2**64 - 1, 5)
     assert lib.sfh_gather_offsets(big, 2, 1, 2**64 - 1, off) == -1  # overflow
     assert lib.sfh_gather_offsets(None, 2, 0, 0, off) == -1 and lib.sfh_gather_offsets(sizes, 0, 0, 0, off) == -1
-    assert _capi.EFFORT == {"default": 0, "fast": 1, "fastest": 2, "thorough": 3, "max": 4, "best": 5, "ultra": 6}  # enum sfh_effort
+    assert _capi.EFFORT == {"default": 0, "fast": 1, "fastest": 2, "thorough": 3, "max": 4, "best": 5, "ultra": 6, "extreme": 7}  # enum sfh_effort
     assert lib.sfh_stage_name(0) == b"k_lz77" and lib.sfh_stage_name(3) == b"k_emit" and lib.sfh_stage_name(9) == b""
     import zlib
     a, b = bytes(range(256)) * 300, b"starflate" * 5000  # host-side checksum combine rules against zlib

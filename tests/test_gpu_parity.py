@@ -109,9 +109,9 @@ def test_effort_fast_bit_exact_vs_oracle(compressor, starfleet):
             _roundtrip(got4, data)
 
 
-@pytest.mark.parametrize("effort", ["best", "ultra"])
+@pytest.mark.parametrize("effort", ["best", "ultra", "extreme"])
 def test_effort_chains_bit_exact_vs_oracle(compressor, starfleet, effort):
-    """SFH_EFFORT_BEST / _ULTRA: exact hash chains of depth 8 / 16 (the specification's chain_depth: every position inserted
+    """SFH_EFFORT_BEST / _ULTRA / _EXTREME: exact hash chains of depth 8 / 16 / 32 (the specification's chain_depth: every position inserted
     and searched, most recent candidate first) -- bit-exact like every other effort, over inputs whose chains look very
     different (text, the reference's HTML file, mixed stripes, one value, short periods, noise), strips that reach past one
     batch of the links' ring, ragged tails, every strategy and lazy level; never larger than the default effort's stream
@@ -166,7 +166,9 @@ def test_largest_and_odd_strips(compressor):
     segments per strip) and at a non-power-of-two multiple of 32 KiB: bit-exact, and decodable on the GPU."""
     data = np.concatenate([synth.gen_text(20 << 20, seed=71), synth.gen_mixed(13 << 20, seed=72, stripe=1 << 18)[: (13 << 20) - 77]])
     for bb, effort, ekw in ((16 << 20, "default", {}), (3 * CHUNK, "default", {}), (16 << 20, "thorough", dict(stride2=0, step=512)), (16 << 20, "max", dict(stride2=0, step=512, hash_bits=12, long_hash_bytes=7)),
-                            (5 * CHUNK, "fastest", dict(depth=1, use_near=0))):
+                            (5 * CHUNK, "fastest", dict(depth=1, use_near=0)),
+                            # chains: the heads' step codes aged a thousand times, the links' ring wrapped four hundred times
+                            (16 << 20, "best", dict(chain_depth=8)), (7 * CHUNK, "ultra", dict(chain_depth=16))):
         got = np.frombuffer(compressor.compress(data, block_bytes=bb, effort=effort), np.uint8)
         assert np.array_equal(got, O.compress(data, O.default_params(strip_bytes=bb, **ekw))), (bb, effort)
         back, st = compressor.decompress(got, compressor.last_index(), data.size, subindex=compressor.last_subindex(), block_bytes=bb)
@@ -247,7 +249,7 @@ def test_stored_fast_path(compressor):
 
 EFFORT_PARAMS = {"default": {}, "fast": {"depth": 1}, "fastest": {"depth": 1, "use_near": 0}, "thorough": {"stride2": 0, "step": 512},
                  "max": {"stride2": 0, "step": 512, "hash_bits": 12, "long_hash_bytes": 7},
-                 "best": {"chain_depth": 8}, "ultra": {"chain_depth": 16}}
+                 "best": {"chain_depth": 8}, "ultra": {"chain_depth": 16}, "extreme": {"chain_depth": 32}}
 
 
 @pytest.mark.parametrize("effort", sorted(EFFORT_PARAMS))
@@ -589,7 +591,7 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
         # every effort: default (even positions searched), thorough (all, steps of 512), fast (one level), fastest (no near)
         effort, ekw = [("default", {}), ("thorough", dict(stride2=0, step=512)), ("best", dict(chain_depth=8)), ("fast", dict(depth=1)),
                        ("fastest", dict(depth=1, use_near=0)), ("max", dict(stride2=0, step=512, hash_bits=12, long_hash_bytes=7)),
-                       ("ultra", dict(chain_depth=16)), ("default", {})][it % 8 if it % 13 else 5]
+                       ("ultra", dict(chain_depth=16)), ("extreme", dict(chain_depth=32))][it % 8 if it % 13 else 5]
         got = np.frombuffer(compressor.compress(data, strategy=strategy, lazy=lazy, stored_fast_path=fast, block_bytes=bb, effort=effort), np.uint8)
         want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=int(fast), strip_bytes=bb, **ekw))
         assert np.array_equal(got, want), (it, total, strategy, lazy, fast, bb, effort, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
