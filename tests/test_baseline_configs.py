@@ -131,7 +131,7 @@ def test_real_bytes_bit_exact(compressor, kind):
         pytest.skip(f"no {kind} corpus in this image")
     off = (buf.size // 2) & ~0xFFFF
     data = buf[off: off + (4 << 20) + 4321]  # ragged tail
-    for effort, kw in (("default", {}), ("thorough", dict(stride2=0, step=512))):
+    for effort, kw in (("default", {}), ("thorough", dict(stride2=0, step=512)), ("best", dict(chain_depth=8))):
         got = np.frombuffer(compressor.compress(data, effort=effort), np.uint8)
         want = O.compress(data, O.default_params(**kw))
         assert got.size == want.size and np.array_equal(got, want), (kind, effort)
