@@ -603,7 +603,7 @@ def main():
                 t = t.repeat(reps)
                 desc += f", repeated x{reps} for throughput"
                 nb *= reps
-            for eff in ("default", "thorough", "max", "best", "ultra", "extreme"):
+            for eff in ("default", "thorough", "max", "chain4", "best", "ultra", "extreme"):
                 others[key if eff == "default" else f"{key}_effort_{eff}"] = secondary_workload(
                     comp, key, nb, dev, 0, effort=eff, data=t, wl=desc)
             del t
@@ -618,7 +618,7 @@ def main():
         others["effort_max"] = secondary_workload(comp, args.workload, n, dev, bb, effort="max", data=data, wl=wl)
         others["mixed_effort_max"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort="max")
         # SFH_EFFORT_BEST / _ULTRA / _EXTREME: exact hash chains of depth 8 / 16 / 32 (zlib's structure) instead of the step tables
-        for eff in ("best", "ultra", "extreme"):
+        for eff in ("chain4", "best", "ultra", "extreme"):  # chain4: sfh_options.chain_depth = 4 with a chain effort
             others[f"effort_{eff}"] = secondary_workload(comp, args.workload, n, dev, bb, effort=eff, data=data, wl=wl)
             others[f"mixed_effort_{eff}"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort=eff)
 

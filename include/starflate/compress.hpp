@@ -55,6 +55,7 @@ struct compress_options {
   Container container{Container::Raw};  // Zlib / Gzip: wrapper + GPU-computed Adler-32 / CRC-32 (needs final_stream)
   int device{0};
   Effort effort{Effort::Default};  // sfh_options.effort
+  std::uint8_t chain_depth{0};     // sfh_options.chain_depth: with Best / Ultra / Extreme, candidates per position (0: 8 / 16 / 32)
   std::uint32_t block_bytes{0};  // bytes coded independently of what precedes them: a multiple of 32768, 0 = default
                                  // (sfh_options.block_bytes); larger compresses better, 32768 = independent DEFLATE blocks
 };
@@ -94,6 +95,7 @@ inline auto to_c(const compress_options& o) -> sfh_options {
   c.container = static_cast<std::uint32_t>(o.container);
   c.block_bytes = o.block_bytes;
   c.effort = static_cast<std::uint32_t>(o.effort);
+  c.chain_depth = o.chain_depth;
   return c;
 }
 }  // namespace detail

@@ -86,7 +86,10 @@ typedef struct sfh_options {
                             its hash tried, nearest first): what closes the gap to zlib -6 on real data, where recency
                             counts for more than on the synthetic text, at a quarter to a tenth of the default's speed;
                             EXTREME is zlib -6's own ratio on the text workload */
-  uint32_t reserved;     /* must be 0 */
+  uint32_t chain_depth;  /* 0: what the effort implies.  With a chain effort (SFH_EFFORT_BEST / _ULTRA / _EXTREME) any depth
+                            1..255 -- candidates per position, most recent first (the specification's chain_depth): 4 is
+                            SFH_EFFORT_MAX's ratio on text and the chains' on real data at 80 K MiB/s.  Must be 0 with the
+                            table efforts (this was the `reserved` word: a caller that zeroes it gets what it got) */
 } sfh_options;
 
 enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1, SFH_EFFORT_FASTEST = 2, SFH_EFFORT_THOROUGH = 3, SFH_EFFORT_MAX = 4,

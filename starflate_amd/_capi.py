@@ -33,7 +33,7 @@ EXPORTS = [
 class Options(C.Structure):
     _fields_ = [("strategy", C.c_uint32), ("final_stream", C.c_uint32), ("lazy", C.c_uint32),
                 ("no_stored_fast_path", C.c_uint32), ("container", C.c_uint32), ("block_bytes", C.c_uint32),
-                ("effort", C.c_uint32), ("reserved", C.c_uint32)]
+                ("effort", C.c_uint32), ("chain_depth", C.c_uint32)]
 
 
 class DeviceProps(C.Structure):
@@ -148,7 +148,10 @@ def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path
     o.no_stored_fast_path = int(not stored_fast_path)
     o.container = CONTAINER[container] if isinstance(container, str) else int(container)
     o.block_bytes = int(block_bytes)
-    o.effort = EFFORT[effort] if isinstance(effort, str) else int(effort)
+    if isinstance(effort, str) and effort.startswith("chain"):  # "chain4": exact hash chains of that depth
+        o.effort, o.chain_depth = EFFORT["best"], int(effort[5:].lstrip(":") or 8)
+    else:
+        o.effort = EFFORT[effort] if isinstance(effort, str) else int(effort)
     return o
 
 

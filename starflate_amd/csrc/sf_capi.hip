@@ -178,7 +178,7 @@ int check_opt(const sfh_options* o) {
   if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 3 || o->no_stored_fast_path > 1) return -1;
   if (o->container > SFH_GZIP || (o->container && !o->final_stream)) return -1;  // a non-final shard has no trailer
   if (o->block_bytes % sf::kChunk || o->block_bytes > sf::kMaxStrip) return -1;
-  if (o->effort > SFH_EFFORT_EXTREME || o->reserved) return -1;
+  if (o->effort > SFH_EFFORT_EXTREME || o->chain_depth > 255 || (o->chain_depth && o->effort < SFH_EFFORT_BEST)) return -1;
   return 0;
 }
 
@@ -213,7 +213,8 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
                        (o.effort == SFH_EFFORT_DEFAULT || o.effort >= SFH_EFFORT_THOROUGH) ? 1u : 0u,
                        o.effort == SFH_EFFORT_FASTEST ? 0u : 1u, o.effort >= SFH_EFFORT_THOROUGH ? 0u : 1u,
                        o.effort == SFH_EFFORT_MAX ? 1u : 0u,
-                       o.effort == SFH_EFFORT_BEST ? 8u : o.effort == SFH_EFFORT_ULTRA ? 16u : o.effort == SFH_EFFORT_EXTREME ? 32u : 0u};
+                       o.effort < SFH_EFFORT_BEST ? 0u : o.chain_depth ? o.chain_depth
+                       : o.effort == SFH_EFFORT_BEST ? 8u : o.effort == SFH_EFFORT_ULTRA ? 16u : 32u};
   ctx->last_block_bytes = ko.strip_bytes;
   const bool prof = ctx->profiling != 0;
   if ((rc = order_behind_last_call(ctx, s)) != SFH_OK) return rc;

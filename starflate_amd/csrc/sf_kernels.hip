@@ -128,26 +128,22 @@ constexpr uint32_t L_WTOT = L_HIST + 4 * kHistStride;        // u32[16] tokens |
 constexpr uint32_t L_DSYM = L_WTOT + 4 * K1_WAVES;            // u8[512] distance - 1 -> symbol: [d] below 256, [256 + (d >> 7)] from there on
 constexpr uint32_t K1_LDS = L_DSYM + 512;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
-// CHAIN (SFH_EFFORT_BEST / _ULTRA): exact hash chains.  One workgroup per CU: behind the 4-bit lengths come the chain
-// HEADS (u16 step codes, one per hash: the LATEST position with it), the LINKS (u16 per position of window + round, a
-// ring indexed by strip position mod kChainRing: the distance to the previous position with the same hash, 0: none),
-// then histogram, wave totals and the distance-symbol table as before
-constexpr uint32_t kChainRing = kWindow + kRound;            // positions that have a link
-constexpr uint32_t C_L_HEAD = L_TABLE;                       // u16[1<<kHashBits]
-constexpr uint32_t C_L_PREV = C_L_HEAD + (2u << kHashBits);  // u16[kChainRing]
-constexpr uint32_t C_L_POST = C_L_PREV + 2 * kChainRing;     // u16[2][kStep]: what the slices post for the serial pass, and what it answers
+// CHAIN (SFH_EFFORT_BEST / _ULTRA / _EXTREME): exact hash chains.  One workgroup per CU: behind the 4-bit lengths come the
+// chain HEADS (one dword per hash holding a 16-bit step code: the LATEST position with it; a dword because they are
+// updated by ds_wrxchg_rtn_b32, see the match phase), the LINKS (u16 per position, a ring indexed by strip position mod
+// kChainRing: the distance to the previous position with the same hash, 0: none), two exchange areas, then histogram,
+// wave totals and the distance-symbol table as before.  The ring holds the window, the step whose chains are being
+// walked and the step being inserted: a walk never reads a slot that the insertion beside it is writing.
+constexpr uint32_t kChainRingSteps = kWindow / kStep + 2;
+constexpr uint32_t kChainRing = kChainRingSteps * kStep;     // positions that have a link
+constexpr uint32_t C_L_HEAD = L_TABLE;                       // u32[1<<kHashBits]
+constexpr uint32_t C_L_PREV = C_L_HEAD + (4u << kHashBits);  // u16[kChainRing]
+constexpr uint32_t C_L_POST = C_L_PREV + 2 * kChainRing;     // u16[2][kStep]: what the threads post for the serial pass, and what it answers
 constexpr uint32_t C_L_HIST = C_L_POST + 4 * kStep;
 constexpr uint32_t C_L_WTOT = C_L_HIST + 4 * kHistStride;
 constexpr uint32_t C_L_DSYM = C_L_WTOT + 4 * K1_WAVES;
 constexpr uint32_t C_K1_LDS = C_L_DSYM + 512;
 static_assert(C_K1_LDS <= 160 * 1024 && C_L_PREV % 16 == 0 && C_L_HIST % 16 == 0 && C_L_WTOT % 16 == 0, "K1 (chains): one workgroup per CU");
-static_assert(kRound * 5 == kChainRing, "the ring index of a round's first position is (round mod 5) * kRound");
-static_assert(L_WTOT % 16 == 0 && L_TABLE % 16 == 0 && L_LEN4 % 16 == 0 && L_HIST % 16 == 0, "LDS alignment");
-static_assert(kCap - 3 <= 15, "capped len-3 fits four bits");
-// the round's distances are staged in the chunk's own item array (k_lz77, match phase): a chunk never holds more items
-// than positions, because a literal is one item and a match, two items, covers at least two positions
-static_assert(kMinMatch >= 2, "distance staging: items <= positions");
-static_assert((kWindow + kLook) % 16 == 0 && kRound % 16 == 0, "window shift in 16-byte units");
 
 // v_ffbl_b32 as the hardware defines it: the lowest set bit, 0xFFFFFFFF for 0 (spelled out, because the C
 // builtins leave 0 undefined or make the compiler add a compare and a select to patch it)
@@ -275,7 +271,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
   [[maybe_unused]] uint32_t* s_table2 = s_table + (1u << HB);  // LONG: the seven-byte table behind the four-byte one
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + LH);
   uint32_t* s_wtot = reinterpret_cast<uint32_t*>(smem + LW);
-  [[maybe_unused]] uint16_t* s_head = reinterpret_cast<uint16_t*>(smem + C_L_HEAD);
+  [[maybe_unused]] uint32_t* s_head = reinterpret_cast<uint32_t*>(smem + C_L_HEAD);
   [[maybe_unused]] uint16_t* s_prev = reinterpret_cast<uint16_t*>(smem + C_L_PREV);
 
   const uint32_t t = threadIdx.x;
@@ -298,7 +294,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
   // ---- prologue: empty table and histogram; the strip's first kLook bytes where the first shift finds them ----
   {
     uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
-    for (uint32_t idx = t; idx < (CHAIN ? 2u : 4u) * (1u << kHashBits) / 16; idx += K1_THREADS) t4[idx] = make_uint4(0, 0, 0, 0);
+    for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) t4[idx] = make_uint4(0, 0, 0, 0);
     for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) s_hist[idx] = (idx == 256) ? 1u : 0u;
     if (t < kLook / 4) s_data[(kWindow + kRound) / 4 + t] = load4(4 * t);
     if (t < 4) s_len4[kRound / 8 + t] = 0;  // pad read by the take pass
@@ -353,7 +349,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         constexpr uint32_t kSub2 = (kEpS << SH) * 0x00010001u;
         uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
         static_assert((1u << kHashBits) % (4 * K1_THREADS) == 0, "ageing: whole 16-byte units per thread");
-        for (uint32_t idx = t; idx < (CHAIN ? 2u : 4u) * (1u << kHashBits) / 16; idx += K1_THREADS) {
+        for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) {
           uint4 e = t4[idx];
           asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.x) : "s"(kSub2));
           asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.y) : "s"(kSub2));
@@ -394,25 +390,27 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       __builtin_amdgcn_s_setprio(2);
       if constexpr (CHAIN) {
         // ---- exact hash chains (the specification's chain_depth > 0) ----
-        // A step is 1024 positions, one per thread.  INSERTION is serial in the position, but only where hashes meet:
-        // every wave finds the equal hashes inside its own 64-position slice by ballots (a lane's predecessor is the
-        // nearest lower lane with its hash) and posts, per position, the hash and whether it is the first / the last of
-        // its hash in the slice.  ONE wave (they take turns) then runs through the sixteen slices in order -- a first reads
-        // its predecessor from the heads, a last writes the head; one wave's LDS operations execute in order, so no
-        // barrier is needed between slices -- while the others WALK the chains of the step before, whose links are
-        // complete (the links a walk follows are older than anything being inserted).  Three barriers per step.
+        // A step is 1024 positions, one per thread.  INSERTION is serial in the position -- a position's link is the latest
+        // EARLIER position with its hash -- and one LDS instruction does it for 64 positions at once: ds_wrxchg_rtn_b32
+        // executes the lanes of a wave-instruction in ASCENDING LANE ORDER where they meet at one address
+        // (tools/micro/lds_xchg_order.hip: 472 M lane observations on every CU, no exception; tests/test_gpu_parity.py runs
+        // it as a guard), so `old = exchange(head[hash], own code)` hands every lane the nearest lower lane with its hash,
+        // or what the head held before the slice, and leaves the slice's last position of every hash in the head.  Every
+        // thread posts its hash; ONE wave (they take turns) then issues the sixteen slices' exchanges in order, back to
+        // back -- the LDS executes a wave's operations in the order they were issued, so no barrier is needed between
+        // slices -- while the others WALK the chains of the step before, whose links are complete (the links a walk follows
+        // are older than anything being inserted).  Three barriers per step.
         static_assert(STEP == K1_THREADS && K1_WAVES == 16, "one position per thread and step, sixteen slices");
-        uint16_t* const s_post = reinterpret_cast<uint16_t*>(smem + C_L_POST);  // [STEP] hash | first << 13 | last << 14
-        uint16_t* const s_hv = s_post + STEP;                                    // [STEP] what the heads held for a first
-        static_assert(kHashBits == 13, "posted entry layout");
-        const uint32_t ringb = (r % 5u) * kRound;            // (uniform) ring index of the round's first position
+        uint16_t* const s_post = reinterpret_cast<uint16_t*>(smem + C_L_POST);  // [STEP] hash | inserted << 15
+        uint16_t* const s_hv = s_post + STEP;                                    // [STEP] the head's code before the position went in
+        static_assert(kHashBits <= 15, "posted entry layout");
+        const uint32_t ring0 = (r * (kRound / STEP)) % kChainRingSteps;  // (uniform) ring step of the round's first step
         uint8_t* const gst = reinterpret_cast<uint8_t*>(gi) + stage_off;
         const uint32_t sh0 = t & 3u;
-        const uint64_t below = (1ull << lane) - 1ull;        // the lanes before this one
         const uint32_t to_rend = kRegion - (t & (kRegion - 1));
         const uint32_t mlen0 = to_rend < kCap ? to_rend : kCap;
         // the walk of the position this thread owns in the step before
-        uint32_t w_a0 = 0, w_a1 = 0, w_a2 = 0, w_a3 = 0, w_maxlen = 0, w_tot = 0, w_best = 0, w_bdist = 0, w_q = 0;
+        uint32_t w_a0 = 0, w_a1 = 0, w_a2 = 0, w_a3 = 0, w_maxlen = 0, w_tot = 0, w_best = 0, w_bdist = 0, w_q = 0, w_idx = 0;
         bool w_act = false;
         // One candidate of a walk: the 16 bytes at distance `tot` behind the position (five dwords, whatever its alignment)
         // and its own link.  (Measured and not kept: the same bytes as three aligned ds_read_b64 + selects, 21.8 against
@@ -423,7 +421,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         struct Cand { uint32_t p0, p1, p2, p3, p4, dn, csh; };
         auto fetch = [&](uint32_t tot) -> Cand {
           const uint32_t c = (kWindow + w_q) - tot;            // the candidate's LDS byte address (inside the window)
-          int32_t ci = (int32_t)(ringb + w_q) - (int32_t)tot;
+          int32_t ci = (int32_t)w_idx - (int32_t)tot;
           ci += (ci >> 31) & (int32_t)kChainRing;              // ... and its ring index
           const uint32_t cw = c >> 2;
           Cand k;
@@ -455,8 +453,8 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         for (uint32_t it = 0; it <= nsteps; ++it) {
           const uint32_t sb = it * STEP;                       // (uniform) the step's first position, round-relative
           const uint32_t q = sb + t;
-          bool ins = false, isfirst = false, islast = false;
-          uint32_t h = 0, dl = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+          bool ins = false;
+          uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
           const uint32_t code = ((rb / STEP + it - ebase + 1) << SH) | t;  // step code | index in the step: ascending in the position
           if (it < nsteps) {
             const uint32_t wb = kWindow + (q & ~3u);
@@ -465,48 +463,29 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
                            d4 = *reinterpret_cast<const uint32_t*>(smem + wb + 16);
             a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0); a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
             a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0); a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
-            h = (a0 * 2654435761u) >> (32 - kHashBits);
+            const uint32_t h = (a0 * 2654435761u) >> (32 - kHashBits);
             ins = rb + q + kMinMatch <= n;                     // the specification inserts and searches what has four bytes left
-            // the lanes of this wave with the same hash, one ballot per hash bit
-            // (in 32-bit halves, the ballot and its complement as scalars: a compare, two selects and two ANDs per bit)
-            const uint64_t all = __builtin_amdgcn_ballot_w64(ins);
-            uint32_t slo = (uint32_t)all, shi = (uint32_t)(all >> 32);
-#pragma unroll
-            for (uint32_t b = 0; b < kHashBits; ++b) {
-              const bool bit = (h & (1u << b)) != 0;
-              const uint64_t bb = __builtin_amdgcn_ballot_w64(bit), nb = ~bb;
-              slo &= bit ? (uint32_t)bb : (uint32_t)nb;
-              shi &= bit ? (uint32_t)(bb >> 32) : (uint32_t)(nb >> 32);
-            }
-            const uint32_t llo = slo & (uint32_t)below, lhi = shi & (uint32_t)(below >> 32);   // the lanes before this one
-            const uint32_t ulo = slo & ~(uint32_t)below, uhi = shi & ~(uint32_t)(below >> 32); // this one and those behind it
-            isfirst = ins && (llo | lhi) == 0;
-            islast = ins && __builtin_popcount(ulo) + __builtin_popcount(uhi) == 1;
-            dl = lhi ? lane - (63u - (uint32_t)__builtin_clz(lhi)) : llo ? lane - (31u - (uint32_t)__builtin_clz(llo)) : 0u;
+            s_post[t] = (uint16_t)(h | (ins ? 1u << 15 : 0u));
           }
-          if (it < nsteps) s_post[t] = (uint16_t)(h | (isfirst ? 1u << 13 : 0u) | (islast ? 1u << 14 : 0u));
           lds_barrier();
-          if (it < nsteps && wave == (it & (K1_WAVES - 1))) {  // (uniform) this wave's turn: the step's heads, slice by slice
+          if (it < nsteps && wave == (it & (K1_WAVES - 1))) {  // (uniform) this wave's turn: the step goes into the heads, slice by slice
             // Nothing here waits for an answer before the next request goes out: the sixteen posted entries are fetched
-            // together, then read-head / write-head pairs follow one another slice by slice -- the LDS executes a wave's
-            // operations in the order they were issued, which is all the heads need -- and the answers are stored at the end
+            // together, the sixteen exchanges follow one another, the answers are stored at the end
             const uint32_t code0 = ((rb / STEP + it - ebase + 1) << SH) | lane;
             uint32_t e[K1_WAVES], old[K1_WAVES];
 #pragma unroll
             for (uint32_t sl = 0; sl < K1_WAVES; ++sl) e[sl] = s_post[sl * 64 + lane];
 #pragma unroll
             for (uint32_t sl = 0; sl < K1_WAVES; ++sl) {
-              const uint32_t hh = e[sl] & ((1u << kHashBits) - 1u);
-              // (every lane reads, a lane that is no first ignores the answer: no divergent branch between the LDS operations)
-              old[sl] = s_head[hh];
-              if (e[sl] & (1u << 14)) s_head[hh] = (uint16_t)(code0 + sl * 64);
+              old[sl] = 0;
+              if (e[sl] & (1u << 15)) old[sl] = atomicExch(&s_head[e[sl] & ((1u << kHashBits) - 1u)], code0 + sl * 64);
             }
 #pragma unroll
             for (uint32_t sl = 0; sl < K1_WAVES; ++sl) s_hv[sl * 64 + lane] = (uint16_t)old[sl];
           }
           if (it >= 1) walk_chain();
           lds_barrier();
-          const uint32_t hv = (it < nsteps && isfirst) ? s_hv[t] : 0u;
+          const uint32_t hv = (it < nsteps && ins) ? s_hv[t] : 0u;
           if (it >= 1) {
             // ---- the position of the step before is settled: its length and distance go where the parse finds them ----
             const uint32_t bd1 = w_bdist - 1u;                 // distance - 1 (what is staged; only read where there is a match)
@@ -519,9 +498,13 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
                          :: "v"(w_q >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
           }
           if (it < nsteps) {
-            // the position's link: the nearest lower lane with its hash, or what the heads held (empty, or aged out: none)
-            const uint32_t d = !ins ? 0u : (!isfirst ? dl : (hv >= STEP ? code - hv : 0u));
-            s_prev[ringb + q] = (uint16_t)d;
+            // the position's link: the distance to what the head named before it went in -- an earlier position of this
+            // step or any before; an empty head, or one aged out (older than the window anyway): none
+            const uint32_t d = (ins && hv >= STEP) ? code - hv : 0u;
+            uint32_t rs = ring0 + it;                          // (uniform) the step's place in the ring
+            rs -= rs >= kChainRingSteps ? kChainRingSteps : 0u;
+            w_idx = rs * STEP + t;
+            s_prev[w_idx] = (uint16_t)d;
             w_a0 = a0; w_a1 = a1; w_a2 = a2; w_a3 = a3; w_q = q;
             w_maxlen = (uint32_t)max(min((int)(qn - sb) - (int)t, (int)mlen0), 0);
             w_tot = d; w_best = 0; w_bdist = 0;

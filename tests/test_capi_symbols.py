@@ -31,7 +31,7 @@ def test_host_side_entry_points_without_gpu():
     o = _capi.Options()
     lib.sfh_default_options(C.byref(o))
     assert (o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path, o.container, o.block_bytes, o.effort) == (0, 1, 3, 0, 0, 0, 0)
-    assert o.reserved == 0 and C.sizeof(o) == 32
+    assert o.chain_depth == 0 and C.sizeof(o) == 32
     for bb in (0, 32768, 262144):  # sfh_compress_bound(n, block_bytes); per 32 KiB DEFLATE block
         assert lib.sfh_compress_bound(0, bb) == 32768 + 4096 + 640
         assert lib.sfh_compress_bound(32768, bb) == 32768 + 4096 + 640

@@ -136,6 +136,17 @@ def test_effort_chains_bit_exact_vs_oracle(compressor, starfleet, effort):
             got = np.frombuffer(compressor.compress(text, effort=effort, strategy=strategy, lazy=lazy, stored_fast_path=False), np.uint8)
             want = O.compress(text, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=0, **EFFORT_PARAMS[effort]))
             assert np.array_equal(got, want), (strategy, lazy)
+    if effort == "best":
+        # sfh_options.chain_depth: any depth with a chain effort ("chain4" = SFH_EFFORT_BEST with chain_depth 4); not with a table effort
+        for depth in (1, 2, 4, 5, 33):
+            got = np.frombuffer(compressor.compress(text, effort=f"chain{depth}"), np.uint8)
+            assert np.array_equal(got, O.compress(text, O.default_params(chain_depth=depth))), depth
+        o = _capi.make_options(effort="thorough")
+        o.chain_depth = 4
+        import ctypes as C
+        n_out = C.c_size_t(0)
+        buf = np.empty(compressor.compress_bound(text.size), np.uint8)
+        assert compressor._lib.sfh_compress(compressor._h, text.ctypes.data, text.size, buf.ctypes.data, buf.size, C.byref(n_out), C.byref(o)) == -1
     # the GPU decoder reads these streams like any other (index + sub-index)
     got = compressor.compress(text, effort=effort)
     back, st = compressor.decompress(got, compressor.last_index(), text.size, subindex=compressor.last_subindex(), block_bytes=compressor.last_block_bytes())
@@ -662,3 +673,20 @@ def test_compress_multi_is_bit_identical_to_one_call(compressor, starfleet):
         compress_multi([ctxs[0], ctxs[0]], text)  # the same context twice
     for c in ctxs:
         c.close()
+
+
+def test_lds_exchange_executes_lanes_in_ascending_order(tmp_path):
+    """The chain efforts insert 64 positions with one ds_wrxchg_rtn_b32 and rely on the LDS executing the lanes of that
+    instruction in ascending lane order where they meet at one address (each lane gets the nearest lower lane with its
+    hash).  That is measured behaviour of gfx950, not an architectural promise: this guard runs the micro-test on the
+    device the suite runs on, so a part or a driver that orders them differently fails HERE and not as a wrong stream."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = tmp_path / "lds_xchg_order"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-Wno-unused-value",
+                           os.path.join(ROOT, "tools", "micro", "lds_xchg_order.hip"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ascending lane order holds" in out.stdout, out.stdout + out.stderr
