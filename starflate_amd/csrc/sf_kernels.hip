@@ -399,7 +399,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         // thread posts its hash; ONE wave (they take turns) then issues the sixteen slices' exchanges in order, back to
         // back -- the LDS executes a wave's operations in the order they were issued, so no barrier is needed between
         // slices -- while the others WALK the chains of the step before, whose links are complete (the links a walk follows
-        // are older than anything being inserted).  Three barriers per step.
+        // are older than anything being inserted).  Two barriers per step.
         static_assert(STEP == K1_THREADS && K1_WAVES == 16, "one position per thread and step, sixteen slices");
         uint16_t* const s_post = reinterpret_cast<uint16_t*>(smem + C_L_POST);  // [STEP] hash | inserted << 15
         uint16_t* const s_hv = s_post + STEP;                                    // [STEP] the head's code before the position went in
@@ -450,24 +450,31 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             cur = nxt;
           }
         };
+        // [A] of a step: the position's bytes and hash, posted for the serial pass.  It runs one stage AHEAD (for step 0 before
+        // the loop, for step it + 1 at the end of iteration it), so a step costs two barriers, not three: the barrier that
+        // makes a step's links visible is also the one that makes the next step's posts visible.
+        uint32_t n_a0 = 0, n_a1 = 0, n_a2 = 0, n_a3 = 0;
+        bool n_ins = false;
+        auto stage_a = [&](uint32_t st) {                      // st: (uniform) step index in the round, < nsteps
+          const uint32_t q = st * STEP + t;
+          const uint32_t wb = kWindow + (q & ~3u);
+          const uint32_t d0 = *reinterpret_cast<const uint32_t*>(smem + wb), d1 = *reinterpret_cast<const uint32_t*>(smem + wb + 4),
+                         d2 = *reinterpret_cast<const uint32_t*>(smem + wb + 8), d3 = *reinterpret_cast<const uint32_t*>(smem + wb + 12),
+                         d4 = *reinterpret_cast<const uint32_t*>(smem + wb + 16);
+          n_a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0); n_a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
+          n_a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0); n_a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
+          const uint32_t h = (n_a0 * 2654435761u) >> (32 - kHashBits);
+          n_ins = rb + q + kMinMatch <= n;                     // the specification inserts and searches what has four bytes left
+          s_post[t] = (uint16_t)(h | (n_ins ? 1u << 15 : 0u));
+        };
+        if (nsteps) stage_a(0);
+        lds_barrier();
         for (uint32_t it = 0; it <= nsteps; ++it) {
           const uint32_t sb = it * STEP;                       // (uniform) the step's first position, round-relative
           const uint32_t q = sb + t;
-          bool ins = false;
-          uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+          const bool ins = it < nsteps && n_ins;
+          const uint32_t a0 = n_a0, a1 = n_a1, a2 = n_a2, a3 = n_a3;
           const uint32_t code = ((rb / STEP + it - ebase + 1) << SH) | t;  // step code | index in the step: ascending in the position
-          if (it < nsteps) {
-            const uint32_t wb = kWindow + (q & ~3u);
-            const uint32_t d0 = *reinterpret_cast<const uint32_t*>(smem + wb), d1 = *reinterpret_cast<const uint32_t*>(smem + wb + 4),
-                           d2 = *reinterpret_cast<const uint32_t*>(smem + wb + 8), d3 = *reinterpret_cast<const uint32_t*>(smem + wb + 12),
-                           d4 = *reinterpret_cast<const uint32_t*>(smem + wb + 16);
-            a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0); a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
-            a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0); a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
-            const uint32_t h = (a0 * 2654435761u) >> (32 - kHashBits);
-            ins = rb + q + kMinMatch <= n;                     // the specification inserts and searches what has four bytes left
-            s_post[t] = (uint16_t)(h | (ins ? 1u << 15 : 0u));
-          }
-          lds_barrier();
           if (it < nsteps && wave == (it & (K1_WAVES - 1))) {  // (uniform) this wave's turn: the step goes into the heads, slice by slice
             // Nothing here waits for an answer before the next request goes out: the sixteen posted entries are fetched
             // together, the sixteen exchanges follow one another, the answers are stored at the end
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
           }
           if (it >= 1) walk_chain();
           lds_barrier();
-          const uint32_t hv = (it < nsteps && ins) ? s_hv[t] : 0u;
+          const uint32_t hv = ins ? s_hv[t] : 0u;
           if (it >= 1) {
             // ---- the position of the step before is settled: its length and distance go where the parse finds them ----
             const uint32_t bd1 = w_bdist - 1u;                 // distance - 1 (what is staged; only read where there is a match)
@@ -509,8 +516,9 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             w_maxlen = (uint32_t)max(min((int)(qn - sb) - (int)t, (int)mlen0), 0);
             w_tot = d; w_best = 0; w_bdist = 0;
             w_act = d != 0 && d <= kWindow && w_maxlen >= kMinMatch;
+            if (it + 1 < nsteps) stage_a(it + 1);              // (the posts of this step were read before the barrier above)
           }
-          lds_barrier();  // the step's links are in place before anything walks over them
+          lds_barrier();  // the step's links and the next step's posts are in place
         }
       } else {
         // A step has 512 searches for 1024 threads: the even positions of 1024 (STRIDE2), or all of 512 (thorough).  The
