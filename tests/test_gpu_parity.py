@@ -169,6 +169,12 @@ def test_batches_give_the_stream_of_one_launch(monkeypatch):
             assert np.array_equal(c.last_index(), widx) and np.array_equal(c.last_subindex(), wsub)
             back, st = c.decompress(got, c.last_index(), data.size, subindex=c.last_subindex(), block_bytes=c.last_block_bytes())
             assert st == 0 and back == data.tobytes()
+        # a chain effort through the same loop, wrapped and as a non-final shard
+        got = np.frombuffer(c.compress(data, block_bytes=bb, container="zlib", effort="best"), np.uint8)
+        want = O.compress(data, O.default_params(strip_bytes=bb, container=_capi.CONTAINER["zlib"], chain_depth=8))
+        assert np.array_equal(got, want), (bc, bb, "best/zlib")
+        got = np.frombuffer(c.compress(data, block_bytes=bb, final_stream=False, effort="chain3"), np.uint8)
+        assert np.array_equal(got, O.compress(data, O.default_params(strip_bytes=bb, final_stream=0, chain_depth=3))), (bc, bb, "chain3/shard")
         c.close()
 
 
