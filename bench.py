@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the MI355X DEFLATE compressor.
 
 Workload (BASELINE.json configs[2]): 1 GiB synthetic enwik-like text per GPU, compressed in strips of
-sfh_options.block_bytes (default 256 KiB: a 32 KiB window sliding over eight 32 KiB DEFLATE blocks), input
+sfh_options.block_bytes (default at this size 512 KiB: a 32 KiB window sliding over sixteen 32 KiB DEFLATE blocks), input
 resident in HBM when the timed region starts.  A "step" = one pass of the whole hot path (k_lz77 -> k_plan ->
 k_scan -> k_emit) over that input; with N > 1 every rank compresses its own 1 GiB (weak scaling) and the
 byte-aligned streams are concatenated on rank 0 over RCCL.  For N > 1 the sharding is block-cyclic in --rounds
@@ -315,7 +315,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=1 << 30, help="input bytes per GPU")
     ap.add_argument("--workload", default="text", choices=["text", "random", "mixed", "runs"])
     ap.add_argument("--effort", default="default", choices=["default", "fast", "fastest", "thorough", "max", "best", "ultra", "extreme"], help="sfh_options.effort of the timed steps")
-    ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default, 256 KiB at this size)")
+    ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default: 512 KiB at 1 GiB, 1 MiB with the chain efforts)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the e2e leg and the other two workloads")
@@ -395,7 +395,7 @@ def main():
     comp.set_profiling(True)
     K = max(1, args.rounds) if multi else 1
     # every piece is compressed with the strip size of the whole shard, so rounds do not change the stream's ratio
-    bb = _capi.resolve_block_bytes(args.block_bytes, n)
+    bb = _capi.resolve_block_bytes(args.block_bytes, n, args.effort)
     if n % (K * bb):
         raise SystemExit("--bytes must be a multiple of rounds * block_bytes")
     pieces = list(data.chunk(K))
@@ -619,7 +619,8 @@ def main():
         others["mixed_effort_max"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort="max")
         # SFH_EFFORT_BEST / _ULTRA / _EXTREME: exact hash chains of depth 8 / 16 / 32 (zlib's structure) instead of the step tables
         for eff in ("chain4", "best", "ultra", "extreme"):  # chain4: sfh_options.chain_depth = 4 with a chain effort
-            others[f"effort_{eff}"] = secondary_workload(comp, args.workload, n, dev, bb, effort=eff, data=data, wl=wl)
+            # (block_bytes 0: the chain efforts' own default strip, 1 MiB at this size)
+            others[f"effort_{eff}"] = secondary_workload(comp, args.workload, n, dev, 0, effort=eff, data=data, wl=wl)
             others[f"mixed_effort_{eff}"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort=eff)
 
     # ---- CPU baseline: oracle restatement of the reference decompress(), 1 thread ----

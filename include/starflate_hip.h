@@ -67,8 +67,9 @@ typedef struct sfh_options {
   uint32_t container;    /* enum sfh_container; SFH_ZLIB / SFH_GZIP need final_stream = 1.  The checksum is
                             computed on the GPU from the same device buffer (two more launches) */
   uint32_t block_bytes;  /* bytes of input coded independently of what precedes them (a "strip"): a multiple of
-                            32768 up to 16 MiB; 0 (default) = SFH_DEFAULT_BLOCK_BYTES, less for inputs too small to
-                            fill the device with strips of that size (a function of n alone).  A strip is written
+                            32768 up to 16 MiB; 0 (default) = SFH_DEFAULT_BLOCK_BYTES, more (SFH_LARGE_BLOCK_BYTES,
+                            SFH_CHAIN_BLOCK_BYTES with the chain efforts) for inputs of half a GiB and up, less for inputs
+                            too small to fill the device with strips of that size (a function of n and the effort alone).  A strip is written
                             as one byte-aligned DEFLATE block per 32 KiB; inside it the 32 KiB window slides across
                             those blocks (src/decompress.cpp:178 only requires distance <= bytes written), so
                             larger strips compress better; 32768 makes every DEFLATE block independent */
@@ -96,6 +97,10 @@ enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1, SFH_EFFORT_FASTES
                   SFH_EFFORT_BEST = 5, SFH_EFFORT_ULTRA = 6, SFH_EFFORT_EXTREME = 7 };
 
 #define SFH_DEFAULT_BLOCK_BYTES 262144u
+/* block_bytes = 0 on inputs large enough to fill the device four times over with strips of that size (2048 / 1024 of them):
+ * 512 KiB, 1 MiB with SFH_EFFORT_BEST and above */
+#define SFH_LARGE_BLOCK_BYTES 524288u
+#define SFH_CHAIN_BLOCK_BYTES 1048576u
 
 /* fills *o with defaults: AUTO, final_stream=1, lazy=3, block_bytes=0, effort=SFH_EFFORT_DEFAULT */
 void sfh_default_options(sfh_options* o);

@@ -958,11 +958,14 @@ static void emit_chunk(const uint8_t* data, uint32_t n, const uint32_t* tokens,
   }
 }
 
-/* strip_bytes = 0: the largest power-of-two multiple of chunk_bytes up to SFO_DEFAULT_STRIP chunks' worth that still
- * gives SFO_MIN_STRIPS strips (a function of n alone; the GPU library uses the same rule for block_bytes = 0) */
+/* strip_bytes = 0: the largest power-of-two multiple of chunk_bytes up to SFO_DEFAULT_STRIP chunks' worth (SFO_CHAIN_STRIP
+ * with hash chains) that still gives SFO_MIN_STRIPS strips (a function of n and of the matcher alone; the GPU library uses
+ * the same rule for block_bytes = 0) */
 size_t sfo_resolve_strip_bytes(const sfo_params* p, size_t n) {
   if (p->strip_bytes) return p->strip_bytes;
-  size_t b = (size_t)p->chunk_bytes * SFO_DEFAULT_STRIP_CHUNKS;
+  const size_t base = (size_t)p->chunk_bytes * SFO_DEFAULT_STRIP_CHUNKS;
+  size_t b = (size_t)p->chunk_bytes * (p->chain_depth ? SFO_CHAIN_STRIP_CHUNKS : SFO_LARGE_STRIP_CHUNKS);
+  while (b > base && n / b < (p->chain_depth ? SFO_CHAIN_MIN_STRIPS : SFO_LARGE_MIN_STRIPS)) b >>= 1;
   while (b > p->chunk_bytes && n / b < SFO_MIN_STRIPS) b >>= 1;
   return b;
 }

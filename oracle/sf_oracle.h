@@ -121,7 +121,15 @@ typedef struct sfo_params {
 } sfo_params;
 
 #define SFO_WINDOW 32768u
-#define SFO_DEFAULT_STRIP_CHUNKS 8u /* 256 KiB strips of 32 KiB chunks */
+#define SFO_DEFAULT_STRIP_CHUNKS 8u /* 256 KiB strips of 32 KiB chunks ... */
+/* ... and larger ones for inputs that still fill the device several times over with them (a strip starts with an empty
+ * window: fewer starts, a better ratio; the match kernel's time per byte does not change):
+ *   step tables: 512 KiB while that gives 2048 strips (two workgroups per CU: four rounds of workgroups)
+ *   hash chains: 1 MiB   while that gives 1024 strips (one workgroup per CU: four rounds) */
+#define SFO_LARGE_STRIP_CHUNKS 16u
+#define SFO_LARGE_MIN_STRIPS 2048u
+#define SFO_CHAIN_STRIP_CHUNKS 32u
+#define SFO_CHAIN_MIN_STRIPS 1024u
 #define SFO_MIN_STRIPS 256u
 size_t sfo_resolve_strip_bytes(const sfo_params* p, size_t n);
 

@@ -17,6 +17,8 @@ DBG_NTOK, DBG_TOKENS, DBG_HIST, DBG_PLAN, DBG_LENS, DBG_OFFSETS, DBG_STAMPS = ra
 DBG_SUBINDEX = 7
 DBG_ITEMS, DBG_NITEMS = 8, 9
 DEFAULT_BLOCK_BYTES = 262144
+LARGE_BLOCK_BYTES = 1 << 19
+CHAIN_BLOCK_BYTES = 1 << 20
 SUBINDEX_WORDS = 64
 
 # every symbol include/starflate_hip.h declares
@@ -155,11 +157,15 @@ def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path
     return o
 
 
-def resolve_block_bytes(block_bytes, n):
-    """What sfh_options.block_bytes = 0 stands for on an input of n bytes (mirrors sf_capi.hip)."""
+def resolve_block_bytes(block_bytes, n, effort="default"):
+    """What sfh_options.block_bytes = 0 stands for on an input of n bytes (mirrors sf_capi.hip): up to 256 KiB, 1 MiB with
+    the chain efforts."""
     if block_bytes:
         return int(block_bytes)
-    b = DEFAULT_BLOCK_BYTES
+    chain = isinstance(effort, str) and (effort.startswith("chain") or EFFORT.get(effort, 0) >= EFFORT["best"])
+    b = CHAIN_BLOCK_BYTES if chain else LARGE_BLOCK_BYTES
+    while b > DEFAULT_BLOCK_BYTES and n // b < (1024 if chain else 2048):
+        b >>= 1
     while b > SEGMENT_BYTES and n // b < 256:
         b >>= 1
     return b

@@ -151,11 +151,15 @@ int ensure_dtok(sfh_ctx* ctx, uint32_t nseg) {
 
 uint32_t chunks_of(size_t n) { return n ? (uint32_t)((n + sf::kChunk - 1) / sf::kChunk) : 1u; }
 
-// block_bytes = 0: the largest power-of-two strip up to SFH_DEFAULT_BLOCK_BYTES that still leaves a
-// workgroup per CU of a 256-CU device (a function of n alone, so the stream is too)
-uint32_t resolve_block_bytes(uint32_t block_bytes, size_t n) {
+// block_bytes = 0: SFH_DEFAULT_BLOCK_BYTES -- larger (SFH_LARGE_BLOCK_BYTES, SFH_CHAIN_BLOCK_BYTES with a chain effort)
+// while the input still fills the device four times over with such strips (a strip starts with an empty window: fewer
+// starts, a better ratio, the same time per byte), smaller while it has fewer than 256 strips.  A function of n and the
+// effort alone, so the stream is too; the oracle's sfo_resolve_strip_bytes is the same rule
+uint32_t resolve_block_bytes(uint32_t block_bytes, size_t n, uint32_t effort = SFH_EFFORT_DEFAULT) {
   if (block_bytes) return block_bytes;
-  uint32_t b = SFH_DEFAULT_BLOCK_BYTES;
+  const bool chain = effort >= SFH_EFFORT_BEST;
+  uint32_t b = chain ? SFH_CHAIN_BLOCK_BYTES : SFH_LARGE_BLOCK_BYTES;
+  while (b > SFH_DEFAULT_BLOCK_BYTES && n / b < (chain ? 1024u : 2048u)) b >>= 1;
   while (b > sf::kChunk && n / b < 256) b >>= 1;
   return b;
 }
@@ -209,7 +213,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   if (rc) return rc;
   ctx->last_chunks = nchunks;
   const sf::Options ko{o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path ? 0u : 1u,
-                       resolve_block_bytes(o.block_bytes, n),
+                       resolve_block_bytes(o.block_bytes, n, o.effort),
                        (o.effort == SFH_EFFORT_DEFAULT || o.effort >= SFH_EFFORT_THOROUGH) ? 1u : 0u,
                        o.effort == SFH_EFFORT_FASTEST ? 0u : 1u, o.effort >= SFH_EFFORT_THOROUGH ? 0u : 1u,
                        o.effort == SFH_EFFORT_MAX ? 1u : 0u,
@@ -666,7 +670,7 @@ int sfh_compress_multi(sfh_ctx* const* ctxs, int nctx, const void* src, size_t n
   if (opt) o = *opt; else sfh_default_options(&o);
   // the strip size is fixed once, from the whole input: every shard is a whole number of strips, so the
   // shards' streams are exactly the pieces of the single-call stream
-  o.block_bytes = resolve_block_bytes(o.block_bytes, n);
+  o.block_bytes = resolve_block_bytes(o.block_bytes, n, o.effort);
   // shards: equal numbers of strips, the tail shards may be empty (they then contribute nothing)
   const size_t cps = o.block_bytes / sf::kChunk;  // chunks per strip
   const size_t nstrips = n ? (n + o.block_bytes - 1) / o.block_bytes : 1;

@@ -39,11 +39,14 @@ def test_host_side_entry_points_without_gpu():
     for bb in (1000, 32768 + 1, (16 << 20) + 32768):  # what sfh_compress rejects has no bound
         assert lib.sfh_compress_bound(32768, bb) == 0
     assert lib.sfh_compress_bound(1 << 20, 16 << 20) == 32 * (32768 + 4096 + 640)
-    assert _capi.resolve_block_bytes(0, 1 << 30) == 262144 and _capi.resolve_block_bytes(0, 1 << 20) == 32768
+    assert _capi.resolve_block_bytes(0, 1 << 30) == 524288 and _capi.resolve_block_bytes(0, 512 << 20) == 262144 and _capi.resolve_block_bytes(0, 1 << 20) == 32768
     import oracle_lib as O  # the specification's rule for strip_bytes = 0 is the library's for block_bytes = 0
 
     for n in (0, 1, 32768, 8 << 20, (8 << 20) + 1, 16 << 20, 64 << 20, (64 << 20) - 1, 1 << 30, 5 << 30):
         assert _capi.resolve_block_bytes(0, n) == O.resolve_strip_bytes(O.default_params(), n), n
+        for eff, depth in (("best", 8), ("extreme", 32), ("chain4", 4)):  # the chain efforts: up to 1 MiB
+            assert _capi.resolve_block_bytes(0, n, eff) == O.resolve_strip_bytes(O.default_params(chain_depth=depth), n), (n, eff)
+    assert _capi.resolve_block_bytes(0, 1 << 30, "ultra") == 1 << 20 and _capi.resolve_block_bytes(0, 256 << 20, "best") == 262144
     # sfh_gather_offsets: where every rank's stream lands on the root (host arithmetic of sfh_gather_streams)
     sizes, off = (C.c_uint64 * 4)(10, 0, 7, 3), (C.c_uint64 * 5)()
     assert lib.sfh_gather_offsets(sizes, 4, 5, 25, off) == 0 and list(off) == [5, 15, 15, 22, 25]
