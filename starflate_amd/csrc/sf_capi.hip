@@ -154,7 +154,7 @@ uint32_t chunks_of(size_t n) { return n ? (uint32_t)((n + sf::kChunk - 1) / sf::
 // block_bytes = 0: SFH_DEFAULT_BLOCK_BYTES -- larger (SFH_LARGE_BLOCK_BYTES, SFH_CHAIN_BLOCK_BYTES with a chain effort)
 // while the input still fills the device four times over with such strips (a strip starts with an empty window: fewer
 // starts, a better ratio, the same time per byte), smaller while it has fewer than 256 strips.  A function of n and the
-// effort alone, so the stream is too; the oracle's sfo_resolve_strip_bytes is the same rule
+// effort alone, so the stream is too (the encoder specification states the same rule)
 uint32_t resolve_block_bytes(uint32_t block_bytes, size_t n, uint32_t effort = SFH_EFFORT_DEFAULT) {
   if (block_bytes) return block_bytes;
   const bool chain = effort >= SFH_EFFORT_BEST;
