@@ -216,20 +216,32 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
 
   uint32_t wbase = 0, wvalid = 0;  // the window in LDS: first dword index, dwords it holds
   uint32_t pbase = 0, pvalid = 0;  // the one on its way
+  bool pending = false;            // ... if one is
   Dwords4 p0{0, 0, 0, 0}, p1{0, 0, 0, 0};
-  auto load_window = [&]() {
-    pbase = ab >> 5;
-    const uint32_t avail = (active && last >= pbase) ? last - pbase + 1u : 0u;  // dwords readable from there
-    pvalid = avail < kWinDwords ? (avail & ~3u) : kWinDwords;                   // whole 16-byte chunks
-    if (pvalid > 0) p0 = *reinterpret_cast<const Dwords4*>(seg32 + pbase);
-    if (pvalid > 4) p1 = *reinterpret_cast<const Dwords4*>(seg32 + pbase + 4);
+  // A period of four tokens takes 38 bits of a text stream on average, 192 at the very most, and a window holds 256: a
+  // lane asks for the next one only once it is kReload dwords into the one it has (round 4; before: every period, 32
+  // bytes requested per 5 consumed -- most of k_inflate_tokens_sub's 12 GB of reads per GiB).  A lane that then outruns
+  // its window inside a period reads the missing dwords from memory, as it always did.
+  constexpr uint32_t kReload = 4;  // 1 / 2 / 3 / 4 / 5 on one box: 3.44 / 2.96 / 2.76 / 2.71 / 2.93 ms per GiB
+  auto load_window = [&](bool first) {
+    const uint32_t at = ab >> 5;
+    pending = active && (first || at - wbase >= kReload);
+    if (pending) {
+      pbase = at;
+      const uint32_t avail = last >= pbase ? last - pbase + 1u : 0u;              // dwords readable from there
+      pvalid = avail < kWinDwords ? (avail & ~3u) : kWinDwords;                   // whole 16-byte chunks
+      if (pvalid > 0) p0 = *reinterpret_cast<const Dwords4*>(seg32 + pbase);
+      if (pvalid > 4) p1 = *reinterpret_cast<const Dwords4*>(seg32 + pbase + 4);
+    }
   };
   auto window_to_lds = [&]() {
-    uint32_t* row = R.win[lane];
-    row[0] = p0.a; row[1] = p0.b; row[2] = p0.c; row[3] = p0.d;
-    row[4] = p1.a; row[5] = p1.b; row[6] = p1.c; row[7] = p1.d;
-    wbase = pbase;
-    wvalid = pvalid;
+    if (pending) {
+      uint32_t* row = R.win[lane];
+      row[0] = p0.a; row[1] = p0.b; row[2] = p0.c; row[3] = p0.d;
+      row[4] = p1.a; row[5] = p1.b; row[6] = p1.c; row[7] = p1.d;
+      wbase = pbase;
+      wvalid = pvalid;
+    }
   };
   // the 32 stream bits from bit position a on
   auto peek = [&](uint32_t a) -> uint32_t {
@@ -252,6 +264,8 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
 
   uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, made = 0;  // the period's tokens
   uint32_t nflushed = 0;
+  // (Measured and not kept, round 4: full periods kept back and stored 32 / 64 bytes at a time -- 2.60 against 2.80 ms per GiB
+  // in one pairing, 2.74 / 2.87 against 2.68 in the next: inside the box-to-box noise.)
   auto flush = [&]() {
     if (made == kPeriod) {
       *reinterpret_cast<Dwords4*>(tokens + nflushed) = Dwords4{t0, t1, t2, t3};
@@ -315,12 +329,12 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
   };
 
   // the first window: loaded and waited for on the spot
-  load_window();
+  load_window(true);
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
     // period start: last period's window (arrived meanwhile) into LDS, last period's tokens out, next window's loads
     window_to_lds();
     flush();
-    load_window();
+    load_window(false);
     uint32_t tk;
     if (active) { step(tk); t0 = tk; }
     if (active) { step(tk); t1 = tk; }
