@@ -195,6 +195,23 @@ auto main(int argc, char** argv) -> int {
         size_of[static_cast<int>(e)] = *ne;
       }
     }
+    {
+      // compress_options::chain_depth: any depth with a chain effort (4 lies between Max's tables and Best's 8), refused with a table effort
+      compress_options c4;
+      c4.effort = Effort::Best;
+      c4.chain_depth = 4;
+      const auto n4 = gpu.compress(html, comp, c4);
+      std::vector<std::byte> b4(html.size());
+      if (!n4 || decompress(std::span{comp}.first(*n4), b4) != DecompressStatus::Success || b4 != html || *n4 < size_of[SFH_EFFORT_BEST]) {
+        std::printf("chain_depth 4\n");
+        ++fail;
+      }
+      compress_options bad_depth;
+      bad_depth.effort = Effort::Thorough;
+      bad_depth.chain_depth = 4;
+      const auto nbd = gpu.compress(html, comp, bad_depth);
+      if (nbd || nbd.error() != CompressStatus::InvalidArgument) { std::printf("chain_depth with a table effort\n"); ++fail; }
+    }
     if (!(size_of[SFH_EFFORT_EXTREME] <= size_of[SFH_EFFORT_ULTRA] && size_of[SFH_EFFORT_ULTRA] <= size_of[SFH_EFFORT_BEST] && size_of[SFH_EFFORT_BEST] <= size_of[SFH_EFFORT_MAX] &&
           size_of[SFH_EFFORT_MAX] <= size_of[SFH_EFFORT_DEFAULT] && size_of[SFH_EFFORT_DEFAULT] <= size_of[SFH_EFFORT_FASTEST])) {
       std::printf("effort: sizes out of order\n");
