@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <memory>
 #include <new>
 #include <thread>
 #include <vector>
@@ -797,11 +798,15 @@ int sfh_gather_streams(sfh_ctx* ctx, void* nccl_comm, int root, const void* d_st
   if ((rc = R.AllGather(d_size, ctx->d_sizes, 1, kNcclUint64, nccl_comm, s)) != 0) return comm_fail(ctx, "ncclAllGather", rc);
   SF_HIP(hipMemcpyAsync(ctx->h_sizes, ctx->d_sizes, (size_t)nranks * sizeof(uint64_t), hipMemcpyDeviceToHost, s), "sizes read-back");
   SF_HIP(hipStreamSynchronize(s), "stream sync");
-  std::vector<uint64_t> off((size_t)nranks + 1);
+  // (no exception may cross the C boundary: the offsets live in a nothrow allocation)
+  struct Free { void operator()(uint64_t* p) const { free(p); } };
+  const std::unique_ptr<uint64_t, Free> off_mem((uint64_t*)malloc(((size_t)nranks + 1) * sizeof(uint64_t)));
+  if (!off_mem) return fail(ctx, SFH_E_NOMEM, "sfh_gather_streams: offsets", hipSuccess);
+  uint64_t* const off = off_mem.get();
   for (int r = 0; r < nranks; ++r) h_sizes[r] = ctx->h_sizes[r];
   // every rank judges the same numbers (base and cap are the root's, passed alike by all), so every rank returns the same
   // verdict BEFORE any transfer is posted: nobody is left waiting in a send whose receive was refused
-  rc = sfh_gather_offsets(h_sizes, nranks, base, cap, off.data());
+  rc = sfh_gather_offsets(h_sizes, nranks, base, cap, off);
   *out_end = off[(size_t)nranks];
   if (rc != SFH_OK) return fail(ctx, rc, "sfh_gather_streams: the gathered streams do not fit cap", hipSuccess);
   if (rank != root) {
