@@ -37,7 +37,8 @@ enum sfh_status {
   SFH_E_NO_DEVICE = -3,     /* no HIP device / device index out of range */
   SFH_E_HIP = -4,           /* a HIP runtime call failed; see sfh_last_error() */
   SFH_E_NOMEM = -5,         /* device scratch allocation failed */
-  SFH_E_COMM = -6           /* RCCL not loadable, or an RCCL call failed; see sfh_last_error() */
+  SFH_E_COMM = -6,          /* RCCL not loadable, or an RCCL call failed; see sfh_last_error() */
+  SFH_E_UNSUPPORTED = -7    /* the effort asked for rests on LDS behaviour this device does not show (sfh_lds_order_check) */
 };
 
 /* block strategy (inverse of src/decompress.cpp:416-458 dispatch) */
@@ -94,7 +95,7 @@ typedef struct sfh_options {
 } sfh_options;
 
 enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1, SFH_EFFORT_FASTEST = 2, SFH_EFFORT_THOROUGH = 3, SFH_EFFORT_MAX = 4,
-                  SFH_EFFORT_BEST = 5, SFH_EFFORT_ULTRA = 6, SFH_EFFORT_EXTREME = 7 };
+                  SFH_EFFORT_BEST = 5, SFH_EFFORT_ULTRA = 6, SFH_EFFORT_EXTREME = 7, SFH_EFFORT_RECENT = 8, SFH_EFFORT_RECENT_ALL = 9 };
 
 #define SFH_DEFAULT_BLOCK_BYTES 262144u
 /* block_bytes = 0 on inputs large enough to fill the device four times over with strips of that size (2048 / 1024 of them):
@@ -121,6 +122,17 @@ typedef struct sfh_device_props {
 } sfh_device_props;
 int sfh_get_device_props(int device, sfh_device_props* out);
 int sfh_create(sfh_ctx** out, int device);
+/* The chain efforts (SFH_EFFORT_BEST / _ULTRA / _EXTREME) and SFH_EFFORT_RECENT insert 64 positions into their hash buckets
+ * with ONE returning LDS atomic and rely on the LDS executing that wave-instruction's lanes in ascending order where they
+ * meet at one address (op 0: ds_wrxchg_rtn_b32, op 1: ds_mskor_rtn_b32) -- measured behaviour of gfx950, not an ISA
+ * promise.  This runs the check the library itself runs (cached per context) before the first call with such an effort:
+ * `blocks` workgroups x `iters` insertion steps x five collision densities in the match kernel's own access pattern
+ * (partial exec masks, sixteen back-to-back instructions by one wave on shared buckets, the other waves reading the
+ * table meanwhile), every position compared with the sequential model.  *mismatches == 0: the order holds.  A compress
+ * call with one of those efforts on a context whose check failed returns SFH_E_UNSUPPORTED and changes nothing
+ * (sfh_last_error says why); every other effort is unaffected.  SFH_FORCE_ORDER_FAIL=1 in the environment at
+ * sfh_create makes the library's own check report failure (tests of that branch). */
+int sfh_lds_order_check(sfh_ctx* ctx, uint32_t op, uint32_t blocks, uint32_t iters, uint64_t* mismatches, uint64_t* checked);
 void sfh_destroy(sfh_ctx* ctx);
 const char* sfh_last_error(const sfh_ctx* ctx);
 

@@ -427,15 +427,21 @@ static int matcher_init(matcher* m, const uint8_t* src, uint32_t n, const sfo_pa
   m->d = (uint8_t*)calloc((size_t)n + 16, 1);
   m->len16 = (uint16_t*)calloc((size_t)n + 1, 2);
   m->dist16 = (uint16_t*)calloc((size_t)n + 1, 2);
-  if (p->chain_depth) {
+  if (p->chain_depth || p->recent) {
     m->H = (uint32_t*)malloc((size_t)HS * 4);
     m->prev = (uint32_t*)malloc((size_t)(n + 1) * 4);
     if (m->H) for (uint32_t k = 0; k < HS; k++) m->H[k] = 0xFFFFFFFFu;
+    if (p->recent && !p->chain_depth) { /* hi half of the buckets; the buckets as read before a step */
+      m->T = (uint32_t*)malloc((size_t)HS * 4);
+      m->far = (uint32_t*)malloc((size_t)p->step * 2 * 4);
+      if (m->T) for (uint32_t k = 0; k < HS; k++) m->T[k] = 0xFFFFFFFFu;
+      if (!m->T || !m->far) return -1;
+    }
   } else {
     m->T = (uint32_t*)calloc((size_t)NT * D * HS, 4);
     m->far = (uint32_t*)malloc((size_t)p->step * NT * D * 4);
   }
-  if (!m->d || !m->len16 || !m->dist16 || (p->chain_depth ? (!m->H || !m->prev) : (!m->T || !m->far))) return -1;
+  if (!m->d || !m->len16 || !m->dist16 || ((p->chain_depth || p->recent) ? (!m->H || !m->prev) : (!m->T || !m->far))) return -1;
   if (n) memcpy(m->d, src, n);
   return 0;
 }
@@ -463,6 +469,22 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
       if (rend - i < maxlen) maxlen = rend - i;
       uint32_t cmplen = (p->cap && p->cap < maxlen) ? p->cap : maxlen;
       uint32_t best = 0, bc = 0, c = H[h];
+      if (p->x_long_levels & 64) { /* analysis: candidates ranked by TAGS (hashes of bytes 4..7, 8..11, 12..15), the best one verified */
+        const uint32_t TB = (p->x_long_levels >> 8) ? (p->x_long_levels >> 8) : 5;
+        uint32_t lvl_best = 0, have = 0;
+        uint32_t ti[3];
+        for (uint32_t q = 0; q < 3; q++) ti[q] = (load32(d + i + 4 + 4 * q) * 2654435761u) >> (32 - TB);
+        for (uint32_t k = 0; k < p->chain_depth && c != NONE && i - c <= (p->x_window ? p->x_window : SFO_WINDOW); k++, c = prev[c]) {
+          uint32_t lvl = 1;
+          for (uint32_t q = 0; q < 3; q++) {
+            if (((load32(d + c + 4 + 4 * q) * 2654435761u) >> (32 - TB)) != ti[q]) break;
+            lvl++;
+          }
+          if (!have || lvl > lvl_best) { lvl_best = lvl; bc = c; have = 1; }
+          if (lvl_best == 4) break;
+        }
+        if (have) best = match_len(d, i, bc, cmplen);
+      } else
       for (uint32_t k = 0; k < p->chain_depth && c != NONE && i - c <= (p->x_window ? p->x_window : SFO_WINDOW); k++, c = prev[c]) {
         uint32_t l = match_len(d, i, c, cmplen);
         if (l > best) { best = l; bc = c; }
@@ -472,6 +494,81 @@ static void match_steps(matcher* m, uint32_t s0, uint32_t s1) {
       if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)(i - bc); }
       prev[i] = H[h];
       H[h] = i;
+    }
+    return;
+  }
+
+  if (p->recent) {
+    /* EXACT RECENCY step tables.  lo[h]: the latest position with hash h; hi[h]: what lo[h] held before the most recent
+     * step that inserted h (every inserting position of a step writes the same value); prev[i]: what lo named just
+     * before i went in, i.e. the nearest earlier position with i's hash.  A position's candidates:
+     *   the link chain  c1 = prev[i], c2 = prev[c1], ... : at most near_depth of them; a link is only followed FROM a
+     *                   position of the current step or the link_steps - 1 steps before it (the links kept);
+     *   lo and hi as they stood before the step (lo == c1 for the step's first position with the hash).
+     * Ranking, winner, far4 and the odd positions' inheritance are the step tables'. */
+    uint32_t *lo = m->H, *hi = m->T, *prev = m->prev, *far = m->far;
+    const uint32_t ND = p->near_depth ? p->near_depth : 1, LS = p->link_steps ? p->link_steps : 1;
+    const uint32_t WIN = p->x_window ? p->x_window : SFO_WINDOW;
+    for (uint32_t s = s0; s < s1; s++) {
+      uint32_t b = s * W;
+      if (b >= n) break;
+      uint32_t e = b + W < n ? b + W : n;
+      for (uint32_t i = b; i < e; i++) {
+        far[2 * (i - b)] = far[2 * (i - b) + 1] = NONE;
+        if (i + MM > n) continue;
+        uint32_t h = hash_of(load32(d + i), p);
+        far[2 * (i - b)] = lo[h];
+        far[2 * (i - b) + 1] = hi[h];
+      }
+      for (uint32_t i = b; i < e; i++) {
+        if (i + MM > n) continue;
+        uint32_t h = hash_of(load32(d + i), p);
+        prev[i] = lo[h];
+        lo[h] = i;
+        hi[h] = far[2 * (i - b)];
+      }
+      const uint32_t ring_lo = s + 1 >= LS ? (s + 1 - LS) * W : 0;
+      for (uint32_t i = b; i < e; i++) {
+        if (p->stride2 && (i & 1)) continue;
+        if (i + MM > n) continue;
+        uint32_t rend = (i / R + 1) * R;
+        uint32_t maxlen = n - i < 258 ? n - i : 258;
+        if (rend - i < maxlen) maxlen = rend - i;
+        uint32_t cmplen = (p->cap && p->cap < maxlen) ? p->cap : maxlen;
+        uint32_t cand[40], nc = 0;
+        for (uint32_t k = 0, c = prev[i]; k < ND && k < 32 && c != NONE; k++) {
+          cand[nc++] = c;
+          if (c < ring_lo) break;
+          c = prev[c];
+        }
+        if (far[2 * (i - b)] != NONE) cand[nc++] = far[2 * (i - b)];
+        if (far[2 * (i - b) + 1] != NONE && !(p->x_long_levels & 16)) cand[nc++] = far[2 * (i - b) + 1]; /* analysis: 16 = no hi level */
+        uint32_t best = 0, bdist = 0;
+        for (uint32_t k = 0; k < nc; k++) {
+          uint32_t dist = i - cand[k];
+          if (dist > WIN) continue;
+          uint32_t l = match_len(d, i, cand[k], cmplen);
+          if (p->rank_bytes && l > p->rank_bytes) l = p->rank_bytes;
+          if (l > best || (l == best && l && dist < bdist)) { best = l; bdist = dist; }
+        }
+        if (p->rank_bytes && best == p->rank_bytes) best = match_len(d, i, i - bdist, cmplen);
+        if (p->far4_dist && best == 4 && bdist > p->far4_dist) best = 0;
+        if (best >= MM) { len16[i] = (uint16_t)best; dist16[i] = (uint16_t)bdist; }
+      }
+      if (p->stride2) {
+        for (uint32_t i = b; i < e; i++) {
+          if (!(i & 1) || i + 1 >= n || (i + 1) % R == 0) continue;
+          if (i + 1 >= e) continue;
+          uint32_t l = len16[i + 1], dd = dist16[i + 1];
+          if (l && dd <= i && d[i] == d[i - dd]) {
+            uint32_t nl = l + 1;
+            if (p->cap && nl > p->cap) nl = p->cap;
+            if (nl > 258) nl = 258;
+            len16[i] = (uint16_t)nl;
+            dist16[i] = (uint16_t)dd;
+          }
+        }
+      }
     }
     return;
   }

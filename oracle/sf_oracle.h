@@ -118,6 +118,16 @@ typedef struct sfo_params {
   uint32_t run_dist1;    /* 1: a taken match of SFO_RUN_MIN bytes or more (with room to be longer) is coded at distance 1
                             when the bytes it covers all equal the byte before it (a run): its length is then the
                             run's (region end and 258 as usual), if that is not shorter than the extended match */
+  uint32_t recent;       /* 1: EXACT RECENCY step tables (round 5; SFH_EFFORT_RECENT on the GPU).  A bucket holds
+                            {lo: the LATEST position with the hash, hi: what lo held before the most recent step that
+                            inserted the hash}; positions go in one by one in ascending order, and every position keeps
+                            a LINK to the position lo named just before it went in (its exact predecessor).  Candidates
+                            of a searched position, see match_steps(): the `near_depth` nearest earlier positions with
+                            its hash as far as the links reach (the position's own step and the `link_steps` - 1 steps
+                            before it), then lo and hi as read before the step.  depth / use_near do not apply;
+                            stride2, rank_bytes, cap, far4_dist do */
+  uint32_t near_depth;   /* recent: candidates taken from the link chain (>= 1) */
+  uint32_t link_steps;   /* recent: steps (the current one included) whose positions have links (>= 1) */
 } sfo_params;
 
 #define SFO_WINDOW 32768u

@@ -28,7 +28,7 @@ EXPORTS = [
     "sfh_last_block_bytes", "sfh_index_entries", "sfh_copy_index", "sfh_copy_subindex", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms",
     "sfh_inflate_stage_name", "sfh_checksum_device", "sfh_crc32_combine", "sfh_adler32_combine",
     "sfh_set_profiling", "sfh_last_stage_ms", "sfh_stage_name", "sfh_debug_read",
-    "sfh_gather_offsets", "sfh_gather_streams", "sfh_comm_ranks",
+    "sfh_gather_offsets", "sfh_gather_streams", "sfh_comm_ranks", "sfh_lds_order_check",
 ]
 
 
@@ -125,6 +125,8 @@ def lib():
     L.sfh_stage_name.restype = C.c_char_p
     L.sfh_debug_read.argtypes = [vp, C.c_int, vp, sz]
     L.sfh_debug_read.restype = C.c_int
+    L.sfh_lds_order_check.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sfh_lds_order_check.restype = C.c_int
     _LIB = L
     return L
 
@@ -137,7 +139,7 @@ def device_props(device=0):
     return {k: (getattr(p, k).decode() if isinstance(getattr(p, k), bytes) else getattr(p, k)) for k, _ in p._fields_ if k != "reserved"}
 
 
-EFFORT = {"default": 0, "fast": 1, "fastest": 2, "thorough": 3, "max": 4, "best": 5, "ultra": 6, "extreme": 7}
+EFFORT = {"default": 0, "fast": 1, "fastest": 2, "thorough": 3, "max": 4, "best": 5, "ultra": 6, "extreme": 7, "recent": 8, "recent_all": 9}
 
 
 def make_options(strategy="auto", final_stream=True, lazy=True, stored_fast_path=True, container="raw", block_bytes=0,
@@ -162,7 +164,11 @@ def resolve_block_bytes(block_bytes, n, effort="default"):
     the chain efforts."""
     if block_bytes:
         return int(block_bytes)
-    chain = isinstance(effort, str) and (effort.startswith("chain") or EFFORT.get(effort, 0) >= EFFORT["best"])
+    if isinstance(effort, str):  # a name, "chainN", or (as make_options accepts) the enum's integer
+        e = EFFORT["best"] if effort.startswith("chain") else EFFORT[effort]
+    else:
+        e = int(effort)
+    chain = EFFORT["best"] <= e <= EFFORT["extreme"]
     b = CHAIN_BLOCK_BYTES if chain else LARGE_BLOCK_BYTES
     while b > DEFAULT_BLOCK_BYTES and n // b < (1024 if chain else 2048):
         b >>= 1

@@ -6,7 +6,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 # SFH_LIB=<path>: another build of the library (kernel experiments side by side: tools/exp/variants.sh)
 LIB_PATH = os.environ.get("SFH_LIB") or os.path.join(PKG_DIR, "libstarflate_hip.so")
-SOURCES = ["sf_kernels.hip", "sf_checksum.hip", "sf_inflate.hip", "sf_capi.hip"]
+SOURCES = ["sf_kernels.hip", "sf_checksum.hip", "sf_inflate.hip", "sf_guard.hip", "sf_capi.hip"]
 HEADERS = [os.path.join(CSRC, "sf_device.h"), os.path.join(CSRC, "sf_inflate_core.h"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "starflate_hip.h")]
 

@@ -207,6 +207,15 @@ class Compressor:
             raise ValueError(f"tensor is on cuda:{t.device.index}, compressor on cuda:{self.device}")
 
     # ---- measurement / inspection ----
+    def lds_order_check(self, op, blocks=256, iters=50):
+        """sfh_lds_order_check: does the LDS execute a returning atomic's lanes in ascending order on this device (op 0:
+        ds_wrxchg_rtn_b32, the chain efforts; op 1: ds_mskor_rtn_b32, effort "recent")? -> (mismatches, positions checked)"""
+        bad, n = C.c_uint64(0), C.c_uint64(0)
+        rc = self._lib.sfh_lds_order_check(self._h, int(op), int(blocks), int(iters), C.byref(bad), C.byref(n))
+        if rc:
+            raise StarflateError(rc, self._lib.sfh_last_error(self._h).decode())
+        return bad.value, n.value
+
     def set_profiling(self, on=True):
         self._lib.sfh_set_profiling(self._h, int(bool(on)))
 

@@ -55,6 +55,8 @@ struct sfh_ctx {
   uint64_t* d_sizes = nullptr;   // sfh_gather_streams: the ranks' sizes on the device and in pinned memory
   uint64_t* h_sizes = nullptr;
   int sizes_cap = 0;
+  int order_ok[2] = {0, 0};      // sfh_lds_order_check per op (0 exchange: chains, 1 masked-or: recent): 0 not run, 1 holds, -1 does not
+  int force_order_fail = 0;      // SFH_FORCE_ORDER_FAIL=1: the library's own check reports failure (tests)
   char err[256] = {0};
 };
 
@@ -158,7 +160,7 @@ uint32_t chunks_of(size_t n) { return n ? (uint32_t)((n + sf::kChunk - 1) / sf::
 // effort alone, so the stream is too (the encoder specification states the same rule)
 uint32_t resolve_block_bytes(uint32_t block_bytes, size_t n, uint32_t effort = SFH_EFFORT_DEFAULT) {
   if (block_bytes) return block_bytes;
-  const bool chain = effort >= SFH_EFFORT_BEST;
+  const bool chain = effort >= SFH_EFFORT_BEST && effort <= SFH_EFFORT_EXTREME;
   uint32_t b = chain ? SFH_CHAIN_BLOCK_BYTES : SFH_LARGE_BLOCK_BYTES;
   while (b > SFH_DEFAULT_BLOCK_BYTES && n / b < (chain ? 1024u : 2048u)) b >>= 1;
   while (b > sf::kChunk && n / b < 256) b >>= 1;
@@ -183,8 +185,37 @@ int check_opt(const sfh_options* o) {
   if (o->strategy > SFH_DYNAMIC || o->final_stream > 1 || o->lazy > 3 || o->no_stored_fast_path > 1) return -1;
   if (o->container > SFH_GZIP || (o->container && !o->final_stream)) return -1;  // a non-final shard has no trailer
   if (o->block_bytes % sf::kChunk || o->block_bytes > sf::kMaxStrip) return -1;
-  if (o->effort > SFH_EFFORT_EXTREME || o->chain_depth > 255 || (o->chain_depth && o->effort < SFH_EFFORT_BEST)) return -1;
+  if (o->effort > SFH_EFFORT_RECENT_ALL || o->chain_depth > 255) return -1;
+  if (o->chain_depth && (o->effort < SFH_EFFORT_BEST || o->effort > SFH_EFFORT_EXTREME)) return -1;
   return 0;
+}
+
+// The returning LDS atomic of the exact-recency match finders (op 0: chains, op 1: recent) executes a wave's lanes in
+// ascending order on this device?  Checked once per context, on the context's own stream, before the first call that
+// needs it (64 workgroups x 4 steps x 5 densities: 1.2 M positions, well under a millisecond of kernels).
+int check_order(sfh_ctx* ctx, int op, uint64_t* bad, uint64_t* checked, uint32_t blocks, uint32_t iters) {
+  SF_HIP(sf::run_lds_order_check(op, blocks, iters, ctx->d_value, ctx->stream), "lds order check");
+  uint32_t r[2] = {0, 0};
+  SF_HIP(hipMemcpyAsync(r, ctx->d_value, sizeof r, hipMemcpyDeviceToHost, ctx->stream), "lds order check result");
+  SF_HIP(hipStreamSynchronize(ctx->stream), "lds order check sync");
+  *bad = r[0];
+  *checked = r[1];
+  return SFH_OK;
+}
+int ensure_order(sfh_ctx* ctx, int op) {
+  if (ctx->order_ok[op] == 0) {
+    uint64_t bad = 0, checked = 0;
+    const int rc = check_order(ctx, op, &bad, &checked, 64, 4);
+    if (rc) return rc;
+    ctx->order_ok[op] = (bad == 0 && checked != 0 && !ctx->force_order_fail) ? 1 : -1;
+  }
+  if (ctx->order_ok[op] < 0) {
+    snprintf(ctx->err, sizeof ctx->err, "%s does not execute a wave's lanes in ascending order on this device%s: the %s need it",
+             op ? "ds_mskor_rtn_b32" : "ds_wrxchg_rtn_b32", ctx->force_order_fail ? " (SFH_FORCE_ORDER_FAIL=1)" : "",
+             op ? "effort SFH_EFFORT_RECENT" : "chain efforts (SFH_EFFORT_BEST / _ULTRA / _EXTREME)");
+    return SFH_E_UNSUPPORTED;
+  }
+  return SFH_OK;
 }
 
 // Host buffers of sfh_compress: with them the batch loop also moves the data -- batch b's input goes up on one copy
@@ -213,13 +244,19 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   if (!rc && o.container) rc = ensure_sums(ctx, nchunks);
   if (rc) return rc;
   ctx->last_chunks = nchunks;
+  // effort -> what the match kernel does: {both levels, near candidate, even positions only, second table, chain depth, exact recency}
+  const uint32_t ef = o.effort;
+  const bool ef_chain = ef >= SFH_EFFORT_BEST && ef <= SFH_EFFORT_EXTREME, ef_recent = ef == SFH_EFFORT_RECENT || ef == SFH_EFFORT_RECENT_ALL;
+  const bool ef_all = ef == SFH_EFFORT_THOROUGH || ef == SFH_EFFORT_MAX || ef_chain || ef == SFH_EFFORT_RECENT_ALL;  // every position searched
   const sf::Options ko{o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path ? 0u : 1u,
                        resolve_block_bytes(o.block_bytes, n, o.effort),
-                       (o.effort == SFH_EFFORT_DEFAULT || o.effort >= SFH_EFFORT_THOROUGH) ? 1u : 0u,
-                       o.effort == SFH_EFFORT_FASTEST ? 0u : 1u, o.effort >= SFH_EFFORT_THOROUGH ? 0u : 1u,
-                       o.effort == SFH_EFFORT_MAX ? 1u : 0u,
-                       o.effort < SFH_EFFORT_BEST ? 0u : o.chain_depth ? o.chain_depth
-                       : o.effort == SFH_EFFORT_BEST ? 8u : o.effort == SFH_EFFORT_ULTRA ? 16u : 32u};
+                       (ef == SFH_EFFORT_FAST || ef == SFH_EFFORT_FASTEST) ? 0u : 1u,
+                       ef == SFH_EFFORT_FASTEST ? 0u : 1u, ef_all ? 0u : 1u,
+                       ef == SFH_EFFORT_MAX ? 1u : 0u,
+                       !ef_chain ? 0u : o.chain_depth ? o.chain_depth
+                       : ef == SFH_EFFORT_BEST ? 8u : ef == SFH_EFFORT_ULTRA ? 16u : 32u,
+                       ef_recent ? 1u : 0u};
+  if ((ko.chain_depth || ko.recent) && (rc = ensure_order(ctx, ko.recent ? 1 : 0)) != SFH_OK) return rc;
   ctx->last_block_bytes = ko.strip_bytes;
   const bool prof = ctx->profiling != 0;
   if ((rc = order_behind_last_call(ctx, s)) != SFH_OK) return rc;
@@ -402,6 +439,8 @@ int sfh_create(sfh_ctx** out, int device) {
     ctx->k1_stamps = (e && e[0] == '1');
     const char* b = getenv("SFH_BATCH_CHUNKS");
     if (b && atoi(b) > 0) ctx->batch_chunks = std::min<uint32_t>((uint32_t)atoi(b), sf::kBatchChunks);
+    const char* f = getenv("SFH_FORCE_ORDER_FAIL");
+    ctx->force_order_fail = (f && f[0] == '1');
   }
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
@@ -456,6 +495,14 @@ void sfh_destroy(sfh_ctx* ctx) {
 }
 
 const char* sfh_last_error(const sfh_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
+
+int sfh_lds_order_check(sfh_ctx* ctx, uint32_t op, uint32_t blocks, uint32_t iters, uint64_t* mismatches, uint64_t* checked) {
+  if (!ctx || op > 1 || !blocks || blocks > 65535 || !iters || iters > 4096 || !mismatches || !checked)
+    return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
+  SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+  return check_order(ctx, (int)op, mismatches, checked, blocks, iters);
+}
+
 
 size_t sfh_compress_bound(size_t n, uint32_t block_bytes) {
   // per 32 KiB DEFLATE block: fixed-Huffman worst case (9 bits per literal) + headers + alignment block.  A strip is a

@@ -108,6 +108,7 @@ struct Options {
   uint32_t stride2;      // 1: only even positions are searched, odd ones take over their successor's match (0: thorough)
   uint32_t long_table;   // 1: two tables of 4096 buckets, keyed by four and by seven bytes (with stride2 = 0: SFH_EFFORT_MAX)
   uint32_t chain_depth;  // > 0: exact hash chains of this depth instead of the step tables (SFH_EFFORT_BEST 8, _ULTRA 16, _EXTREME 32)
+  uint32_t recent;       // 1: exact recency (SFH_EFFORT_RECENT): buckets {latest, the one before the latest inserting step} + the exact predecessor
 };
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,
@@ -139,6 +140,10 @@ hipError_t launch_inflate_tokens_sub(const uint8_t* src, uint64_t src_n, const u
 hipError_t launch_inflate_bytes(const uint8_t* src, uint64_t src_n, uint32_t nseg, const uint32_t* tokens, SegInfo* info,
                                 uint8_t* dst, uint32_t sps, hipStream_t s);
 hipError_t launch_inflate_status(const SegInfo* info, uint32_t nseg, uint32_t* d_result, hipStream_t s);
+
+// sf_guard.hip: does the LDS execute a returning atomic's lanes in ascending order (op 0: ds_wrxchg_rtn_b32, 1: ds_mskor_rtn_b32)?
+// d_result[0] = mismatches against the sequential model, [1] = positions checked
+hipError_t run_lds_order_check(int op, uint32_t blocks, uint32_t iters, uint32_t* d_result, hipStream_t s);
 
 uint32_t crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);        // host arithmetic
 uint32_t adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b);  // host arithmetic

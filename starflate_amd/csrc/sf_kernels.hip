@@ -128,6 +128,16 @@ constexpr uint32_t L_WTOT = L_HIST + 4 * kHistStride;        // u32[16] tokens |
 constexpr uint32_t L_DSYM = L_WTOT + 4 * K1_WAVES;            // u8[512] distance - 1 -> symbol: [d] below 256, [256 + (d >> 7)] from there on
 constexpr uint32_t K1_LDS = L_DSYM + 512;
 static_assert(2 * K1_LDS <= 160 * 1024, "K1: two workgroups per CU");
+// RECENT (SFH_EFFORT_RECENT): exact recency.  A bucket is {hi, lo}: lo the LATEST position with the hash, hi what lo held
+// before the most recent step that inserted the hash; positions go in by ordered exchanges (one wave, slice after slice,
+// as with the chains), and what an exchange returns -- the position's exact predecessor -- is its near candidate.  The
+// hashes the threads POST for that wave (u16 per position) lie where the histogram is: nothing touches the histogram
+// during the match phase, its counts wait in registers meanwhile.  The ANSWERS (u16 per searched position) follow the
+// distance-symbol table.  Same two workgroups per CU.
+constexpr uint32_t R_L_POST = L_HIST;                        // u16[kStep]
+constexpr uint32_t R_L_ANS = L_DSYM + 512;                   // u16[kStep / 2]
+constexpr uint32_t R_K1_LDS = R_L_ANS + kStep;
+static_assert(2 * kStep <= 4 * kHistStride && 2 * R_K1_LDS <= 160 * 1024 && R_L_ANS % 4 == 0, "K1 (recent): two workgroups per CU");
 // CHAIN (SFH_EFFORT_BEST / _ULTRA / _EXTREME): exact hash chains.  One workgroup per CU: behind the 4-bit lengths come the
 // chain HEADS (one dword per hash holding a 16-bit step code: the LATEST position with it; a dword because they are
 // updated by ds_wrxchg_rtn_b32, see the match phase), the LINKS (u16 per position, a ring indexed by strip position mod
@@ -235,13 +245,15 @@ __device__ __forceinline__ uint32_t entry_rel(uint32_t v) {
 // CHAIN (SFH_EFFORT_BEST / _ULTRA): exact hash chains instead of the step tables -- every position is inserted and
 // searched, most recent candidate first, `chain_depth` of them at most (the specification's chain_depth; zlib's
 // structure).  One workgroup per CU (the links take 80 KiB of LDS), 128 vector registers.
-template <bool STAMPS, bool DEPTH2, bool NEAR, bool STRIDE2, bool LONG, bool CHAIN = false>
+// RECENT (SFH_EFFORT_RECENT): the step tables with EXACT RECENCY -- see R_L_POST above and the match phase.
+template <bool STAMPS, bool DEPTH2, bool NEAR, bool STRIDE2, bool LONG, bool CHAIN = false, bool RECENT = false>
 __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREADS / 256) void k_lz77(
     const uint8_t* __restrict__ src, uint64_t n_total, uint32_t strip_bytes, uint16_t* __restrict__ items,
     uint32_t* __restrict__ nitems_out, uint32_t* __restrict__ ntok_out, uint32_t* __restrict__ hist_out,
     uint32_t* __restrict__ rtok_out, uint32_t lazy, uint32_t fast_skip, uint64_t* __restrict__ stamps,
     uint32_t chain_depth) {
   static_assert(!CHAIN || (!STRIDE2 && !LONG && DEPTH2 && NEAR), "chains: every position searched, no step tables");
+  static_assert(!RECENT || (!LONG && !CHAIN && DEPTH2 && NEAR), "recent: the step tables' search patterns (stride 2 or every position)");
   constexpr uint32_t LH = CHAIN ? C_L_HIST : L_HIST, LW = CHAIN ? C_L_WTOT : L_WTOT, LD = CHAIN ? C_L_DSYM : L_DSYM;
   uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t st_t = 0;
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
   static_assert(((kEpMax + 1) << SH) <= 65536 && kRound % STEP == 0, "step codes");
 
   // static LDS (its address is a compile-time constant: no base register, no add per access)
-  __shared__ __attribute__((aligned(16))) uint8_t smem[CHAIN ? C_K1_LDS : K1_LDS];
+  __shared__ __attribute__((aligned(16))) uint8_t smem[CHAIN ? C_K1_LDS : RECENT ? R_K1_LDS : K1_LDS];
   uint32_t* s_data = reinterpret_cast<uint32_t*>(smem + L_DATA);
   uint8_t* s_bytes = smem + L_DATA;
   uint32_t* s_len4 = reinterpret_cast<uint32_t*>(smem + L_LEN4);
@@ -326,6 +338,8 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
     if (rc == 0) { tot_tok = 0; tot_items = 0; skip = false; }
     if (rc == kSkipSpan / kRound) skip = fast_skip && (n - cstart) > kSkipSpan && tot_tok >= kSkipSpan - kSkipSlack;
 
+    // RECENT: the histogram's place holds the match phase's posts; its counts wait here meanwhile
+    [[maybe_unused]] uint32_t hsave = 0;
     // ---- stage: shift the window down by one round, append the prefetched 4 KiB ----
     {
       uint4* s4 = reinterpret_cast<uint4*>(smem + L_DATA);
@@ -339,7 +353,8 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       s4[K1_THREADS + t] = c1;
       if (t < kUnits - 2 * K1_THREADS) s4[2 * K1_THREADS + t] = c2;
       *reinterpret_cast<uint2*>(&s_data[(kWindow + kLook) / 4 + 2 * t]) = make_uint2(pre_lo, pre_hi);
-      if (r + 1 < nrounds) {
+      // (RECENT asks for them behind the match phase, whose serial pass wants the registers: parse and emit hide the latency)
+      if (!RECENT && r + 1 < nrounds) {
         pre_lo = load4(rb + kRound + kLook + 8 * t);
         pre_hi = load4(rb + kRound + kLook + 8 * t + 4);
       }
@@ -359,6 +374,8 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         }
         ebase += kEpS;
       }
+      // (the barrier at the top of the stage follows the previous round's last histogram update)
+      if constexpr (RECENT) hsave = t < kHistStride ? s_hist[t] : 0u;
       __syncthreads();
     }
     stamp(0);
@@ -366,6 +383,10 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
     if (skip) {
       // the chunk's first kSkipSpan positions were (almost) all literals: no search, no insertion,
       // every position is a literal
+      if (RECENT && r + 1 < nrounds) {  // (the other kernels asked for the next round's bytes in the stage)
+        pre_lo = load4(rb + kRound + kLook + 8 * t);
+        pre_hi = load4(rb + kRound + kLook + 8 * t + 4);
+      }
       for (uint32_t rel = t; rel < qn; rel += K1_THREADS) {
         const uint32_t b = s_bytes[kWindow + rel];
         gi[tot_items + rel] = (uint16_t)((rel & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((rc * kRSubs + rel / kSubBytes) << 8)) : b);
@@ -519,6 +540,177 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             if (it + 1 < nsteps) stage_a(it + 1);              // (the posts of this step were read before the barrier above)
           }
           lds_barrier();  // the step's links and the next step's posts are in place
+        }
+      } else if constexpr (RECENT) {
+        // ---- exact recency (the specification's `recent`, near_depth 1, link_steps 1) ----
+        // The step tables' search pattern -- the even positions of a step of 1024 searched and every position inserted
+        // (STRIDE2), or every one of a step's 512 positions searched; a search split over two intervals and the two halves
+        // of the workgroup -- with other candidates.  A bucket is {hi, lo}: lo the LATEST position with the hash, hi what
+        // lo held before the most recent step that inserted the hash.  A position's candidates are lo and hi as they
+        // stand BEFORE its step and its exact PREDECESSOR, the nearest earlier position with its hash, in the step or
+        // before it.  Insertion is `old = {hi, lo} <- {hi, own code}` in ascending position order: ds_mskor_rtn_b32 with
+        // mask 0xFFFF replaces the low half alone and returns the bucket as it was, and the LDS executes the lanes of
+        // such a wave-instruction in ascending order where they meet at one bucket (like the chains' exchange;
+        // sf_guard.hip checks it on the device at hand), so old.lo IS the predecessor.  ONE wave issues the step's slices
+        // in order, back to back.  What it needs, the hashes, the searching half POSTS before barrier 1; what comes
+        // back is the ANSWER a searched position reads an interval later.  Between the barriers the posting half stores
+        // the buckets' new hi (the lo it read before the step: every position with the hash stores the same) and ranks
+        // its far candidates, and one wave of the other half does the pass -- the pass is not alone on the critical path.
+        // Step codes ASCEND with the position here: ((step - epoch) + 1) << SH | index in the step.
+        constexpr uint32_t NSL = STEP / 64;               // slices of a step
+        static_assert((NSL == 16 || NSL == 8) && kHashBits <= 16 && 2 * STEP <= 4 * kHistStride && 2 * 512 <= kStep,
+                      "one posted u16 per position, one answer per search");
+        uint16_t* const s_post = reinterpret_cast<uint16_t*>(smem + R_L_POST);  // [STEP] hash of every position of the step
+        uint16_t* const s_ans = reinterpret_cast<uint16_t*>(smem + R_L_ANS);    // [512] the bucket's lo before a searched position went in
+        const uint32_t grp = wave >> 3;                   // (uniform) this wave's half
+        const uint32_t tp = t & 511u;                     // index in the half
+        const uint32_t ps = STRIDE2 ? 2 * tp : tp;        // the thread's searched position within a step
+        const uint32_t to_rend = kRegion - (ps & (kRegion - 1));
+        [[maybe_unused]] const bool inh_here = tp != 0 && (tp & (kRegion / 2 - 1)) != 0;
+        [[maybe_unused]] const uint32_t first_ad = kWindow - rb;
+        const uint32_t sh0 = ps & 3u;
+        const uint32_t pswK = kWindow + (ps & ~3u);
+        const uint32_t psK1 = kWindow - 1u + ps;
+        const uint32_t mlen0 = to_rend < kCap ? to_rend : kCap;
+        auto lds32 = [&](uint32_t at, uint32_t off) { return *reinterpret_cast<const uint32_t*>(smem + at + off); };
+        uint8_t* const gst = reinterpret_cast<uint8_t*>(gi) + stage_off;
+        const uint32_t KK = K - STEP;                     // LDS byte address of a coded position = code + KK (mod 2^32)
+        uint32_t f_a0 = 0, f_a1 = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;
+        for (uint32_t it = 0; it <= nsteps; ++it) {
+          const uint32_t code_it = (rb / STEP + it - ebase + 1) << SH;  // (uniform) step code of step `it`
+          const bool first_half = (it & 1) == grp;        // (uniform) this half searches step `it`; the other finishes step it - 1
+          uint32_t farv = 0, f_h = 0;
+          [[maybe_unused]] uint32_t farv2 = 0;
+          if (first_half) {
+            if (it < nsteps) {
+              // ---- first part (a): bytes, the hashes posted, the buckets as they stand before the step ----
+              const uint32_t wb = it * STEP + pswK;
+              const uint32_t d0 = lds32(wb, 0), d1 = lds32(wb, 4), d2 = lds32(wb, 8);
+              f_a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0);
+              f_a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
+              const uint32_t h = (f_a0 * 2654435761u) >> (32 - kHashBits);
+              farv = s_table[h];
+              if constexpr (STRIDE2) {
+                // the odd position behind this one is only inserted: its four bytes are in the registers already
+                const uint32_t h2 = (__builtin_amdgcn_alignbyte(f_a1, f_a0, 1) * 2654435761u) >> (32 - kHashBits);
+                farv2 = s_table[h2];
+                f_h = h | (h2 << 16);
+                *reinterpret_cast<uint32_t*>(smem + R_L_POST + 4u * tp) = f_h;  // positions ps and ps + 1
+              } else {
+                f_h = h;
+                s_post[tp] = (uint16_t)h;
+              }
+            }
+          } else if (it >= 1) {
+            // ---- second part of the search at position ps of step it - 1 ----
+            const uint32_t sb = (it - 1) * STEP;
+            const uint32_t ad1 = sb + psK1;
+            const uint32_t wb = sb + pswK;
+            const uint32_t a0 = f_a0, a1 = f_a1, maxlen = f_maxlen;
+            uint32_t neare = s_ans[tp];
+            uint32_t pbyte = STRIDE2 ? smem[ad1] : 0u;
+            uint32_t d2 = lds32(wb, 8), d3 = lds32(wb, 12), d4 = lds32(wb, 16);
+            asm volatile("" : "+v"(neare), "+v"(pbyte), "+v"(d2), "+v"(d3), "+v"(d4));  // one round trip for all
+            // the exact predecessor: an earlier position by construction; inside the window?
+            const int32_t thr = (int32_t)((sb + ps) - KK);
+            const uint32_t nc = neare + KK;
+            const bool okn = (int32_t)neare >= thr;
+            const uint32_t ln = rank8(s_data, a0, a1, nc, maxlen);
+            // longest wins; ties go to the smaller distance: the predecessor, then lo, then hi
+            uint32_t best = okn ? ln : 0u, bq = nc;
+            if (f_m0 > best) { best = f_m0; bq = f_q0; }
+            if (f_m1 > best) { best = f_m1; bq = f_q1; }
+            const uint32_t bd1 = ad1 - bq;
+            const uint32_t cbyte = STRIDE2 ? s_bytes[(bq - 1) & 0xFFFFu] : 0u;
+            if (best == kRank) {
+              const uint32_t a2 = __builtin_amdgcn_alignbyte(d3, d2, sh0), a3 = __builtin_amdgcn_alignbyte(d4, d3, sh0);
+              const uint32_t lx = kRank + cmp8<kRank / 4>(s_data, a2, a3, bq);
+              best = lx < maxlen ? lx : maxlen;
+            }
+            const bool ok = best >= (bd1 >= kFar4 ? kMinMatch + 1 : kMinMatch);
+            const uint32_t len4 = ok ? best - 3 : 0u;
+            if constexpr (STRIDE2) {
+              const bool inh = ok && inh_here && pbyte == cbyte && bq != first_ad;
+              const uint32_t len4o = inh ? (best < kCap ? best - 2 : kCap - 3) : 0u;
+              *reinterpret_cast<uint16_t*>(gst + (ad1 - (kWindow - 1u))) = (uint16_t)bd1;
+              smem[L_LEN4 + ((sb >> 1) + tp)] = (uint8_t)(len4o | (len4 << 4));
+            } else {
+              *reinterpret_cast<uint16_t*>(gst + 2u * (ad1 - (kWindow - 1u))) = (uint16_t)bd1;
+              uint32_t v = len4;
+              v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, true) << 4;
+              asm volatile("s_mov_b64 exec, %2\n\tds_write_b8 %0, %1 offset:%3\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
+                           :: "v"((sb + tp) >> 1), "v"(v), "s"(0x5555555555555555ull), "n"(L_LEN4) : "memory");
+            }
+          }
+          if (it == nsteps) break;
+          lds_barrier();  // the posts are in place, every read of the table as it stands before step `it` is done
+          if (first_half) {
+            // ---- first part (b): the buckets' new hi; the far candidates lo and hi, ranked ----
+            *reinterpret_cast<uint16_t*>(smem + L_TABLE + 2u + 4u * (f_h & 0xFFFFu)) = (uint16_t)farv;
+            if constexpr (STRIDE2) *reinterpret_cast<uint16_t*>(smem + L_TABLE + 2u + 4u * (f_h >> 16)) = (uint16_t)farv2;
+            const uint32_t sb = it * STEP;
+            const uint32_t m0 = farv & 0xFFFFu, m1 = farv >> 16;
+            const uint32_t c0 = m0 + KK, c1 = m1 + KK;
+            // ad - c <= kWindow  <=>  code >= thr, as signed numbers (thr > STEP: an empty half, or what ageing left of
+            // an entry, lies below it)
+            const int32_t thr = (int32_t)((sb + ps) - KK);
+            const bool ok0 = (int32_t)m0 >= thr, ok1 = (int32_t)m1 >= thr;
+            const uint32_t maxlen = (uint32_t)max(min((int)((qn - sb) - ps), (int)mlen0), 0);
+            uint32_t l0, l1;
+            rank8x2(s_data, f_a0, f_a1, c0, c1, maxlen, l0, l1);
+            f_maxlen = maxlen;
+            f_q0 = c0; f_q1 = c1;
+            f_m0 = ok0 ? l0 : 0u;
+            f_m1 = ok1 ? l1 : 0u;
+          } else if ((wave & 7u) == 0) {
+            // ---- the step goes into the buckets, slice by slice, in position order (one wave of the idle half) ----
+            // (Positions past the input's end go in like the rest: they follow every position that is searched.)
+            __builtin_amdgcn_s_setprio(3);
+            uint32_t o[NSL];  // the bucket's byte offset in the table, then what the bucket held
+#pragma unroll
+            for (uint32_t sl = 0; sl < NSL; ++sl) o[sl] = (uint32_t)s_post[sl * 64 + lane] << 2;
+            uint32_t dat = code_it | lane;
+            const uint32_t msk = 0xFFFFu;
+            // (an asm statement takes thirty operands at most: eight slices each; the last one waits for all)
+#define SF_MSKOR(O) "ds_mskor_rtn_b32 " O ", " O ", %[m], %[d] offset:%[tab]\n\tv_add_u32 %[d], 64, %[d]\n\t"
+#define SF_MSKOR8 SF_MSKOR("%0") SF_MSKOR("%1") SF_MSKOR("%2") SF_MSKOR("%3") SF_MSKOR("%4") SF_MSKOR("%5") SF_MSKOR("%6") SF_MSKOR("%7")
+            if constexpr (NSL == 16) {
+              asm volatile(SF_MSKOR8
+                           : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), [d] "+v"(dat)
+                           : [m] "v"(msk), [tab] "n"(L_TABLE)
+                           : "memory");
+              asm volatile(SF_MSKOR8 "s_waitcnt lgkmcnt(0)"
+                           : "+v"(o[8]), "+v"(o[9]), "+v"(o[10]), "+v"(o[11]), "+v"(o[12]), "+v"(o[13]), "+v"(o[14]), "+v"(o[15]), [d] "+v"(dat),
+                             "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])
+                           : [m] "v"(msk), [tab] "n"(L_TABLE)
+                           : "memory");
+            } else {
+              asm volatile(SF_MSKOR8 "s_waitcnt lgkmcnt(0)"
+                           : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), [d] "+v"(dat)
+                           : [m] "v"(msk), [tab] "n"(L_TABLE)
+                           : "memory");
+            }
+#undef SF_MSKOR8
+#undef SF_MSKOR
+            if constexpr (STRIDE2) {
+              if (!(lane & 1u)) {
+#pragma unroll
+                for (uint32_t sl = 0; sl < NSL; ++sl) s_ans[sl * 32 + (lane >> 1)] = (uint16_t)o[sl];
+              }
+            } else {
+#pragma unroll
+              for (uint32_t sl = 0; sl < NSL; ++sl) s_ans[sl * 64 + lane] = (uint16_t)o[sl];
+            }
+            __builtin_amdgcn_s_setprio(2);
+          }
+          lds_barrier();  // the step is in the table, the answers are in place
+        }
+        // STRIDE2: the last odd position of the last step that ran has no successor in its step: no match (see below)
+        if (STRIDE2 && t == 0 && nsteps < kRound / STEP) smem[L_LEN4 + nsteps * (STEP / 2)] = 0;
+        if (t < kHistStride) s_hist[t] = hsave;  // (the last barrier above follows the last read of a post)
+        if (r + 1 < nrounds) {  // the next round's bytes
+          pre_lo = load4(rb + kRound + kLook + 8 * t);
+          pre_hi = load4(rb + kRound + kLook + 8 * t + 4);
         }
       } else {
         // A step has 512 searches for 1024 threads: the even positions of 1024 (STRIDE2), or all of 512 (thorough).  The
@@ -1860,6 +2052,16 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
     hipLaunchKernelGGL(kernel, dim3(nstrips), dim3(K1_THREADS), 0, s, src, n, opt.strip_bytes, ws.items, ws.nitems, ws.ntok,
                        ws.hist, ws.rtok, opt.lazy, opt.fast_skip, stamps, opt.chain_depth);
   };
+  if (opt.recent) {  // exact recency (SFH_EFFORT_RECENT: even positions searched; SFH_EFFORT_RECENT_ALL: every position)
+    if (opt.stride2) {
+      if (ws.stamps) launch(k_lz77<true, true, true, true, false, false, true>, ws.stamps);
+      else launch(k_lz77<false, true, true, true, false, false, true>, (uint64_t*)nullptr);
+    } else {
+      if (ws.stamps) launch(k_lz77<true, true, true, false, false, false, true>, ws.stamps);
+      else launch(k_lz77<false, true, true, false, false, false, true>, (uint64_t*)nullptr);
+    }
+    return hipGetLastError();
+  }
   if (opt.chain_depth) {  // exact hash chains (SFH_EFFORT_BEST / _ULTRA / _EXTREME)
     if (ws.stamps) launch(k_lz77<true, true, true, false, false, true>, ws.stamps);
     else launch(k_lz77<false, true, true, false, false, true>, (uint64_t*)nullptr);

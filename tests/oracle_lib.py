@@ -41,6 +41,9 @@ class Params(C.Structure):
         ("use_prev", C.c_uint32),
         ("stride2", C.c_uint32),
         ("run_dist1", C.c_uint32),
+        ("recent", C.c_uint32),
+        ("near_depth", C.c_uint32),
+        ("link_steps", C.c_uint32),
     ]
 
 
