@@ -102,13 +102,13 @@ def run_steps(step, fence, steps, warmup):
     return time.perf_counter() - t0
 
 
-def pipelined_step(compress_fn, pieces, gathered, container="raw", checksum_fn=None, group=None, validate=True, bound_fn=None):
+def pipelined_step(compress_fn, pieces, gathered, container="raw", checksum_fn=None, group=None, validate=True, bound_fn=None, timing=None):
     """One N > 1 step: block-cyclic rounds with the gather overlapped (what the driver's --gpus N runs).  validate: the
     argument checks of compress_pipelined (two small collectives); a repeated step passes False after the first."""
     from starflate_amd import multigpu
 
     return multigpu.compress_pipelined(compress_fn, pieces, out=gathered, container=container, checksum_fn=checksum_fn, group=group,
-                                       validate=validate, bound_fn=bound_fn)
+                                       validate=validate, bound_fn=bound_fn, timing=timing)
 
 
 def verify_pieces(pieces, streams, sizes, wbits):
@@ -131,23 +131,39 @@ def verify_concatenation(whole_stream, wbits, total_in, piece_bytes, crcs_by_ran
         for k in range(K) for r in range(world))
 
 
+XGMI_LINK_GBS = 77.0      # one xGMI link, one direction (MI355X_MICROARCH.md: ~153 GB/s both ways per pair of GPUs)
+XGMI_P2P_EFFICIENCY = 0.82  # what a point-to-point RCCL transfer reaches of that
+
+
+def predict_scaling(world, rounds, compute_ms, stream_bytes_per_rank):
+    """DESIGN.md section 4 in numbers, so that a SCALE record can be read against the model without the document: every
+    rank but the root sends its stream over ITS OWN link, the links run side by side, so the gather of a step takes
+    T_x = (a rank's stream bytes) / (link rate) whatever N >= 2 is; with K block-cyclic rounds only the last round's
+    transfer is exposed: step ~ max(T_c, T_x) + T_x / K, where T_c is this rank's kernel time for the step as measured."""
+    t_x = 0.0 if world < 2 else stream_bytes_per_rank / (XGMI_LINK_GBS * XGMI_P2P_EFFICIENCY * 1e9) * 1e3
+    step = max(compute_ms, t_x) + (t_x / max(rounds, 1) if world > 1 else 0.0)
+    return {"model": "step_ms = max(T_c, T_x) + T_x / rounds;  T_x = stream bytes per rank / (77 GB/s x 0.82), the same for any N >= 2 "
+                     "(one xGMI link per peer into the root, side by side)",
+            "T_c_ms": round(compute_ms, 3), "T_x_ms": round(t_x, 3), "predicted_step_ms": round(step, 3),
+            "predicted_efficiency": round(compute_ms / step, 3) if step > 0 else None,
+            "bound": "gather (xGMI into the root)" if t_x > compute_ms else "compression"}
+
+
 def zlib6_size(host_bytes):
     co = zlib.compressobj(6, zlib.DEFLATED, -15)
     return len(co.compress(host_bytes)) + len(co.flush())
 
 
-def traffic_from_profile(kernel, n):
+def traffic_from_profile(kernel, n, now):
     """HBM bytes per launch of `kernel` (FETCH_SIZE x 2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) from the
     committed rocprofv3 --pmc passes of this very command (tools/prof_round.sh -> profiles/pmc_traffic.json), scaled to this
     run's bytes.  The profile carries the commit and a SHA-256 of the kernel sources it measured; `current` says whether
     those are the sources that are running now (a number from other sources is still reported, flagged)."""
-    from starflate_amd.build import source_stamp
-
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        e, meta, now = d.get(kernel), d.get("_meta", {}), source_stamp()
+        e, meta = d.get(kernel), d.get("_meta", {})
         if not e:
             return None, None
         scale = n / float(meta.get("bytes_per_launch", 1 << 30))
@@ -160,17 +176,15 @@ def traffic_from_profile(kernel, n):
         return None, None
 
 
-def issue_from_profile(kernel, kernel_ms, n, props):
+def issue_from_profile(kernel, kernel_ms, n, props, now):
     """The dominant kernel is nowhere near the HBM roofline; what it spends instead: vector
     instructions per launch from the committed PMC profile (SQ_INSTS_VALU of the same workload -- NOT counted in this run) over
     this run's kernel time, as cycles per wave-instruction per SIMD, and the share of the CU's cycles its LDS is busy.
     Dropped (None) when the profile was taken from other kernel sources than the ones running."""
-    from starflate_amd.build import source_stamp
-
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             meta = json.load(f).get("_meta", {})
-        if meta.get("csrc_sha256") != source_stamp()["csrc_sha256"] or not meta.get("pmc_summary"):
+        if meta.get("csrc_sha256") != now["csrc_sha256"] or not meta.get("pmc_summary"):
             return None
         with open(os.path.join(ROOT, "profiles", meta["pmc_summary"])) as f:
             d = json.load(f)
@@ -314,7 +328,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=1 << 30, help="input bytes per GPU")
     ap.add_argument("--workload", default="text", choices=["text", "random", "mixed", "runs"])
-    ap.add_argument("--effort", default="default", choices=["default", "fast", "fastest", "thorough", "max", "best", "ultra", "extreme"], help="sfh_options.effort of the timed steps")
+    ap.add_argument("--effort", default="default", choices=["default", "fast", "fastest", "thorough", "max", "best", "ultra", "extreme", "recent", "recent_all"], help="sfh_options.effort of the timed steps")
     ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default: 512 KiB at 1 GiB, 1 MiB with the chain efforts)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -337,6 +351,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
+
+    # what ties this run to kernel sources (commit + SHA-256): taken ONCE, here -- before torch or anything else has touched
+    # the GPU, so the `git` children it starts are not children of a GPU process (nor of a profiler's preloaded library)
+    from starflate_amd.build import source_stamp
+
+    stamp = source_stamp()
 
     import numpy as np
     import torch
@@ -436,6 +456,13 @@ def main():
         for name, v in ms.items():
             stage_acc.setdefault(name, []).append(v)
 
+    def compress_fn_for_timing():
+        def compress_fn(piece, final, k):
+            comp.compress_tensor_async(piece, scratch[k], size_dev[k], final_stream=final, block_bytes=bb, effort=args.effort)
+            return scratch[k], size_dev[k]
+
+        return compress_fn
+
     def fence():
         if multi:
             dist.barrier()
@@ -452,6 +479,25 @@ def main():
         dt = float(tmax.item())
 
     ms_per_step = dt / args.steps * 1e3
+    # ---- N > 1: what the record needs to be read without DESIGN.md -- who took part, what the gather cost, what was expected ----
+    multi_info = None
+    if multi:
+        if rehearsal:
+            me = f"cpu rank {rank} pid {os.getpid()}"
+        else:
+            pr = torch.cuda.get_device_properties(dev)
+            me = (f"{pr.name} pci {getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+                  f" uuid {getattr(pr, 'uuid', 'n/a')}")
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        # one more step, untimed, with events around each round's transfers (rank 0: the receives; the others: their send)
+        timing = {}
+        pipelined_step(compress_fn_for_timing(), pieces, gathered, container=args.container,
+                       checksum_fn=(lambda piece, k: comp.checksum_tensor(piece, args.container)) if args.container != "raw" else None,
+                       validate=False, bound_fn=comp.compress_bound, timing=timing)
+        fence()
+        multi_info = {"ranks_seen": dist.get_world_size(), "distinct_devices": len(set(seen)), "devices": seen,
+                      "gather_ms_per_round": timing.get("gather_ms"), "rounds": K}
     total_in = n * world
     value = total_in * args.steps / dt / 2**20
     total_out = int(result["total"])
@@ -481,7 +527,9 @@ def main():
                           "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(ms_per_step, 3), "rehearsal": True, "backend": "gloo", "compressor": comp.name,
                           "config": {"workload": wl, "parallelism": f"shard{world} block-cyclic x{K}"},
-                          "compressed_bytes": total_out, "roundtrip_ok": ok}), flush=True)
+                          "compressed_bytes": total_out, "roundtrip_ok": ok,
+                          "multi_gpu": dict(multi_info, gather_ms_per_step=round(sum(multi_info["gather_ms_per_round"] or [0.0]), 4),
+                                            prediction=predict_scaling(world, K, ms_per_step, local_n))}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -514,7 +562,7 @@ def main():
         dp = _capi.device_props(local_rank)
     except Exception as e:  # noqa: BLE001
         dp = {"error": str(e)}
-    traffic, traffic_info = traffic_from_profile(dom, n)
+    traffic, traffic_info = traffic_from_profile(dom, n, stamp)
     text_default = args.effort == "default" and args.workload == "text" and not corpus and args.container == "raw" and not multi
     if not text_default:  # the profile is of the default command: another workload's traffic is not in it
         traffic, traffic_info = None, None
@@ -523,7 +571,7 @@ def main():
                 "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None, "traffic_info": traffic_info,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
                 "read_frac": round(n / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "issue": issue_from_profile(dom, stage_ms[dom], n, dp) if text_default and "error" not in dp else None}
+                "issue": issue_from_profile(dom, stage_ms[dom], n, dp, stamp) if text_default and "error" not in dp else None}
     if "error" in dp:
         roofline["device"] = dp
     else:
@@ -603,7 +651,7 @@ def main():
                 t = t.repeat(reps)
                 desc += f", repeated x{reps} for throughput"
                 nb *= reps
-            for eff in ("default", "thorough", "max", "chain4", "best", "ultra", "extreme"):
+            for eff in ("default", "recent", "thorough", "recent_all", "max", "chain4", "best", "ultra", "extreme"):
                 others[key if eff == "default" else f"{key}_effort_{eff}"] = secondary_workload(
                     comp, key, nb, dev, 0, effort=eff, data=t, wl=desc)
             del t
@@ -617,6 +665,10 @@ def main():
         # SFH_EFFORT_MAX: thorough with a second hash table keyed by seven bytes
         others["effort_max"] = secondary_workload(comp, args.workload, n, dev, bb, effort="max", data=data, wl=wl)
         others["mixed_effort_max"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort="max")
+        # SFH_EFFORT_RECENT / _RECENT_ALL: the step tables with exact recency (buckets filled by ordered LDS atomics)
+        for eff in ("recent", "recent_all"):
+            others[f"effort_{eff}"] = secondary_workload(comp, args.workload, n, dev, bb, effort=eff, data=data, wl=wl)
+            others[f"mixed_effort_{eff}"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort=eff)
         # SFH_EFFORT_BEST / _ULTRA / _EXTREME: exact hash chains of depth 8 / 16 / 32 (zlib's structure) instead of the step tables
         for eff in ("chain4", "best", "ultra", "extreme"):  # chain4: sfh_options.chain_depth = 4 with a chain effort
             # (block_bytes 0: the chain efforts' own default strip, 1 MiB at this size)
@@ -674,6 +726,11 @@ def main():
         "kernel_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "kernels_total_ms": round(kern_total_ms, 4),
         "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "workloads": others, "decompress": decomp,
     }
+    if multi_info is not None:
+        # RCCL saw these devices; the gather of one step as measured (events around each round's transfers on rank 0) beside
+        # what the xGMI arithmetic of DESIGN.md section 4 predicts for this step's own numbers
+        line["multi_gpu"] = dict(multi_info, gather_ms_per_step=round(sum(multi_info["gather_ms_per_round"] or [0.0]), 4),
+                                 prediction=predict_scaling(world, K, kern_total_ms, local_n))
     print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()

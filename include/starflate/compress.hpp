@@ -25,6 +25,7 @@ enum class CompressStatus : std::uint8_t {
   DeviceError,
   OutOfMemory,
   CommError,    // RCCL not loadable, or an RCCL call failed (gather_streams)
+  Unsupported,  // the effort rests on LDS behaviour this device does not show (sfh_lds_order_check)
 };
 
 enum class BlockStrategy : std::uint8_t { Auto, Stored, Fixed, Dynamic };
@@ -36,6 +37,9 @@ enum class BlockStrategy : std::uint8_t { Auto, Stored, Fixed, Dynamic };
 ///   Thorough: every position searched
 ///   Max     : Thorough with a second hash table keyed by seven bytes
 ///   Best / Ultra / Extreme: exact hash chains of depth 8 / 16 / 32 (zlib's structure) instead of the step tables
+///   Recent / RecentAll: the step tables with EXACT RECENCY -- a bucket holds the latest position with the hash and the one
+///             before the latest inserting step, a position's nearest earlier occurrence is its third candidate; every
+///             other position searched (Recent) or every position (RecentAll)
 enum class Effort : std::uint8_t {
   Default = SFH_EFFORT_DEFAULT,
   Fast = SFH_EFFORT_FAST,
@@ -45,6 +49,8 @@ enum class Effort : std::uint8_t {
   Best = SFH_EFFORT_BEST,    // exact hash chains, the 8 most recent positions with the hash
   Ultra = SFH_EFFORT_ULTRA,  // ... the 16 most recent
   Extreme = SFH_EFFORT_EXTREME,  // ... the 32 most recent: zlib -6's own ratio
+  Recent = SFH_EFFORT_RECENT,
+  RecentAll = SFH_EFFORT_RECENT_ALL,
 };
 
 struct compress_options {
@@ -82,6 +88,7 @@ inline auto to_status(int rc) -> CompressStatus {
     case SFH_E_HIP: return CompressStatus::DeviceError;
     case SFH_E_NOMEM: return CompressStatus::OutOfMemory;
     case SFH_E_COMM: return CompressStatus::CommError;
+    case SFH_E_UNSUPPORTED: return CompressStatus::Unsupported;
     default: return CompressStatus::InvalidArgument;
   }
 }

@@ -731,7 +731,9 @@ static uint32_t parse_regions(const uint8_t* data, uint32_t n, const sfo_params*
  * Stored fast path: when the first SFO_SKIP_SPAN positions of a block parse to (almost) nothing but
  * literals -- at least SFO_SKIP_SPAN - SFO_SKIP_SLACK tokens -- the rest of the block is neither
  * searched nor inserted into the tables: every later position is emitted as a literal.  (High-entropy
- * data then costs a quarter of the match work and ends up in a stored block.)
+ * data then costs a quarter of the match work and ends up in a stored block.)  Round 5: the block BEHIND such a block
+ * in its strip is probed on SFO_SKIP_PROBE positions only (a sixteenth of the match work while the data stays
+ * high-entropy).
  * tokens: region r's tokens at tokens[r * region_bytes + k], k < ntok[r] (regions counted from the
  * strip's start); a block's regions are those it covers.
  */
@@ -739,6 +741,7 @@ int sfo_strip_tokens(const uint8_t* src, uint32_t n, const sfo_params* p, uint32
   const uint32_t cb = p->chunk_bytes, R = p->region_bytes, W = p->step;
   matcher m;
   if (matcher_init(&m, src, n, p)) { matcher_free(&m); return -3; }
+  int prev_skipped = 0; /* the strip's previous block took the stored fast path */
   for (uint32_t c0 = 0; c0 < n; c0 += cb) {
     const uint32_t cn = n - c0 < cb ? n - c0 : cb;
     const uint32_t r0 = c0 / R, r1 = (c0 + cn + R - 1) / R;
@@ -747,14 +750,21 @@ int sfo_strip_tokens(const uint8_t* src, uint32_t n, const sfo_params* p, uint32
     if (!can_skip) {
       match_steps(&m, s0, s1);
       parse_regions(m.d, n, p, m.len16, m.dist16, r0, r1, 0, tokens, ntok);
+      prev_skipped = 0;
       continue;
     }
+    /* Behind a block that took the fast path only the first SFO_SKIP_PROBE positions of the probe span are searched and
+     * inserted (the rest of the span are literals whatever they hold): high-entropy data usually goes on.  The rule that
+     * decides stays the same -- tokens of the whole span -- so such a block needs nearly all of the searched positions
+     * to be literals as well. */
+    const uint32_t probe = (prev_skipped && SFO_SKIP_PROBE % W == 0) ? SFO_SKIP_PROBE : SFO_SKIP_SPAN;
     const uint32_t sh = s0 + SFO_SKIP_SPAN / W, rh = r0 + SFO_SKIP_SPAN / R;
-    match_steps(&m, s0, sh);
+    match_steps(&m, s0, s0 + probe / W);
     const uint32_t head = parse_regions(m.d, n, p, m.len16, m.dist16, r0, rh, 0, tokens, ntok);
     const int skip = head >= SFO_SKIP_SPAN - SFO_SKIP_SLACK;
     if (!skip) match_steps(&m, sh, s1);
     parse_regions(m.d, n, p, m.len16, m.dist16, rh, r1, skip, tokens, ntok);
+    prev_skipped = skip;
   }
   matcher_free(&m);
   return 0;
@@ -916,9 +926,49 @@ static uint32_t rle_lengths(const uint8_t* lens, uint32_t n, uint8_t* sym, uint8
   return k;
 }
 
+/* ~ 256 * log2(x), x >= 1: the exponent and the top six mantissa bits through a table (integers only: the GPU's k_plan
+ * computes the same) */
+static const uint8_t est_lg64[64] = {0, 6, 11, 17, 22, 28, 33, 38, 44, 49, 54, 59, 63, 68, 73, 78, 82, 87, 92, 96, 100, 105, 109, 113, 118, 122,
+                                     126, 130, 134, 138, 142, 146, 150, 154, 157, 161, 165, 169, 172, 176, 179, 183, 186, 190, 193, 197,
+                                     200, 203, 207, 210, 213, 216, 220, 223, 226, 229, 232, 235, 238, 241, 244, 247, 250, 253};
+static uint32_t est_log2(uint32_t x) {
+  uint32_t e = 0;
+  for (uint32_t v = x | 1u; v > 1; v >>= 1) e++;
+  uint32_t m = (e >= 6 ? x >> (e - 6) : x << (6 - e)) & 63u;
+  return (e << 8) + est_lg64[m];
+}
+
 void sfo_plan_chunk(const uint32_t* ll, const uint32_t* d, uint32_t n_raw, int is_last,
                     const sfo_params* p, sfo_plan* plan) {
   memset(plan, 0, sizeof *plan);
+  if (p->strategy == 0) {
+    /* Stored without a code (round 5).  A chunk that is (all but) incompressible -- the fixed block no shorter than the
+     * stored one, and the ESTIMATE of the dynamic block (entropy of the symbols in fixed point + extra bits + the
+     * shortest header) within SFO_STORE_MARGIN bytes of it -- is stored, and no Huffman code is built for it: such a
+     * chunk gives up SFO_STORE_MARGIN bytes at most, and the high-entropy chunks of the stored fast path cost the
+     * planner a histogram pass. */
+    uint32_t tot = 0, nmat = 0, ent = 0, extra = 0, fixb = 0;
+    for (uint32_t s = 0; s < 286; s++) tot += ll[s];
+    for (uint32_t s = 0; s < 30; s++) nmat += d[s];
+    for (uint32_t s = 0; s < 286; s++) {
+      if (ll[s]) ent += ll[s] * (est_log2(tot) - est_log2(ll[s]));
+      fixb += ll[s] * fixed_ll_len(s);
+      if (s >= 257) extra += ll[s] * len_extra[s - 257];
+    }
+    for (uint32_t s = 0; s < 30; s++) {
+      if (d[s]) ent += d[s] * (est_log2(nmat) - est_log2(d[s]));
+      extra += d[s] * dist_extra[s];
+    }
+    const int fin0 = is_last && p->final_stream;
+    const uint32_t est_bits = (ent >> 8) + extra + SFO_EST_HEADER_BITS, fixbits = 3 + fixb + extra + 5 * nmat;
+    const uint32_t est_b = fin0 ? (est_bits + 7) / 8 : (est_bits + 3 + 7) / 8 + 4;
+    const uint32_t fix_b = fin0 ? (fixbits + 7) / 8 : (fixbits + 3 + 7) / 8 + 4;
+    if (fix_b >= n_raw + 5 && est_b + SFO_STORE_MARGIN >= n_raw + 5) {
+      plan->btype = 0;
+      plan->out_bytes = n_raw + 5;
+      return;
+    }
+  }
   sfo_build_lengths(ll, 286, 15, plan->ll_lens);
   sfo_build_lengths(d, 30, 15, plan->d_lens);
 

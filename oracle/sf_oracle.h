@@ -146,6 +146,9 @@ size_t sfo_resolve_strip_bytes(const sfo_params* p, size_t n);
 #define SFO_RUN_MIN 32u /* run_dist1: matches shorter than this are left alone */
 #define SFO_SKIP_SPAN 8192u
 #define SFO_SKIP_SLACK 128u
+#define SFO_STORE_MARGIN 64u     /* sfo_plan_chunk: bytes an estimated dynamic block may be short of the stored one and still lose to it */
+#define SFO_EST_HEADER_BITS 29u  /* ... the least a dynamic header takes: block header, HLIT, HDIST, HCLEN, four code-length-code lengths */
+#define SFO_SKIP_PROBE 2048u /* positions searched of a block whose predecessor in the strip took the stored fast path */
 
 void sfo_default_params(sfo_params* p);
 

@@ -250,6 +250,8 @@ class Compressor:
         nit = self.debug(_capi.DBG_NITEMS, nchunks)
         toks, flags = [], []
         for c in range(nchunks):
+            if nit[c] & 0x80000000:  # kItemsSkipped: stored fast path, the items behind the first 8 KiB were never written
+                raise StarflateError(-1, f"chunk {c} took the stored fast path: its items are not materialised (stored_fast_path=False shows them)")
             it = items[c, : nit[c]].astype(np.uint32)
             head = (it & 0x8000) != 0
             cont = np.zeros(it.size, dtype=bool)

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
   uint32_t ebase = 0u - kWindow / STEP;
   uint32_t tot_tok = 0, tot_items = 0;   // of the chunk in flight (uniform)
   bool skip = false;                     // stored fast path (uniform): set after kSkipSpan positions of a chunk
+  bool short_probe = false;              // (uniform) the strip's previous chunk took it: only kSkipProbe positions of this one's span are searched
 
   for (uint32_t r = 0; r < nrounds; ++r) {
     const uint32_t rb = r * kRound;                         // strip position of the round's first byte
@@ -335,7 +336,10 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
     const uint32_t cstart = rb - rc * kRound;               // strip position of the chunk's first byte
     const uint32_t qn = (n - rb) < kRound ? (n - rb) : kRound;  // valid positions in this round
     uint16_t* const gi = items + (uint64_t)chunk * kChunk;
-    if (rc == 0) { tot_tok = 0; tot_items = 0; skip = false; }
+    if (rc == 0) {
+      short_probe = skip && fast_skip && (n - cstart) > kSkipSpan;  // (skip: still the previous chunk's)
+      tot_tok = 0; tot_items = 0; skip = false;
+    }
     if (rc == kSkipSpan / kRound) skip = fast_skip && (n - cstart) > kSkipSpan && tot_tok >= kSkipSpan - kSkipSlack;
 
     // RECENT: the histogram's place holds the match phase's posts; its counts wait here meanwhile
@@ -387,17 +391,30 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         pre_lo = load4(rb + kRound + kLook + 8 * t);
         pre_hi = load4(rb + kRound + kLook + 8 * t + 4);
       }
-      for (uint32_t rel = t; rel < qn; rel += K1_THREADS) {
-        const uint32_t b = s_bytes[kWindow + rel];
-        gi[tot_items + rel] = (uint16_t)((rel & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((rc * kRSubs + rel / kSubBytes) << 8)) : b);
-        atomicAdd(&s_hist[b], 1u);
+      // No item is written: an item of this span IS the position's byte, and k_emit takes it from the input in the rare
+      // case that such a chunk is not stored (kItemsSkipped in nitems).  What the plan needs is the byte histogram
+      {
+        const uint32_t rel0 = 8 * t;
+        if (rel0 < qn) {
+          const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + rel0]);
+          const uint32_t nvb = qn - rel0 < 8 ? qn - rel0 : 8u;
+#pragma unroll
+          for (uint32_t k = 0; k < 8; ++k)
+            if (k < nvb) atomicAdd(&s_hist[((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu], 1u);
+        }
       }
       if (t < kRSubs) rtok_out[chunk * kSubRegions + rc * kRSubs + t] = tot_tok + (t * kSubBytes < qn ? t * kSubBytes : qn);
       tot_tok += qn;
       tot_items += qn;
     } else {
       // ---- match finding over this round ----
-      const uint32_t nsteps = (qn + STEP - 1) / STEP;
+      uint32_t nsteps = (qn + STEP - 1) / STEP;
+      if (short_probe && rc == 0) {
+        // behind a chunk that took the stored fast path: kSkipProbe positions are searched, the rest of the span has no match
+        static_assert(kSkipProbe % STEP == 0 && kSkipProbe < kSkipSpan && kSkipSpan == kRound, "short probe: whole steps of the chunk's first round");
+        nsteps = nsteps < kSkipProbe / STEP ? nsteps : kSkipProbe / STEP;
+        for (uint32_t idx = kSkipProbe / 8 + t; idx < kRound / 8; idx += K1_THREADS) s_len4[idx] = 0;  // (the steps that run write below this)
+      }
       const uint32_t K = kWindow + ebase * STEP - rb;  // LDS byte address of a coded position = entry_pos(code) + K (mod 2^32)
       // The CU's two workgroups are in different phases most of the time.  The match phase is the long one and the one
       // that keeps the LDS and the vector units busy, so its waves go first when both workgroups have instructions ready
@@ -1260,7 +1277,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         hist_out[(uint64_t)chunk * kHistStride + idx] = s_hist[idx];
         s_hist[idx] = (idx == 256) ? 1u : 0u;
       }
-      if (t == 0) { ntok_out[chunk] = tot_tok; nitems_out[chunk] = tot_items; }
+      if (t == 0) { ntok_out[chunk] = tot_tok; nitems_out[chunk] = tot_items | (skip ? kItemsSkipped : 0u); }
       const uint32_t covered = (rc + 1) * kRSubs;  // sub-index regions of the rounds that ran
       if (t < kSubRegions && t >= covered) rtok_out[chunk * kSubRegions + t] = tot_tok;
       stamp(6);
@@ -1556,6 +1573,19 @@ __device__ uint32_t rle_parallel(PlanSmem& S, const uint8_t* lens, uint32_t n, u
   return total;
 }
 
+// est_log2(x) ~ 256 * log2(x) for x >= 1: the exponent and the top six mantissa bits through a table -- plain integers, the
+// same in the specification (oracle: est_log2), so the stored-without-a-code rule of k_plan decides alike on both sides
+__constant__ uint8_t c_est_lg64[64] = {0, 6, 11, 17, 22, 28, 33, 38, 44, 49, 54, 59, 63, 68, 73, 78, 82, 87, 92, 96, 100, 105, 109, 113, 118, 122,
+                                       126, 130, 134, 138, 142, 146, 150, 154, 157, 161, 165, 169, 172, 176, 179, 183, 186, 190, 193, 197,
+                                       200, 203, 207, 210, 213, 216, 220, 223, 226, 229, 232, 235, 238, 241, 244, 247, 250, 253};
+__device__ __forceinline__ uint32_t est_log2(uint32_t x) {
+  const uint32_t e = 31 - __builtin_clz(x | 1u);
+  const uint32_t m = (e >= 6 ? x >> (e - 6) : x << (6 - e)) & 63u;
+  return (e << 8) + c_est_lg64[m];
+}
+constexpr uint32_t kEstHeaderBits = 17 + 3 * 4;  // block header, HLIT, HDIST, HCLEN and four code-length-code lengths: the least a dynamic header takes
+constexpr uint32_t kStoreMargin = 64;            // bytes: an estimate this close to the stored size settles for "stored"
+
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
@@ -1599,6 +1629,49 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   if (lane < 29) hist[(uint64_t)chunk * kHistStride + 257 + lane] = S.freq[257 + lane];  // the folded counts, for parity tests
 
   stamp();  // 0 load
+  if (strategy == 0) {
+    // A chunk that is (all but) incompressible is STORED without building a code: when the fixed block is no shorter than
+    // the stored one and the ESTIMATE of the dynamic block -- the symbols' entropy in fixed point (est_log2: a 64-entry
+    // table, the same integers in the specification) + extra bits + the shortest header -- comes within kStoreMargin
+    // bytes of it.  Part of the specification (the oracle's plan makes the same choice from the same integers): such a
+    // chunk gives up at most kStoreMargin bytes, and the high-entropy chunks of the stored fast path cost a histogram
+    // pass instead of three Huffman codes.
+    uint32_t fixb = 0, extra = 0, tot = 0;
+    for (uint32_t s0 = lane; s0 < 286; s0 += 64) tot += S.freq[s0];
+    tot = wave_sum(tot);
+    const uint32_t ltot = est_log2(tot);
+    uint32_t ent = 0;
+    for (uint32_t s0 = lane; s0 < 286; s0 += 64) {
+      const uint32_t f = S.freq[s0];
+      if (f) ent += f * (ltot - est_log2(f));
+      fixb += f * fixed_ll_len(s0);
+      if (s0 >= 257) extra += f * len_extra_of_sym(s0 - 257);
+    }
+    const uint32_t g = lane < 30 ? S.freq[kHistD + lane] : 0u;
+    const uint32_t nmat = wave_sum(g);
+    if (g) ent += g * (est_log2(nmat) - est_log2(g));
+    if (lane < 30) extra += g * dist_extra_of_sym(lane);
+    const uint32_t extra_all = wave_sum(extra);
+    const uint32_t est_bits = (wave_sum(ent) >> 8) + extra_all + kEstHeaderBits;
+    const uint32_t fixbits = 3 + wave_sum(fixb) + extra_all + 5 * nmat;
+    const uint32_t est_b = fin ? (est_bits + 7) / 8 : (est_bits + 3 + 7) / 8 + 4;
+    const uint32_t fix_b = fin ? (fixbits + 7) / 8 : (fixbits + 3 + 7) / 8 + 4;
+    const uint32_t sto_b = n_raw + 5;
+    if (fix_b >= sto_b && est_b + kStoreMargin >= sto_b) {
+      ChunkCodes& C0 = codes[chunk];
+      for (uint32_t s0 = lane; s0 < 320; s0 += 64) C0.lens[s0] = 0;  // (no code was built)
+      if (lane == 0) {
+        C0.header[0] = fin ? 1u : 0u;
+        ChunkPlan P;
+        P.btype = 0;
+        P.out_bytes = sto_b;
+        P.header_bits = 3;
+        P.body_bits = 0;
+        plan[chunk] = P;
+      }
+      return;
+    }
+  }
   build_lengths<5>(S, S.freq, 286, 15, S.lens, lane);
   stamp();  // 1 lit/len lengths
   build_lengths<1>(S, S.freq + kHistD, 30, 15, S.lens + 288, lane);
@@ -1808,6 +1881,26 @@ __device__ __forceinline__ void match_bits(uint32_t l3, uint32_t d1, const uint3
   nb = p;
 }
 
+// Items [i0, i0 + 8) and the item before them for a chunk whose items behind the first n0 were never written (stored fast
+// path: they are the bytes of the chunk's positions from kSkipSpan on, the first of every 1024 flagged as k_lz77 flags
+// it).  Out of line: it runs for the rare chunk that took the fast path and is NOT stored, and must not cost the common
+// path registers.
+__device__ __attribute__((noinline)) void emit_tail_items(const uint16_t* it, const uint8_t* chunk_src, uint32_t n0, uint32_t nit, uint32_t i0,
+                                                          uint4& q, uint32_t& before) {
+  auto item_of = [&](uint32_t idx) -> uint32_t {
+    if (idx >= nit) return 0u;
+    if (idx < n0) return it[idx];
+    const uint32_t pos = kSkipSpan + (idx - n0);
+    const uint32_t b = chunk_src[pos];
+    return (pos & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((pos / kSubBytes) << 8)) : b;
+  };
+  q.x = item_of(i0) | (item_of(i0 + 1) << 16);
+  q.y = item_of(i0 + 2) | (item_of(i0 + 3) << 16);
+  q.z = item_of(i0 + 4) | (item_of(i0 + 5) << 16);
+  q.w = item_of(i0 + 6) | (item_of(i0 + 7) << 16);
+  before = i0 ? item_of(i0 - 1) : 0u;
+}
+
 __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restrict__ src, uint64_t n_total,
                                                      uint32_t /*nchunks*/, const uint16_t* __restrict__ items,
                                                      const uint32_t* __restrict__ nitems_in,
@@ -1905,7 +1998,11 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
   __syncthreads();
 
   const uint32_t ntok = pre_ntok;
-  const uint32_t nit = pre_nit;
+  const uint32_t nit = pre_nit & ~kItemsSkipped;
+  // stored fast path: the items behind the chunk's first kSkipSpan positions were never written -- they are those
+  // positions' bytes (every position a literal), taken from the input here.  n0: the items that were written
+  const bool tail = (pre_nit & kItemsSkipped) != 0;  // (uniform)
+  const uint32_t n0 = tail ? nit - (n_raw - kSkipSpan) : nit;
   const uint16_t* it = items + (uint64_t)chunk * kChunk;
   uint32_t running = 8 * sh + P.header_bits;
   uint32_t buf = 0;
@@ -1914,6 +2011,10 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
   // neighbour's last -- over the DPP network, only a wave's first lane goes to memory.
   // (reads past nit stay inside the chunk's kChunk-slot item area; they are masked below)
   auto load_batch = [&](uint32_t i0, uint4& q, uint32_t& before) {
+    if (tail) {  // (the rare path, kept out of line: a chunk that took the fast path and is not stored)
+      emit_tail_items(it, src + cbase, n0, nit, i0, q, before);
+      return;
+    }
     q = *reinterpret_cast<const uint4*>(it + i0);
     before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q.w >> 16), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
     if (lane == 0) before = i0 ? it[i0 - 1] : 0u;

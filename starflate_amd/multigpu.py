@@ -7,6 +7,7 @@ into rank 0's output at its prefix offset (a gather-v; each transfer rides one
 xGMI link, no ring).  Works with backend "nccl" (= RCCL on ROCm) on CUDA tensors
 and with "gloo" on CPU tensors (tests)."""
 import contextlib
+import time
 
 import torch
 import torch.distributed as dist
@@ -72,7 +73,7 @@ _SIDE_STREAMS = {}  # device index -> the two side streams of compress_pipelined
 
 
 def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw", checksum_fn=None, bound_fn=None,
-                       validate=True):
+                       validate=True, timing=None):
     """Block-cyclic sharding with overlap.  BYTE ORDER CONTRACT: the global input is K*world pieces in the order
     g = k*world + rank; this rank holds `pieces[k]` for rounds k = 0..K-1 (a file of N bytes is dealt in pieces of
     N / (K*world) bytes, a multiple of the strip size: piece g goes to rank g % world as its round g // world).
@@ -95,7 +96,10 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
 
     validate=False skips the argument checks, which cost two small collectives and two host round trips per call: for
     a caller that repeats a call whose arguments (piece sizes, `out`, container) a first call has already judged --
-    every rank must pass the same value."""
+    every rank must pass the same value.    timing: a dict that receives {"gather_ms": [per round]} -- on every rank the time from the point a round's transfers
+    are posted (its streams are compressed, the sizes exchanged) until they have completed, by device events on the round's
+    side stream (perf_counter over the waits on a CPU group): what the concatenation costs beside the compression.
+    """
     from .compressor import checksum_combine, wrapper_bytes
 
     world = dist.get_world_size(group)
@@ -140,7 +144,7 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
     elif not ok:
         raise ValueError(msg)
 
-    works, keep, parts = [], [], []
+    works, keep, parts, posted = [], [], [], []
     base = len(header)
     running, n_in = None, 0
     enq = {}
@@ -201,16 +205,40 @@ def compress_pipelined(compress_fn, pieces, group=None, out=None, container="raw
                     off += sizes[r]
             else:
                 ops = [dist.P2POp(dist.isend, local[:n], 0, group=group)] if n else []
-            if ops:
-                works.extend(dist.batch_isend_irecv(ops))
+            t_post = None
+            if timing is not None:
+                if side:
+                    t_post = torch.cuda.Event(enable_timing=True)
+                    t_post.record()
+                else:
+                    t_post = time.perf_counter()
+            round_works = dist.batch_isend_irecv(ops) if ops else []
+            works.extend(round_works)
+            posted.append((k, t_post, round_works))
         keep.append(local)
         base += sum(sizes)
-    for w in works:
-        w.wait()
+    gather_ev = []
+    for k, t_post, round_works in posted:
+        with on(k):
+            for w in round_works:
+                w.wait()
+            if timing is not None:
+                if side:
+                    t_done = torch.cuda.Event(enable_timing=True)
+                    t_done.record()
+                    gather_ev.append((t_post, t_done))
+                else:
+                    gather_ev.append(time.perf_counter() - t_post)
     if side:
         for st in side:
             cur.wait_stream(st)
     del keep
+    if timing is not None:
+        if side:
+            torch.cuda.current_stream(dev).synchronize()
+            timing["gather_ms"] = [round(a.elapsed_time(b), 4) for a, b in gather_ev]
+        else:
+            timing["gather_ms"] = [round(1e3 * t, 4) for t in gather_ev]
     trailer = wrapper_bytes(container, running, n_in)[1] if wrapped else b""
     total = base + len(trailer)
     if rank != 0:

@@ -182,8 +182,10 @@ auto main(int argc, char** argv) -> int {
     // compress_options::effort mirrors enum sfh_effort: every level round-trips; Max is the smallest, Fastest the largest
     static_assert(static_cast<int>(Effort::Max) == SFH_EFFORT_MAX && static_cast<int>(Effort::Fastest) == SFH_EFFORT_FASTEST);
     static_assert(static_cast<int>(Effort::Best) == SFH_EFFORT_BEST && static_cast<int>(Effort::Ultra) == SFH_EFFORT_ULTRA);
-    std::size_t size_of[8] = {};
-    for (const Effort e : {Effort::Default, Effort::Fast, Effort::Fastest, Effort::Thorough, Effort::Max, Effort::Best, Effort::Ultra, Effort::Extreme}) {
+    std::size_t size_of[10] = {};
+    static_assert(static_cast<int>(Effort::Recent) == SFH_EFFORT_RECENT && static_cast<int>(Effort::RecentAll) == SFH_EFFORT_RECENT_ALL);
+    for (const Effort e : {Effort::Default, Effort::Fast, Effort::Fastest, Effort::Thorough, Effort::Max, Effort::Best, Effort::Ultra, Effort::Extreme,
+                           Effort::Recent, Effort::RecentAll}) {
       compress_options eo;
       eo.effort = e;
       const auto ne = gpu.compress(html, comp, eo);

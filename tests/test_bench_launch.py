@@ -31,6 +31,13 @@ def test_bench_self_launch_gloo(gpus, container):
     d = json.loads(lines[0])
     assert d["n_gpus"] == gpus and d["rehearsal"] is True and d["roundtrip_ok"] is True
     assert d["steps"] == 2 and d["compressed_bytes"] > 0 and d["value"] > 0
+    # the record explains itself: who took part, what the gather cost per round, what the xGMI arithmetic expects
+    m = d["multi_gpu"]
+    assert m["ranks_seen"] == gpus and m["distinct_devices"] == gpus and len(m["devices"]) == gpus and m["rounds"] == 2
+    assert len(m["gather_ms_per_round"]) == 2 and all(t >= 0 for t in m["gather_ms_per_round"]) and m["gather_ms_per_step"] >= 0
+    pr = m["prediction"]
+    assert {"model", "T_c_ms", "T_x_ms", "predicted_step_ms", "predicted_efficiency", "bound"} <= set(pr)
+    assert 0 < pr["predicted_efficiency"] <= 1 and pr["T_x_ms"] > 0
 
 
 def test_bench_self_launch_propagates_failure():

@@ -55,7 +55,17 @@ def test_host_side_entry_points_without_gpu():
     big = (C.c_uint64 * 2)(2**64 - 1, 5)
     assert lib.sfh_gather_offsets(big, 2, 1, 2**64 - 1, off) == -1  # overflow
     assert lib.sfh_gather_offsets(None, 2, 0, 0, off) == -1 and lib.sfh_gather_offsets(sizes, 0, 0, 0, off) == -1
-    assert _capi.EFFORT == {"default": 0, "fast": 1, "fastest": 2, "thorough": 3, "max": 4, "best": 5, "ultra": 6, "extreme": 7}  # enum sfh_effort
+    assert _capi.EFFORT == {"default": 0, "fast": 1, "fastest": 2, "thorough": 3, "max": 4, "best": 5, "ultra": 6, "extreme": 7,
+                            "recent": 8, "recent_all": 9}  # enum sfh_effort
+    with open(os.path.join(ROOT, "include", "starflate_hip.h")) as f:  # ... as the header spells it
+        enum = re.search(r"enum sfh_effort \{(.*?)\}", f.read(), flags=re.S).group(1)
+    assert {k.strip().replace("SFH_EFFORT_", "").lower(): int(v) for k, v in (e.split("=") for e in enum.split(","))} == _capi.EFFORT
+    # an effort may be given by name, as "chainN", or as the enum's integer: the strip rule must not depend on the spelling
+    for n in (1 << 30, 600 << 20, 64 << 20):
+        for name, val in _capi.EFFORT.items():
+            assert _capi.resolve_block_bytes(0, n, name) == _capi.resolve_block_bytes(0, n, val), (n, name)
+    assert _capi.resolve_block_bytes(0, 1 << 30, 6) == 1 << 20 and _capi.resolve_block_bytes(0, 1 << 30, 8) == 524288
+    assert _capi.resolve_block_bytes(0, 1 << 30, "recent_all") == 524288
     assert lib.sfh_stage_name(0) == b"k_lz77" and lib.sfh_stage_name(3) == b"k_emit" and lib.sfh_stage_name(9) == b""
     import zlib
     a, b = bytes(range(256)) * 300, b"starflate" * 5000  # host-side checksum combine rules against zlib

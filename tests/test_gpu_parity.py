@@ -266,7 +266,9 @@ def test_stored_fast_path(compressor):
 
 EFFORT_PARAMS = {"default": {}, "fast": {"depth": 1}, "fastest": {"depth": 1, "use_near": 0}, "thorough": {"stride2": 0, "step": 512},
                  "max": {"stride2": 0, "step": 512, "hash_bits": 12, "long_hash_bytes": 7},
-                 "best": {"chain_depth": 8}, "ultra": {"chain_depth": 16}, "extreme": {"chain_depth": 32}}
+                 "best": {"chain_depth": 8}, "ultra": {"chain_depth": 16}, "extreme": {"chain_depth": 32},
+                 "recent": {"recent": 1, "near_depth": 1, "link_steps": 1},
+                 "recent_all": {"recent": 1, "near_depth": 1, "link_steps": 1, "stride2": 0, "step": 512}}
 
 
 @pytest.mark.parametrize("effort", sorted(EFFORT_PARAMS))
@@ -608,7 +610,9 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
         # every effort: default (even positions searched), thorough (all, steps of 512), fast (one level), fastest (no near)
         effort, ekw = [("default", {}), ("thorough", dict(stride2=0, step=512)), ("best", dict(chain_depth=8)), ("fast", dict(depth=1)),
                        ("fastest", dict(depth=1, use_near=0)), ("max", dict(stride2=0, step=512, hash_bits=12, long_hash_bytes=7)),
-                       ("ultra", dict(chain_depth=16)), ("extreme", dict(chain_depth=32))][it % 8 if it % 13 else 5]
+                       ("ultra", dict(chain_depth=16)), ("extreme", dict(chain_depth=32)),
+                       ("recent", dict(recent=1, near_depth=1, link_steps=1)),
+                       ("recent_all", dict(recent=1, near_depth=1, link_steps=1, stride2=0, step=512))][it % 10 if it % 13 else 5]
         got = np.frombuffer(compressor.compress(data, strategy=strategy, lazy=lazy, stored_fast_path=fast, block_bytes=bb, effort=effort), np.uint8)
         want = O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=int(fast), strip_bytes=bb, **ekw))
         assert np.array_equal(got, want), (it, total, strategy, lazy, fast, bb, effort, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
@@ -681,18 +685,89 @@ def test_compress_multi_is_bit_identical_to_one_call(compressor, starfleet):
         c.close()
 
 
-def test_lds_exchange_executes_lanes_in_ascending_order(tmp_path):
-    """The chain efforts insert 64 positions with one ds_wrxchg_rtn_b32 and rely on the LDS executing the lanes of that
-    instruction in ascending lane order where they meet at one address (each lane gets the nearest lower lane with its
-    hash).  That is measured behaviour of gfx950, not an architectural promise: this guard runs the micro-test on the
-    device the suite runs on, so a part or a driver that orders them differently fails HERE and not as a wrong stream."""
+@pytest.mark.parametrize("effort", ["recent", "recent_all"])
+def test_effort_recent_bit_exact_vs_oracle(compressor, starfleet, effort):
+    """SFH_EFFORT_RECENT / _RECENT_ALL: the step tables with exact recency (the specification's `recent`: buckets {lo, hi}
+    filled in position order by ds_mskor_rtn_b32, the exact predecessor as the near candidate) -- bit-exact over inputs
+    whose buckets look very different (text, the reference's HTML file, mixed stripes, one value, short periods, noise,
+    real source text and machine code), strips from one chunk to 1 MiB, ragged tails, every strategy and lazy level, with
+    and without the stored fast path, and through the GPU decoder."""
+    from starflate_amd import realbytes
+
+    rng = np.random.default_rng(5)
+    text = synth.gen_text(44 * CHUNK + 77, seed=14)
+    cases = {"text": text, "starfleet": np.frombuffer(starfleet, np.uint8), "mixed": synth.gen_mixed(1 << 20, seed=4, stripe=1 << 15),
+             "zeros": np.zeros(5 * CHUNK + 333, np.uint8), "period7": np.tile(np.arange(7, dtype=np.uint8), 30000),
+             "period300": np.tile(rng.integers(0, 256, 300, dtype=np.uint8), 700), "random": rng.integers(0, 256, 3 * CHUNK + 5, dtype=np.uint8),
+             "low_entropy": rng.integers(0, 3, 2 * CHUNK + 99, dtype=np.uint8), "tiny": np.frombuffer(b"abcabcabcabcabcabc", np.uint8),
+             "empty": np.zeros(0, np.uint8), "three": np.frombuffer(b"xyz", np.uint8),
+             "noise_then_text": np.concatenate([rng.integers(0, 256, 3 * CHUNK, dtype=np.uint8), text[: 2 * CHUNK + 9]])}
+    src, binb = realbytes.source(3 << 20), realbytes.binary(18 << 20)
+    if src.size >= (2 << 20):
+        cases["source"] = src[: 2 << 20]
+    if binb.size >= (18 << 20):
+        cases["binary"] = binb[16 << 20: (16 << 20) + (1 << 20)]
+    for name, data in cases.items():
+        for bb in (0, 32768, 131072, 1 << 20):
+            got = np.frombuffer(compressor.compress(data, effort=effort, block_bytes=bb), np.uint8)
+            want = O.compress(data, O.default_params(strip_bytes=bb, **EFFORT_PARAMS[effort]))
+            assert got.size == want.size and np.array_equal(got, want), (name, bb, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
+            _roundtrip(got, data)
+        if name in ("text", "starfleet", "mixed", "source", "binary"):
+            assert len(compressor.compress(data, effort=effort)) < len(compressor.compress(data)), name
+    for strategy in ("fixed", "dynamic", "stored"):
+        for lazy in (0, 1, 3):
+            got = np.frombuffer(compressor.compress(text, effort=effort, strategy=strategy, lazy=lazy, stored_fast_path=False), np.uint8)
+            want = O.compress(text, O.default_params(strategy=_capi.STRATEGY[strategy], lazy=lazy, fast_skip=0, **EFFORT_PARAMS[effort]))
+            assert np.array_equal(got, want), (strategy, lazy)
+    got = compressor.compress(text, effort=effort)
+    back, st = compressor.decompress(got, compressor.last_index(), text.size, subindex=compressor.last_subindex(),
+                                     block_bytes=compressor.last_block_bytes())
+    assert st == 0 and back == text.tobytes()
+    o = _capi.make_options(effort=effort)
+    o.chain_depth = 4  # chain_depth belongs to the chain efforts
+    import ctypes as C
+    n_out = C.c_size_t(0)
+    buf = np.zeros(compressor.compress_bound(text.size), np.uint8)
+    assert compressor._lib.sfh_compress(compressor._h, text.ctypes.data, text.size, buf.ctypes.data, buf.size, C.byref(n_out), C.byref(o)) == -1
+
+
+def test_lds_atomics_execute_lanes_in_ascending_order(compressor):
+    """The chain efforts insert 64 positions with one ds_wrxchg_rtn_b32, SFH_EFFORT_RECENT with one ds_mskor_rtn_b32, and both
+    rely on the LDS executing the lanes of that instruction in ascending lane order where they meet at one address (each
+    lane gets the nearest lower lane with its hash), and one wave's instructions in issue order.  That is measured behaviour
+    of gfx950, not an architectural promise.  sfh_lds_order_check runs the kernel the library itself runs before the first
+    such call -- the match kernel's own pattern: partial exec masks, sixteen back-to-back instructions by one wave on shared
+    buckets, the other waves reading the table (and, op 1, storing into the buckets' other halves) meanwhile -- here at a
+    few hundred million positions on the device the suite runs on: a part or a driver that orders differently fails HERE."""
+    for op in (0, 1):
+        bad, n = compressor.lds_order_check(op, blocks=1024, iters=40)
+        assert bad == 0 and n > 150_000_000, (op, bad, n)
+
+
+def test_order_guard_refuses_the_efforts_that_need_it():
+    """SFH_FORCE_ORDER_FAIL=1 makes the library's own check (run once per context, before the first call with a chain effort
+    or SFH_EFFORT_RECENT) report failure: those efforts then return SFH_E_UNSUPPORTED with a message that says why, every
+    other effort works as ever, and nothing is written."""
     import os
-    import subprocess
 
-    from conftest import ROOT
+    from starflate_amd import Compressor
+    from starflate_amd.compressor import StarflateError
 
-    exe = tmp_path / "lds_xchg_order"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-Wno-unused-value",
-                           os.path.join(ROOT, "tools", "micro", "lds_xchg_order.hip"), "-o", str(exe)])
-    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0 and "ascending lane order holds" in out.stdout, out.stdout + out.stderr
+    text = synth.gen_text(3 * CHUNK, seed=3)
+    os.environ["SFH_FORCE_ORDER_FAIL"] = "1"
+    try:
+        c = Compressor(0)
+    finally:
+        del os.environ["SFH_FORCE_ORDER_FAIL"]
+    try:
+        for effort in ("best", "ultra", "extreme", "chain3", "recent", "recent_all"):
+            with pytest.raises(StarflateError) as e:
+                c.compress(text, effort=effort)
+            assert e.value.code == -7 and "ascending order" in str(e.value), (effort, str(e.value))
+        for effort in ("default", "fast", "thorough", "max"):
+            got = np.frombuffer(c.compress(text, effort=effort), np.uint8)
+            assert np.array_equal(got, O.compress(text, O.default_params(**EFFORT_PARAMS[effort])))
+        assert c.lds_order_check(0, 8, 2)[0] == 0  # (the exported check itself reports what the device does)
+    finally:
+        c.close()

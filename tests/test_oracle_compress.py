@@ -291,3 +291,145 @@ def test_hash_chains_are_exact_and_most_recent_first(starfleet):
         _check(s, whole)
         sizes.append(s.size)
     assert sizes[3] <= sizes[2] <= sizes[1] and sizes[2] < sizes[0]
+
+
+def test_recent_buckets_hold_exact_recency(starfleet):
+    """recent = 1 (SFH_EFFORT_RECENT / _RECENT_ALL): a position's candidates are its exact predecessor(s) with the same hash
+    -- near_depth of them as far as the links reach (link_steps steps, the current one included) -- plus the bucket's lo and
+    hi as they stood before its step: lo the latest earlier position with the hash, hi what lo was before the most recent
+    step that inserted the hash.  A brute-force model of exactly that must find the same match at every searched position,
+    for both search patterns; and the specification never compresses worse than the step tables it replaces."""
+    data = np.concatenate([np.frombuffer(starfleet, np.uint8)[:40000], np.zeros(3000, np.uint8), synth.gen_text(22536, seed=5)])
+    v = data.astype(np.uint32)
+    w = v[:-3] | (v[1:-2] << 8) | (v[2:-1] << 16) | (v[3:] << 24)
+    for kw in (dict(near_depth=1, link_steps=1), dict(near_depth=3, link_steps=2), dict(near_depth=1, link_steps=1, stride2=0, step=512),
+               dict(near_depth=2, link_steps=4, stride2=0, step=512)):
+        p = O.default_params(recent=1, strip_bytes=65536 * 2, chunk_bytes=32768, **kw)
+        W, R = p.step, p.region_bytes
+        h = ((w.astype(np.uint64) * 2654435761) & 0xFFFFFFFF) >> (32 - p.hash_bits)
+        n = data.size
+        # match_chunk treats its input as one strip: use a strip-sized prefix
+        strip = data[:65536]
+        ln, ds = O.match_chunk(strip, p)
+        n = strip.size
+        lo, hi, prev = {}, {}, {}
+        checked = 0
+        for s0 in range(0, n, W):
+            e = min(s0 + W, n)
+            pre = {}
+            for i in range(s0, e):
+                if i + 4 <= n:
+                    pre[i] = (lo.get(int(h[i])), hi.get(int(h[i])))
+            for i in range(s0, e):
+                if i + 4 <= n:
+                    hh = int(h[i])
+                    prev[i] = lo.get(hh)
+                    lo[hh] = i
+                    hi[hh] = pre[i][0]
+            ring_lo = max(0, (s0 // W + 1 - p.link_steps) * W)
+            for i in range(s0, e, 1):
+                if (p.stride2 and i % 2) or i + 4 > n or i % 5:
+                    continue
+                cands, c, k = [], prev[i], 0
+                while k < p.near_depth and c is not None:
+                    cands.append(c)
+                    k += 1
+                    if c < ring_lo:
+                        break
+                    c = prev[c]
+                cands += [x for x in pre[i] if x is not None]
+                maxlen = min(n - i, 258, (i // R + 1) * R - i, p.cap)
+                best, bd = 0, 0
+                for c in cands:
+                    if i - c > 32768:
+                        continue
+                    l = 0
+                    while l < maxlen and strip[i + l] == strip[c + l]:
+                        l += 1
+                    r = min(l, p.rank_bytes)
+                    if r > best or (r == best and r and i - c < bd):
+                        best, bd = r, i - c
+                if best == p.rank_bytes:
+                    l, c = 0, i - bd
+                    while l < maxlen and strip[i + l] == strip[c + l]:
+                        l += 1
+                    best = l
+                if best == 4 and bd > p.far4_dist:
+                    best = 0
+                if best >= 4:
+                    assert (int(ln[i]), int(ds[i])) == (best, bd), (kw, i)
+                else:
+                    assert ln[i] == 0, (kw, i)
+                checked += 1
+        assert checked > 5000
+    whole = np.frombuffer(starfleet, np.uint8)
+    base = O.compress(whole, O.default_params()).size
+    for kw in (dict(near_depth=1, link_steps=1), dict(near_depth=1, link_steps=1, stride2=0, step=512)):
+        s = O.compress(whole, O.default_params(recent=1, **kw))
+        _check(s, whole)
+        assert s.size < base
+
+
+def test_short_probe_behind_a_skipped_block():
+    """Stored fast path, round 5: the block behind a block that took the fast path is searched on its first SFO_SKIP_PROBE
+    positions only.  High-entropy data stays stored; a strip that turns compressible again is still coded (its first
+    block after the noise loses the matches of the unsearched part of the probe span, nothing else), and everything
+    round-trips."""
+    rng = np.random.default_rng(8)
+    rnd = rng.integers(0, 256, 6 * CHUNK, dtype=np.uint8)
+    text = synth.gen_text(4 * CHUNK, seed=9)
+    for bb in (0, 4 * CHUNK, 16 * CHUNK):
+        s = O.compress(rnd, O.default_params(strip_bytes=bb))
+        assert s.size == rnd.size + 5 * 6
+        _check(s, rnd)
+        mix = np.concatenate([rnd[: 3 * CHUNK], text, rnd[3 * CHUNK:]])
+        on, off = O.compress(mix, O.default_params(strip_bytes=bb)), O.compress(mix, O.default_params(strip_bytes=bb, fast_skip=0))
+        _check(on, mix)
+        assert on.size <= off.size + 3000  # the fast path costs a probe span's worth of matches at most
+    # the tokens of a block behind a skipped one: matches only inside the first SFO_SKIP_PROBE positions of its probe span
+    two = np.concatenate([rnd[:CHUNK], np.tile(text[:4096], 8)])
+    toks, nt = O.strip_tokens(two, O.default_params(strip_bytes=2 * CHUNK))
+    R = 512
+    for r in range(CHUNK // R, 2 * CHUNK // R):
+        t = toks[r * R: r * R + nt[r]]
+        if 2048 <= r * R - CHUNK < 8192:
+            assert not np.any(t & 0x80000000), r  # unsearched part of the probe span: literals
+    assert np.any(toks[(CHUNK + 8192) // R * R:] & 0x80000000)  # the rest of the block is searched again
+
+
+def test_plan_stores_all_but_incompressible_chunks_without_a_code():
+    """sfo_plan_chunk, round 5: when the fixed block is no shorter than the stored one and the integer entropy estimate of
+    the dynamic block comes within SFO_STORE_MARGIN (64) bytes of it, the chunk is stored and no code is built.  The rule
+    may give up at most that margin against the exact choice, fires on high-entropy chunks, and leaves every chunk that
+    compresses alone."""
+    rng = np.random.default_rng(12)
+    p, p_dyn = O.default_params(), O.default_params(strategy=3)
+    fired = 0
+    for kind in range(40):
+        if kind < 10:
+            data = rng.integers(0, 256, CHUNK, dtype=np.uint8)                       # noise
+        elif kind < 20:
+            data = rng.integers(0, 256 - 4 * (kind - 9), CHUNK, dtype=np.uint8)      # a slightly smaller alphabet: near the margin
+        elif kind < 30:
+            data = rng.integers(0, 64, CHUNK, dtype=np.uint8)                        # six bits per byte: compresses, no matches
+        else:
+            data = synth.gen_text(CHUNK, seed=kind)
+        ll = np.bincount(data, minlength=286).astype(np.uint32)
+        ll[256] = 1
+        d = np.zeros(30, np.uint32)
+        auto, dyn = O.plan_chunk(ll, d, CHUNK, False, p), O.plan_chunk(ll, d, CHUNK, False, p_dyn)
+        if auto.btype == 0:
+            assert auto.out_bytes == CHUNK + 5 and not any(auto.ll_lens)
+            assert dyn.out_bytes + 64 >= auto.out_bytes, kind   # the margin is all the rule can cost
+            fired += kind < 20
+        else:
+            assert auto.btype == 2 and auto.out_bytes == dyn.out_bytes and auto.out_bytes < CHUNK + 5, kind
+        if kind < 10:
+            assert auto.btype == 0, kind
+        if kind >= 20:
+            assert auto.btype == 2, kind
+    assert fired >= 10
+    whole = rng.integers(0, 256, 3 * CHUNK + 100, dtype=np.uint8)
+    s = O.compress(whole)
+    assert s.size == whole.size + 5 * 4
+    _check(s, whole)

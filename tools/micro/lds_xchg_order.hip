@@ -1,9 +1,13 @@
 // micro-test: in which order does the LDS execute the lanes of ONE ds_wrxchg_rtn_b32 wave-instruction when several lanes hit
 // the same address?  If it is ascending lane order, `old = exchange(&T[h], lane)` hands every lane the nearest LOWER lane
 // with the same address (or what the slot held before) -- an exact "previous occurrence" in one instruction, which is what
-// a hash-chain insertion of 64 consecutive positions needs.  Also checked: two such instructions issued
-// back to back by one wave (in-order), a second wave's instruction after a barrier, and ds_max_rtn_u32 for comparison.
-// Reports mismatches against the sequential-lane-order model over many random address patterns, on every CU.
+// a hash-chain insertion of 64 consecutive positions needs.
+// What this file checks: ONE full-exec exchange per wave on a table private to the wave, over many random address patterns
+// and collision densities, on every CU.  The check that mirrors the match kernels' real pattern -- partial exec masks,
+// sixteen back-to-back instructions by one wave on buckets all slices share, the other waves reading (and, for
+// ds_mskor_rtn_b32, storing into the other halves of) the same buckets meanwhile -- is the library's own
+// starflate_amd/csrc/sf_guard.hip (sfh_lds_order_check; run per context before the first call that needs it, and by
+// tests/test_gpu_parity.py at a few hundred million positions).  This file stays as the minimal stand-alone reproducer.
 // build: hipcc -O3 --offload-arch=gfx950 tools/micro/lds_xchg_order.hip -o tools/micro/lds_xchg_order
 #include <hip/hip_runtime.h>
 #include <stdint.h>
