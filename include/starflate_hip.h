@@ -175,7 +175,14 @@ int sfh_compress_multi(sfh_ctx* const* ctxs, int nctx, const void* src, size_t n
  * `stream`, which is synchronised once, for the sizes; the call returns with the transfers in flight.  *out_end (every
  * rank) = end of the concatenation.  d_out is only read on the root; `base` and `cap` (the root's: bytes already in d_out,
  * its capacity) are passed alike by every rank, so that all ranks refuse together -- before anything is posted -- when the
- * streams do not fit. */
+ * streams do not fit.  The exchange carries, beside the size, every rank's base and cap and the root's d_stream / d_out
+ * addresses (five u64 per rank): ranks that DISAGREE on base or cap, and a root whose d_stream overlaps the gathered range
+ * of d_out without lying exactly at its own place there (a peer's bytes would land on it, or it would be copied onto
+ * itself), are SFH_E_INVALID_ARG on EVERY rank alike, still before anything is posted.
+ * Contract for what the library cannot see: a failure that strikes ONE rank after the exchange -- the read-back or the
+ * stream synchronisation failing, ncclSend / ncclRecv returning an error -- returns on that rank only; its peers are then
+ * inside a grouped transfer that cannot complete.  The communicator is broken at that point (as after any failed RCCL
+ * call): abort it (ncclCommAbort) on all ranks and build a new one. */
 int sfh_gather_offsets(const uint64_t* sizes, int nranks, uint64_t base, uint64_t cap, uint64_t* offsets);
 /* ranks of the communicator and this process's rank in it (ncclCommCount / ncclCommUserRank through the same binding) */
 int sfh_comm_ranks(void* nccl_comm, int* nranks, int* rank);

@@ -7,6 +7,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 # SFH_LIB=<path>: another build of the library (kernel experiments side by side: tools/exp/variants.sh)
 LIB_PATH = os.environ.get("SFH_LIB") or os.path.join(PKG_DIR, "libstarflate_hip.so")
 SOURCES = ["sf_kernels.hip", "sf_checksum.hip", "sf_inflate.hip", "sf_guard.hip", "sf_capi.hip"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror"]
 HEADERS = [os.path.join(CSRC, "sf_device.h"), os.path.join(CSRC, "sf_inflate_core.h"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "starflate_hip.h")]
 
@@ -30,8 +31,7 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into starflate_amd/libstarflate_hip.so."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-Wall", "-Wextra", "-Werror"]
+    cmd = [hipcc()] + FLAGS
     cmd += os.environ.get("SF_HIPCC_FLAGS", "").split()
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH + ".tmp"]
@@ -42,14 +42,11 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
-if __name__ == "__main__":
-    print(build(force=True, verbose=True))
-
-
 def source_stamp():
     """What ties a measurement to the code it measured: the commit (git here; on a GPU box, which has no .git, the
     `.commit_stamp` file the post-commit hook / tools/stamp_commit.sh leaves at the repo root) and a SHA-256 over the
-    kernel sources and the C-ABI header -- the same on both sides whatever the commit is called."""
+    kernel sources, the C-ABI header and the compiler flags of build() (SF_HIPCC_FLAGS of a variant build included) -- the same
+    on both sides whatever the commit is called.  (The ROCm version is the image's, the same here and on the GPU box.)"""
     import hashlib
 
     root = os.path.dirname(PKG_DIR)
@@ -60,6 +57,7 @@ def source_stamp():
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             h.update(fh.read())
+    h.update(" ".join(FLAGS + os.environ.get("SF_HIPCC_FLAGS", "").split()).encode())
     commit, dirty = None, None
     try:
         commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
@@ -72,3 +70,7 @@ def source_stamp():
         except OSError:
             pass
     return {"commit": commit or "unknown", "dirty": dirty, "csrc_sha256": h.hexdigest()[:16]}
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

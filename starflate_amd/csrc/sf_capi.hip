@@ -830,32 +830,57 @@ int sfh_gather_streams(sfh_ctx* ctx, void* nccl_comm, int root, const void* d_st
   if (root < 0 || root >= nranks || (rank == root && !d_out)) return fail(ctx, SFH_E_INVALID_ARG, "root / d_out", hipSuccess);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  // Every rank contributes {size, base, cap, its d_stream, its d_out}: sizes are what is gathered; base and cap must be the
+  // same on all ranks, and the root's two addresses let EVERY rank judge the root's own placement -- so every rank reaches
+  // the same verdict BEFORE any transfer is posted, and nobody is left waiting in a send whose receive was refused.
+  constexpr int kRec = 5;
   if (ctx->sizes_cap < nranks) {
     (void)hipFree(ctx->d_sizes);
     (void)hipHostFree(ctx->h_sizes);
     ctx->d_sizes = ctx->h_sizes = nullptr;
     ctx->sizes_cap = 0;
-    SF_HIP(hipMalloc(&ctx->d_sizes, (size_t)nranks * sizeof(uint64_t)), "sizes");
-    SF_HIP(hipHostMalloc((void**)&ctx->h_sizes, (size_t)nranks * sizeof(uint64_t), hipHostMallocDefault), "pinned sizes");
+    SF_HIP(hipMalloc(&ctx->d_sizes, ((size_t)nranks + 1) * kRec * sizeof(uint64_t)), "sizes");
+    SF_HIP(hipHostMalloc((void**)&ctx->h_sizes, ((size_t)nranks + 1) * kRec * sizeof(uint64_t), hipHostMallocDefault), "pinned sizes");
     ctx->sizes_cap = nranks;
   }
+  uint64_t* const d_mine = ctx->d_sizes + (size_t)nranks * kRec;  // this rank's record, behind the gathered ones
+  uint64_t* const h_mine = ctx->h_sizes + (size_t)nranks * kRec;
+  h_mine[1] = base;
+  h_mine[2] = cap;
+  h_mine[3] = (uint64_t)(uintptr_t)d_stream;
+  h_mine[4] = (uint64_t)(uintptr_t)d_out;
   // the compressor may have run on another stream of this ctx: its size word is final behind ev_done
   rc = order_behind_last_call(ctx, s);
   if (rc) return rc;
-  if ((rc = R.AllGather(d_size, ctx->d_sizes, 1, kNcclUint64, nccl_comm, s)) != 0) return comm_fail(ctx, "ncclAllGather", rc);
-  SF_HIP(hipMemcpyAsync(ctx->h_sizes, ctx->d_sizes, (size_t)nranks * sizeof(uint64_t), hipMemcpyDeviceToHost, s), "sizes read-back");
+  SF_HIP(hipMemcpyAsync(d_mine + 1, h_mine + 1, (kRec - 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s), "record");
+  SF_HIP(hipMemcpyAsync(d_mine, d_size, sizeof(uint64_t), hipMemcpyDeviceToDevice, s), "size word");
+  if ((rc = R.AllGather(d_mine, ctx->d_sizes, kRec, kNcclUint64, nccl_comm, s)) != 0) return comm_fail(ctx, "ncclAllGather", rc);
+  SF_HIP(hipMemcpyAsync(ctx->h_sizes, ctx->d_sizes, (size_t)nranks * kRec * sizeof(uint64_t), hipMemcpyDeviceToHost, s), "sizes read-back");
   SF_HIP(hipStreamSynchronize(s), "stream sync");
   // (no exception may cross the C boundary: the offsets live in a nothrow allocation)
   struct Free { void operator()(uint64_t* p) const { free(p); } };
   const std::unique_ptr<uint64_t, Free> off_mem((uint64_t*)malloc(((size_t)nranks + 1) * sizeof(uint64_t)));
   if (!off_mem) return fail(ctx, SFH_E_NOMEM, "sfh_gather_streams: offsets", hipSuccess);
   uint64_t* const off = off_mem.get();
-  for (int r = 0; r < nranks; ++r) h_sizes[r] = ctx->h_sizes[r];
-  // every rank judges the same numbers (base and cap are the root's, passed alike by all), so every rank returns the same
-  // verdict BEFORE any transfer is posted: nobody is left waiting in a send whose receive was refused
+  bool agree = true;
+  for (int r = 0; r < nranks; ++r) {
+    const uint64_t* rec = ctx->h_sizes + (size_t)r * kRec;
+    h_sizes[r] = rec[0];
+    agree = agree && rec[1] == base && rec[2] == cap;
+  }
+  if (!agree) return fail(ctx, SFH_E_INVALID_ARG, "sfh_gather_streams: the ranks disagree on base / cap", hipSuccess);  // (on every rank alike)
   rc = sfh_gather_offsets(h_sizes, nranks, base, cap, off);
   *out_end = off[(size_t)nranks];
   if (rc != SFH_OK) return fail(ctx, rc, "sfh_gather_streams: the gathered streams do not fit cap", hipSuccess);
+  {
+    // the root's own stream: already at its place in d_out, or clear of everything the gather writes -- anything between
+    // would be overwritten by a peer's bytes or copied onto itself
+    const uint64_t* rr = ctx->h_sizes + (size_t)root * kRec;
+    const uint64_t rs = rr[3], ro = rr[4], rn = rr[0];
+    const uint64_t w0 = ro + base, w1 = ro + off[(size_t)nranks];
+    if (rn && rs != ro + off[(size_t)root] && rs < w1 && rs + rn > w0)
+      return fail(ctx, SFH_E_INVALID_ARG, "sfh_gather_streams: the root's d_stream overlaps the gathered range of d_out without being at its own place", hipSuccess);
+  }
   if (rank != root) {
     if (h_sizes[rank] && (rc = R.Send(d_stream, (size_t)h_sizes[rank], kNcclUint8, root, nccl_comm, s)) != 0) return comm_fail(ctx, "ncclSend", rc);
     return SFH_OK;

@@ -1881,28 +1881,8 @@ __device__ __forceinline__ void match_bits(uint32_t l3, uint32_t d1, const uint3
   nb = p;
 }
 
-// Items [i0, i0 + 8) and the item before them for a chunk whose items behind the first n0 were never written (stored fast
-// path: they are the bytes of the chunk's positions from kSkipSpan on, the first of every 1024 flagged as k_lz77 flags
-// it).  Out of line: it runs for the rare chunk that took the fast path and is NOT stored, and must not cost the common
-// path registers.
-__device__ __attribute__((noinline)) void emit_tail_items(const uint16_t* it, const uint8_t* chunk_src, uint32_t n0, uint32_t nit, uint32_t i0,
-                                                          uint4& q, uint32_t& before) {
-  auto item_of = [&](uint32_t idx) -> uint32_t {
-    if (idx >= nit) return 0u;
-    if (idx < n0) return it[idx];
-    const uint32_t pos = kSkipSpan + (idx - n0);
-    const uint32_t b = chunk_src[pos];
-    return (pos & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((pos / kSubBytes) << 8)) : b;
-  };
-  q.x = item_of(i0) | (item_of(i0 + 1) << 16);
-  q.y = item_of(i0 + 2) | (item_of(i0 + 3) << 16);
-  q.z = item_of(i0 + 4) | (item_of(i0 + 5) << 16);
-  q.w = item_of(i0 + 6) | (item_of(i0 + 7) << 16);
-  before = i0 ? item_of(i0 - 1) : 0u;
-}
-
 __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restrict__ src, uint64_t n_total,
-                                                     uint32_t /*nchunks*/, const uint16_t* __restrict__ items,
+                                                     uint32_t /*nchunks*/, uint16_t* items,
                                                      const uint32_t* __restrict__ nitems_in,
                                                      const uint32_t* __restrict__ ntok_in,
                                                      const ChunkPlan* __restrict__ plan,
@@ -1950,6 +1930,39 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
     }
     uint8_t* d = o + 5;
     const uint8_t* sp = src + cbase;  // 32 KiB aligned
+    if (n_raw >= 64) {
+      // 16 bytes per thread and step: destination blocks aligned (bytes up to the first one singly), every block from
+      // the two aligned source blocks it straddles -- the same byte shift for the whole chunk (uniform), so the dword it
+      // starts in is a four-way branch and the rest one v_alignbyte per dword.  The blocks whose second source block
+      // would reach past the chunk, and the bytes behind them, go singly at the end (fewer than 48)
+      const uint32_t head16 = (uint32_t)((16 - ((uintptr_t)d & 15)) & 15);
+      if (t < head16) d[t] = sp[t];
+      const uint32_t sft = head16 & 15u, wsel = sft >> 2, bs = sft & 3u;   // (uniform) source offset of a block mod 16
+      const uint32_t nvec = (n_raw - head16) / 16 - (sft ? 1u : 0u);       // blocks whose two source blocks lie inside the chunk
+      const uint4* s4 = reinterpret_cast<const uint4*>(sp);
+      uint4* d4 = reinterpret_cast<uint4*>(d + head16);
+      for (uint32_t k = t; k < nvec; k += K4_THREADS) {
+        const uint4 A = s4[k + (head16 >> 4)], B = sft ? s4[k + (head16 >> 4) + 1] : make_uint4(0, 0, 0, 0);
+        uint4 r;
+        if (wsel == 0) {
+          r.x = __builtin_amdgcn_alignbyte(A.y, A.x, bs); r.y = __builtin_amdgcn_alignbyte(A.z, A.y, bs);
+          r.z = __builtin_amdgcn_alignbyte(A.w, A.z, bs); r.w = __builtin_amdgcn_alignbyte(B.x, A.w, bs);
+        } else if (wsel == 1) {
+          r.x = __builtin_amdgcn_alignbyte(A.z, A.y, bs); r.y = __builtin_amdgcn_alignbyte(A.w, A.z, bs);
+          r.z = __builtin_amdgcn_alignbyte(B.x, A.w, bs); r.w = __builtin_amdgcn_alignbyte(B.y, B.x, bs);
+        } else if (wsel == 2) {
+          r.x = __builtin_amdgcn_alignbyte(A.w, A.z, bs); r.y = __builtin_amdgcn_alignbyte(B.x, A.w, bs);
+          r.z = __builtin_amdgcn_alignbyte(B.y, B.x, bs); r.w = __builtin_amdgcn_alignbyte(B.z, B.y, bs);
+        } else {
+          r.x = __builtin_amdgcn_alignbyte(B.x, A.w, bs); r.y = __builtin_amdgcn_alignbyte(B.y, B.x, bs);
+          r.z = __builtin_amdgcn_alignbyte(B.z, B.y, bs); r.w = __builtin_amdgcn_alignbyte(B.w, B.z, bs);
+        }
+        d4[k] = r;
+      }
+      const uint32_t done16 = head16 + 16 * nvec;
+      if (t < n_raw - done16) d[done16 + t] = sp[done16 + t];
+      return;
+    }
     const uint32_t head = (uint32_t)((4 - ((uintptr_t)d & 3)) & 3);
     const uint32_t h = head < n_raw ? head : n_raw;
     if (t < h) d[t] = sp[t];
@@ -2000,10 +2013,20 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
   const uint32_t ntok = pre_ntok;
   const uint32_t nit = pre_nit & ~kItemsSkipped;
   // stored fast path: the items behind the chunk's first kSkipSpan positions were never written -- they are those
-  // positions' bytes (every position a literal), taken from the input here.  n0: the items that were written
-  const bool tail = (pre_nit & kItemsSkipped) != 0;  // (uniform)
-  const uint32_t n0 = tail ? nit - (n_raw - kSkipSpan) : nit;
+  // positions' bytes (every position a literal), taken from the input here
   const uint16_t* it = items + (uint64_t)chunk * kChunk;
+  if (pre_nit & kItemsSkipped) {  // (uniform; rare: a chunk that took the fast path and is NOT stored)
+    // write them now, into the chunk's own item slots, and go on as for any chunk
+    const uint32_t n0 = nit - (n_raw - kSkipSpan);
+    uint16_t* const wr = items + (uint64_t)chunk * kChunk;
+    for (uint32_t idx = n0 + t; idx < nit; idx += K4_THREADS) {
+      const uint32_t pos = kSkipSpan + (idx - n0);
+      const uint32_t b = src[cbase + pos];
+      wr[idx] = (uint16_t)((pos & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((pos / kSubBytes) << 8)) : b);
+    }
+    __threadfence_block();
+    __syncthreads();  // (the stores have completed: every thread reads its items from memory below)
+  }
   uint32_t running = 8 * sh + P.header_bits;
   uint32_t buf = 0;
   // items in batches of K4_THREADS*8 (one 16-byte load per thread); the next batch is in flight while this
@@ -2011,10 +2034,6 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
   // neighbour's last -- over the DPP network, only a wave's first lane goes to memory.
   // (reads past nit stay inside the chunk's kChunk-slot item area; they are masked below)
   auto load_batch = [&](uint32_t i0, uint4& q, uint32_t& before) {
-    if (tail) {  // (the rare path, kept out of line: a chunk that took the fast path and is not stored)
-      emit_tail_items(it, src + cbase, n0, nit, i0, q, before);
-      return;
-    }
     q = *reinterpret_cast<const uint4*>(it + i0);
     before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q.w >> 16), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
     if (lane == 0) before = i0 ? it[i0 - 1] : 0u;

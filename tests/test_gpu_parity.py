@@ -251,12 +251,23 @@ def test_stored_fast_path(compressor):
     rng = np.random.default_rng(21)
     rnd = rng.integers(0, 256, 5 * CHUNK + 999, dtype=np.uint8)
     head_then_zeros = np.concatenate([rnd[:9000], np.zeros(3 * CHUNK, np.uint8)])
-    for data in (rnd, head_then_zeros, synth.gen_mixed(1 << 20, seed=4, stripe=1 << 15)):
+    # six bits of entropy per byte and no matches: the fast path fires, yet a dynamic block wins -- k_emit then takes the
+    # items behind the first 8 KiB from the input itself (k_lz77 never wrote them); with a compressible stretch in between
+    base64ish = rng.integers(0, 64, 7 * CHUNK + 4321, dtype=np.uint8)
+    turns = np.concatenate([base64ish[: 3 * CHUNK], synth.gen_text(2 * CHUNK + 100, seed=31), base64ish[3 * CHUNK:], rnd[: 2 * CHUNK]])
+    for data in (rnd, head_then_zeros, synth.gen_mixed(1 << 20, seed=4, stripe=1 << 15), base64ish, turns):
         for on in (True, False):
-            got = np.frombuffer(compressor.compress(data, stored_fast_path=on), np.uint8)
-            want = O.compress(data, O.default_params(fast_skip=int(on)))
-            assert np.array_equal(got, want)
-            _roundtrip(got, data)
+            for bb in (0, 4 * CHUNK):
+                got = np.frombuffer(compressor.compress(data, stored_fast_path=on, block_bytes=bb), np.uint8)
+                want = O.compress(data, O.default_params(fast_skip=int(on), strip_bytes=bb))
+                assert np.array_equal(got, want)
+                _roundtrip(got, data)
+    got = compressor.compress(turns, strategy="dynamic")  # (every chunk a Huffman block: the fast path's chunks included)
+    assert np.array_equal(np.frombuffer(got, np.uint8), O.compress(turns, O.default_params(strategy=3)))
+    back, st = compressor.decompress(got, compressor.last_index(), turns.size, subindex=compressor.last_subindex(),
+                                     block_bytes=compressor.last_block_bytes())
+    assert st == 0 and back == turns.tobytes()
+    assert len(compressor.compress(base64ish)) < 0.8 * base64ish.size
     assert len(compressor.compress(rnd)) == rnd.size + 5 * 6  # six stored blocks
     # a skipped block is not inserted into the hash tables either: the next block of the strip sees none of it
     two = np.concatenate([rnd[:CHUNK], rnd[:CHUNK]])
