@@ -63,8 +63,10 @@ typedef struct sfh_options {
                             that is not the last one) */
   uint32_t lazy;         /* 0..3: lazy match deferral, positions of look-ahead (default 3) */
   uint32_t no_stored_fast_path; /* 0 (default): a 32 KiB chunk whose first 8 KiB parse to (almost) only
-                            literals is not searched further (high-entropy data -> stored blocks at a
-                            quarter of the match work); 1: always search the whole chunk */
+                            literals is not searched further and is coded as literals throughout (high-entropy
+                            data -> stored blocks); the chunk behind it in its strip is probed on its first
+                            2 KiB only (a sixteenth of the match work while the data stays like that);
+                            1: always search the whole chunk */
   uint32_t container;    /* enum sfh_container; SFH_ZLIB / SFH_GZIP need final_stream = 1.  The checksum is
                             computed on the GPU from the same device buffer (two more launches) */
   uint32_t block_bytes;  /* bytes of input coded independently of what precedes them (a "strip"): a multiple of
@@ -87,7 +89,15 @@ typedef struct sfh_options {
                             structure (every position inserted and searched, the 8 / 16 / 32 most recent positions with
                             its hash tried, nearest first): what closes the gap to zlib -6 on real data, where recency
                             counts for more than on the synthetic text, at a quarter to a tenth of the default's speed;
-                            EXTREME is zlib -6's own ratio on the text workload */
+                            EXTREME is zlib -6's own ratio on the text workload.
+                            SFH_EFFORT_RECENT / SFH_EFFORT_RECENT_ALL keep the step tables' search pattern (every other
+                            position / every position, three candidates each) but fill the buckets in POSITION ORDER:
+                            a bucket holds the latest position with the hash and the one before the latest inserting
+                            step, and a position's third candidate is its exact predecessor -- the nearest earlier
+                            position with its hash, inside the step or before it.  RECENT is the default's pattern
+                            (about thorough's ratio on real data); RECENT_ALL is thorough's (on real bytes max's ratio
+                            or better -- machine code +3 points -- for a tenth less time).  Both rest on the LDS
+                            executing the lanes of one returning atomic in ascending order (sfh_lds_order_check) */
   uint32_t chain_depth;  /* 0: what the effort implies.  With a chain effort (SFH_EFFORT_BEST / _ULTRA / _EXTREME) any depth
                             1..255 -- candidates per position, most recent first (the specification's chain_depth): 4 is
                             SFH_EFFORT_MAX's ratio on text and the chains' on real data at 80 K MiB/s.  Must be 0 with the

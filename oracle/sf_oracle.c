@@ -730,7 +730,7 @@ static uint32_t parse_regions(const uint8_t* data, uint32_t n, const sfo_params*
  * window carry over from block to block.
  * Stored fast path: when the first SFO_SKIP_SPAN positions of a block parse to (almost) nothing but
  * literals -- at least SFO_SKIP_SPAN - SFO_SKIP_SLACK tokens -- the rest of the block is neither
- * searched nor inserted into the tables: every later position is emitted as a literal.  (High-entropy
+ * searched nor inserted into the tables, and EVERY position of the block is emitted as a literal.  (High-entropy
  * data then costs a quarter of the match work and ends up in a stored block.)  Round 5: the block BEHIND such a block
  * in its strip is probed on SFO_SKIP_PROBE positions only (a sixteenth of the match work while the data stays
  * high-entropy).
@@ -762,6 +762,8 @@ int sfo_strip_tokens(const uint8_t* src, uint32_t n, const sfo_params* p, uint32
     match_steps(&m, s0, s0 + probe / W);
     const uint32_t head = parse_regions(m.d, n, p, m.len16, m.dist16, r0, rh, 0, tokens, ntok);
     const int skip = head >= SFO_SKIP_SPAN - SFO_SKIP_SLACK;
+    /* (round 5) the WHOLE block is literals then, the probe span included: its few matches are dropped */
+    if (skip) parse_regions(m.d, n, p, m.len16, m.dist16, r0, rh, 1, tokens, ntok);
     if (!skip) match_steps(&m, sh, s1);
     parse_regions(m.d, n, p, m.len16, m.dist16, rh, r1, skip, tokens, ntok);
     prev_skipped = skip;
@@ -796,7 +798,9 @@ void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
   }
   const uint32_t rh = SFO_SKIP_SPAN / R;
   const uint32_t head = parse_regions(data, n, p, len16, dist16, 0, rh, 0, tokens, ntok);
-  parse_regions(data, n, p, len16, dist16, rh, nreg, head >= SFO_SKIP_SPAN - SFO_SKIP_SLACK, tokens, ntok);
+  const int skip = head >= SFO_SKIP_SPAN - SFO_SKIP_SLACK;
+  if (skip) parse_regions(data, n, p, len16, dist16, 0, rh, 1, tokens, ntok);
+  parse_regions(data, n, p, len16, dist16, rh, nreg, skip, tokens, ntok);
 }
 
 static inline uint32_t len_symbol(uint32_t len) { /* 3..258 -> 257..285 */

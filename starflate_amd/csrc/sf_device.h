@@ -37,8 +37,8 @@ constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kFar4 = 4096;        // a match of exactly 4 bytes beyond this distance is not used
 constexpr uint32_t kSkipSlack = 128;    // stored fast path: first 8 KiB with >= 8192-128 tokens => no further search
 constexpr uint32_t kSkipProbe = 2048;   // ... and behind such a chunk in its strip only this many positions of the 8 KiB are searched
-constexpr uint32_t kItemsSkipped = 0x80000000u;  // nitems[chunk]: the items behind the first 8 KiB were not written -- they are the
-                                                 // chunk's own bytes (stored fast path); k_emit takes them from the input
+constexpr uint32_t kItemsSkipped = 0x80000000u;  // nitems[chunk]: the items were not written -- they are the chunk's own bytes
+                                                 // (stored fast path: every position a literal); k_emit takes them from the input
 constexpr uint32_t kSubRegions = kChunk / kSubBytes;  // 32 sub-index entries per chunk
 constexpr uint32_t kTokMatch = 0x80000000u;  // decoder token (k_inflate_*): bit31 match, 16..23 len-3, 0..14 dist-1
 constexpr uint32_t kTokRegion = 0x40000000u; // decoder token: first token of a parse region, region index in 24..28

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       short_probe = skip && fast_skip && (n - cstart) > kSkipSpan;  // (skip: still the previous chunk's)
       tot_tok = 0; tot_items = 0; skip = false;
     }
-    if (rc == kSkipSpan / kRound) skip = fast_skip && (n - cstart) > kSkipSpan && tot_tok >= kSkipSpan - kSkipSlack;
+    // (the stored fast path is decided at the end of a chunk's first round, behind its parse: skip_now below)
 
     // RECENT: the histogram's place holds the match phase's posts; its counts wait here meanwhile
     [[maybe_unused]] uint32_t hsave = 0;
@@ -1208,12 +1208,27 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         rtotal = (uint32_t)__builtin_amdgcn_readlane((int)wi, K1_WAVES - 1);
         wbase = (uint32_t)__builtin_amdgcn_readlane((int)(wi - w), (int)wave);
       }
+      // Stored fast path, decided HERE (uniform), as soon as the probe span's token count is known: nearly all literals ->
+      // the WHOLE chunk is literals, this round included (its few matches are dropped: such a chunk is stored anyway, or
+      // a Huffman block of literals).  Nothing of it is written: an item IS the position's byte, and k_emit takes the
+      // items from the input in the rare case that the chunk is not stored (kItemsSkipped in nitems)
+      static_assert(kSkipSpan == kRound, "the probe span is the chunk's first round");
+      const bool skip_now = rc == 0 && fast_skip && (n - cstart) > kSkipSpan && (rtotal & 0xFFFFu) >= kSkipSpan - kSkipSlack;
       // tokens before each 1024-byte sub-index region (two waves): where the decoder's region lanes start
-      if ((wave & (kSubBytes / kRegion - 1)) == 0 && lane == 0)
+      if (!skip_now && (wave & (kSubBytes / kRegion - 1)) == 0 && lane == 0)
         rtok_out[chunk * kSubRegions + rc * kRSubs + wave / (kSubBytes / kRegion)] = tot_tok + (wbase & 0xFFFFu);
       stamp(4);
       __builtin_amdgcn_s_setprio(0);  // emit, flush and the next round's stage: nothing waits for them
 
+      if (skip_now) {
+        // (qn == kRound here: the chunk is longer than the span)
+        const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + 8 * t]);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) atomicAdd(&s_hist[((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu], 1u);
+        if (t < kRSubs) rtok_out[chunk * kSubRegions + t] = t * kSubBytes;
+        skip = true;
+        rtotal = kRound;  // tokens = items = positions
+      } else
       // ---- emit: the lane's chain positions -> items (compact, chunk order) + histogram ----
       if (marks) {
         const uint32_t before = wbase + incl - mine;
@@ -2012,17 +2027,15 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
 
   const uint32_t ntok = pre_ntok;
   const uint32_t nit = pre_nit & ~kItemsSkipped;
-  // stored fast path: the items behind the chunk's first kSkipSpan positions were never written -- they are those
-  // positions' bytes (every position a literal), taken from the input here
+  // stored fast path: the chunk's items were never written -- they are its bytes (every position a literal), taken from
+  // the input here
   const uint16_t* it = items + (uint64_t)chunk * kChunk;
   if (pre_nit & kItemsSkipped) {  // (uniform; rare: a chunk that took the fast path and is NOT stored)
-    // write them now, into the chunk's own item slots, and go on as for any chunk
-    const uint32_t n0 = nit - (n_raw - kSkipSpan);
+    // write them now, into the chunk's own item slots, and go on as for any chunk (nit == n_raw: every position a literal)
     uint16_t* const wr = items + (uint64_t)chunk * kChunk;
-    for (uint32_t idx = n0 + t; idx < nit; idx += K4_THREADS) {
-      const uint32_t pos = kSkipSpan + (idx - n0);
+    for (uint32_t pos = t; pos < nit; pos += K4_THREADS) {
       const uint32_t b = src[cbase + pos];
-      wr[idx] = (uint16_t)((pos & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((pos / kSubBytes) << 8)) : b);
+      wr[pos] = (uint16_t)((pos & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((pos / kSubBytes) << 8)) : b);
     }
     __threadfence_block();
     __syncthreads();  // (the stores have completed: every thread reads its items from memory below)

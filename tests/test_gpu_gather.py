@@ -67,6 +67,20 @@ def test_gather_streams_one_rank_communicator(compressor):
         rc = lib.sfh_gather_streams(compressor._h, comm, 0, shard.data_ptr(), size.data_ptr(), out.data_ptr(), base, base + n - 1,
                                     h_sizes, C.byref(end), C.c_void_p(s))
         assert rc == -2 and b"do not fit" in lib.sfh_last_error(compressor._h)
+        # the root's own stream inside the gathered range of d_out but NOT at its place (a peer's bytes would land on it, or
+        # it would be copied onto itself): refused -- by every rank alike, the exchange carries the root's addresses
+        for shift in (1, 8, n // 2):
+            rc = lib.sfh_gather_streams(compressor._h, comm, 0, out.data_ptr() + base + shift, size.data_ptr(), out.data_ptr(), base,
+                                        out.numel(), h_sizes, C.byref(end), C.c_void_p(s))
+            assert rc == -1 and b"overlaps" in lib.sfh_last_error(compressor._h), shift
+        # ... while one that lies clear of it, before or behind, is fine
+        far = torch.zeros(2 * shard.numel() + 64, dtype=torch.uint8, device="cuda")
+        far[shard.numel():shard.numel() + n] = out[base:base + n]
+        rc = lib.sfh_gather_streams(compressor._h, comm, 0, far.data_ptr() + shard.numel(), size.data_ptr(), far.data_ptr(), 0, n + 5,
+                                    h_sizes, C.byref(end), C.c_void_p(s))
+        assert rc == 0 and end.value == n
+        torch.cuda.synchronize()
+        assert np.array_equal(far[:n].cpu().numpy(), got)
         # bad arguments
         assert lib.sfh_gather_streams(compressor._h, comm, 1, shard.data_ptr(), size.data_ptr(), out.data_ptr(), 0, out.numel(),
                                       h_sizes, C.byref(end), C.c_void_p(s)) == -1  # root outside the communicator

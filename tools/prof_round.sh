@@ -19,3 +19,28 @@ f=$(find $out/kt -name '*kernel_stats.csv' | head -1)
 cat $out/${tag}_kernel_stats.csv
 grep '^{"metric"' $out/kt.log | tail -1 > $out/${tag}_bench_under_rocprof.json
 python tools/pmc_traffic.py $out/${tag}_pmc_summary.json $out/pmc_traffic.json ${tag}_pmc_summary.json > /dev/null
+# BASELINE config[4] (high-entropy input, stored fast path): HBM bytes moved per launch against 2N + 5 per chunk.
+# (The decompress leg is off: every kernel counted here is the compressor's.)
+CMDR="python bench.py --workload random --bytes 268435456 --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --no-decompress"
+bash tools/pmc_run.sh $out/rnd_fetch 300 "FETCH_SIZE" -- $CMDR > $out/rnd_fetch.log 2>&1
+bash tools/pmc_run.sh $out/rnd_write 300 "WRITE_SIZE" -- $CMDR > $out/rnd_write.log 2>&1
+python tools/pmc_summary.py $out/rnd_fetch $out/rnd_write > $out/rnd_summary.json
+python - $out/rnd_summary.json $out/${tag}_random_traffic.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+n = 256 << 20
+out = {"_meta": {"workload": "256 MiB high-entropy bytes (bench.py --workload random), default effort", "algorithmic_bytes": 2 * n + 5 * (n >> 15),
+                 "note": "reads = 2 x FETCH_SIZE KiB (gfx950 wide-read correction), writes = WRITE_SIZE KiB; per launch = sum / dispatches"}}
+tot = 0
+for k, v in d.items():
+    if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        continue
+    m = v.get("pmc_dispatches", 1)
+    rd, wr = 2 * v["FETCH_SIZE"] * 1024 / m, v["WRITE_SIZE"] * 1024 / m
+    out[k.replace("void ", "").split("<")[0]] = {"read_bytes": int(rd), "write_bytes": int(wr), "dispatches": m}
+    tot += rd + wr
+out["_meta"]["hbm_bytes_per_step"] = int(tot)
+out["_meta"]["over_input_bytes"] = round(tot / n, 3)
+json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+print(json.dumps(out["_meta"]))
+PY
