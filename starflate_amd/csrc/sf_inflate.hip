@@ -549,6 +549,10 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     a = a >= kRing ? a - kRing : a;
     return a >= kRing ? a - kRing : a;
   };
+  // a < 2 * kRing -> a mod kRing in two instructions: the unsigned minimum of a and a - kRing (which wraps to a huge
+  // number below kRing); likewise a - d for d <= a + kRing
+  auto wrap1 = [](uint32_t a) -> uint32_t { return min(a, a - kRing); };
+  auto back1 = [](uint32_t a, uint32_t d) -> uint32_t { return min(a - d, a - d + kRing); };  // a < kRing, d <= kWindow + a
   const SegInfo si = info[seg];
   if (si.status != inflate::kOk) return false;
   const uint32_t out_n = si.out_n;
@@ -675,6 +679,7 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     }
     __syncthreads();
     // ---- every thread takes bytes: find the token, then literal / final copy / step-relative pointer ----
+    const uint32_t pbase = ring(pos0);  // (uniform) ring position of the step's first byte: byte j lives at wrap1(pbase + j)
 #pragma unroll
     for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i) {
       const uint32_t j = t + KB_THREADS * i;
@@ -682,14 +687,14 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
         const uint32_t w = j >> 5;
         const uint32_t idx = s_wpre[w] + (uint32_t)__popc(s_mark[w] & (0xFFFFFFFFu >> (31u - (j & 31u)))) - 1u;
         const uint32_t ti = s_tinfo[idx];
+        const uint32_t cur = wrap1(pbase + j);
         if (!(ti & 0x1000u)) {
-          s_out[ring(pos0 + j)] = (uint8_t)(ti >> 16);
+          s_out[cur] = (uint8_t)(ti >> 16);
           s_ptr[j] = (uint16_t)kFinal;
         } else {
           const uint32_t dist = (ti >> 16) + 1u;
           if (dist > j) {  // source before the step: final
-            // (pos0 + j + kRing - dist stays below kChunk + kRing: dist >= 1)
-            s_out[ring(pos0 + j)] = s_out[ring(pos0 + j + kRing - dist)];
+            s_out[cur] = s_out[back1(cur, dist)];  // (dist <= kWindow < kRing)
             s_ptr[j] = (uint16_t)kFinal;
           } else {
             s_ptr[j] = (uint16_t)(j - dist);
@@ -709,7 +714,9 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
           if (p != kFinal) {
             const uint32_t q = s_ptr[p];
             if (q != kFinal) {
-              s_ptr[j] = (uint16_t)q;
+              // two hops per round (a pointer only ever moves to an ancestor, whatever the other threads have done to q)
+              const uint32_t r2 = s_ptr[q];
+              s_ptr[j] = (uint16_t)(r2 != kFinal ? r2 : q);
               changed = true;
             }
           }
@@ -722,7 +729,7 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
       const uint32_t j = t + KB_THREADS * i;
       if (j < span_n) {
         const uint32_t p = s_ptr[j];
-        if (p != kFinal) s_out[ring(pos0 + j)] = s_out[ring(pos0 + p)];  // p is final since the paint phase
+        if (p != kFinal) s_out[wrap1(pbase + j)] = s_out[wrap1(pbase + p)];  // p is final since the paint phase
       }
     }
     if (t == 0) {
@@ -735,7 +742,9 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     {
       const uint32_t end4 = next_pos & ~3u;
       uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
-      for (uint32_t q = flushed + 4 * t; q < end4; q += 4 * KB_THREADS) o32[q >> 2] = *reinterpret_cast<const uint32_t*>(s_out + ring(q));
+      const uint32_t fbase = ring(flushed);  // (uniform; the bytes to flush span less than kRing)
+      for (uint32_t q = flushed + 4 * t; q < end4; q += 4 * KB_THREADS)
+        o32[q >> 2] = *reinterpret_cast<const uint32_t*>(s_out + wrap1(fbase + (q - flushed)));
       flushed = end4;
     }
     tok_base = next_tok;

@@ -688,17 +688,15 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             for (uint32_t sl = 0; sl < NSL; ++sl) o[sl] = (uint32_t)s_post[sl * 64 + lane] << 2;
             uint32_t dat = code_it | lane;
             const uint32_t msk = 0xFFFFu;
-            // (an asm statement takes thirty operands at most: eight slices each; the last one waits for all)
+            // ONE asm statement from the first atomic to the wait: between two statements the compiler could move or spill a
+            // register whose value the LDS has not delivered yet
 #define SF_MSKOR(O) "ds_mskor_rtn_b32 " O ", " O ", %[m], %[d] offset:%[tab]\n\tv_add_u32 %[d], 64, %[d]\n\t"
 #define SF_MSKOR8 SF_MSKOR("%0") SF_MSKOR("%1") SF_MSKOR("%2") SF_MSKOR("%3") SF_MSKOR("%4") SF_MSKOR("%5") SF_MSKOR("%6") SF_MSKOR("%7")
+#define SF_MSKOR8B SF_MSKOR("%8") SF_MSKOR("%9") SF_MSKOR("%10") SF_MSKOR("%11") SF_MSKOR("%12") SF_MSKOR("%13") SF_MSKOR("%14") SF_MSKOR("%15")
             if constexpr (NSL == 16) {
-              asm volatile(SF_MSKOR8
-                           : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), [d] "+v"(dat)
-                           : [m] "v"(msk), [tab] "n"(L_TABLE)
-                           : "memory");
-              asm volatile(SF_MSKOR8 "s_waitcnt lgkmcnt(0)"
-                           : "+v"(o[8]), "+v"(o[9]), "+v"(o[10]), "+v"(o[11]), "+v"(o[12]), "+v"(o[13]), "+v"(o[14]), "+v"(o[15]), [d] "+v"(dat),
-                             "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])
+              asm volatile(SF_MSKOR8 SF_MSKOR8B "s_waitcnt lgkmcnt(0)"
+                           : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]),
+                             "+v"(o[8]), "+v"(o[9]), "+v"(o[10]), "+v"(o[11]), "+v"(o[12]), "+v"(o[13]), "+v"(o[14]), "+v"(o[15]), [d] "+v"(dat)
                            : [m] "v"(msk), [tab] "n"(L_TABLE)
                            : "memory");
             } else {
@@ -707,6 +705,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
                            : [m] "v"(msk), [tab] "n"(L_TABLE)
                            : "memory");
             }
+#undef SF_MSKOR8B
 #undef SF_MSKOR8
 #undef SF_MSKOR
             if constexpr (STRIDE2) {
