@@ -1239,7 +1239,11 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + pb]);
         // first token of a sub-index region: its position is the region's first, which is always a token start,
         // so the flag can only ever go onto the lane's slot 0
-        const uint32_t flag = (t & (kSubBytes / 8 - 1)) == 0 ? (kItemRegion | ((rc * kRSubs + pb / kSubBytes) << 8)) : 0u;
+        // (from an opaque copy of t: hoisted out of the round loop, the flag's thread-constant part is one more register alive
+        // across the match phase -- a spill in this kernel)
+        uint32_t t_now = t;
+        asm volatile("" : "+v"(t_now));
+        const uint32_t flag = (t_now & (kSubBytes / 8 - 1)) == 0 ? (kItemRegion | ((rc * kRSubs + (8 * t_now) / kSubBytes) << 8)) : 0u;
         // an item of the chunk: uniform base + a 32-bit byte offset (no 64-bit address arithmetic)
         auto put_item = [&](uint32_t byte_off, uint32_t v) {
           *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)byte_off) = (uint16_t)v;
