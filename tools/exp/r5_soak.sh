@@ -1,0 +1,4 @@
+# soak runs of the two fuzz tests at the final sources (development aid; GPU box)
+cd "${GRAFT_REPO_ROOT:-.}"; out=gpurun_out/${1:-r5m}; mkdir -p $out
+SF_FUZZ_N=${2:-20000} timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fuzz" > $out/fuzz_c.log 2>&1; echo "compressor fuzz rc $?"; tail -3 $out/fuzz_c.log
+SF_FUZZ_N=${3:-5000} timeout -k 10 600 python -m pytest tests/test_gpu_inflate.py -m gpu -x -q -k "fuzz" > $out/fuzz_d.log 2>&1; echo "decoder fuzz rc $?"; tail -3 $out/fuzz_d.log
