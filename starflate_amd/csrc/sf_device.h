@@ -6,7 +6,11 @@
 //               flight + the hash table + per-position (len,dist) of the round in LDS; step-synchronous
 //               hash insertion (two history levels per bucket), candidate compare, wave-local
 //               register-resident greedy/lazy parse; 16-bit token items + histogram out, one DEFLATE
-//               block per chunk
+//               block per chunk.  Other match phases behind the same stage / parse / emit: exact hash chains
+//               (SFH_EFFORT_BEST ..: heads + links in LDS, one workgroup per CU) and the step tables filled in
+//               position order (SFH_EFFORT_RECENT / _RECENT_ALL: buckets {lo, hi}, the exact predecessor as a
+//               candidate); both insert 64 positions per returning LDS atomic and rest on the lane order
+//               sf_guard.hip checks at run time
 //   K2 k_plan   one wave per chunk: raw length counts folded into symbols, length-limited Huffman lengths (ll, d, cl),
 //               canonical codes, dynamic header bits, block type, exact byte size
 //   K3 k_scan   exclusive scan of chunk byte sizes -> output offsets, total

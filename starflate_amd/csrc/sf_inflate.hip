@@ -688,18 +688,15 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
         const uint32_t idx = s_wpre[w] + (uint32_t)__popc(s_mark[w] & (0xFFFFFFFFu >> (31u - (j & 31u)))) - 1u;
         const uint32_t ti = s_tinfo[idx];
         const uint32_t cur = wrap1(pbase + j);
-        if (!(ti & 0x1000u)) {
-          s_out[cur] = (uint8_t)(ti >> 16);
-          s_ptr[j] = (uint16_t)kFinal;
-        } else {
-          const uint32_t dist = (ti >> 16) + 1u;
-          if (dist > j) {  // source before the step: final
-            s_out[cur] = s_out[back1(cur, dist)];  // (dist <= kWindow < kRing)
-            s_ptr[j] = (uint16_t)kFinal;
-          } else {
-            s_ptr[j] = (uint16_t)(j - dist);
-          }
-        }
+        // No branch on what the byte is (a wave executes every side of such a branch anyway): a literal is final, a match
+        // byte whose source lies before the step is final and copied at once (dist <= kWindow < kRing), one whose source
+        // lies inside the step gets a pointer -- and a byte that nobody reads before the resolve pass overwrites it (what
+        // a literal reads, one byte back, it ignores)
+        const bool mt = (ti & 0x1000u) != 0;
+        const uint32_t dist = (ti >> 16) + 1u;
+        const uint32_t sv = s_out[back1(cur, mt ? dist : 1u)];
+        s_out[cur] = (uint8_t)(mt ? sv : ti >> 16);
+        s_ptr[j] = (uint16_t)((!mt || dist > j) ? kFinal : j - dist);
       }
     }
     __syncthreads();
@@ -710,16 +707,14 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
       for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i) {
         const uint32_t j = t + KB_THREADS * i;
         if (j < span_n) {
+          // two hops per round (a pointer only ever moves to an ancestor, whatever the other threads have done to it
+          // meanwhile), without branches: a final entry reads itself and is written back as it was
           const uint32_t p = s_ptr[j];
-          if (p != kFinal) {
-            const uint32_t q = s_ptr[p];
-            if (q != kFinal) {
-              // two hops per round (a pointer only ever moves to an ancestor, whatever the other threads have done to q)
-              const uint32_t r2 = s_ptr[q];
-              s_ptr[j] = (uint16_t)(r2 != kFinal ? r2 : q);
-              changed = true;
-            }
-          }
+          const uint32_t q = s_ptr[p != kFinal ? p : j];
+          const uint32_t r2 = s_ptr[q != kFinal ? q : j];
+          const bool upd = p != kFinal && q != kFinal;
+          s_ptr[j] = (uint16_t)(upd ? (r2 != kFinal ? r2 : q) : p);
+          changed = changed || upd;
         }
       }
       if (!__syncthreads_or(changed)) break;
@@ -728,8 +723,9 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i) {
       const uint32_t j = t + KB_THREADS * i;
       if (j < span_n) {
-        const uint32_t p = s_ptr[j];
-        if (p != kFinal) s_out[wrap1(pbase + j)] = s_out[wrap1(pbase + p)];  // p is final since the paint phase
+        const uint32_t p = s_ptr[j];  // (final since the paint phase, or a pointer to a byte that is)
+        const uint32_t cur = wrap1(pbase + j);
+        s_out[cur] = s_out[p != kFinal ? wrap1(pbase + p) : cur];  // (a final byte is written back as it is)
       }
     }
     if (t == 0) {
