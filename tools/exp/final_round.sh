@@ -1,9 +1,9 @@
-# parity + profile passes + the full bench line at the final sources, in this order (development aid; GPU box)
+# usage: bash tools/exp/final_round.sh <out> [tag]: parity + profile passes + the full bench line at the final sources, in this order (GPU box)
 cd "${GRAFT_REPO_ROOT:-.}"; out=gpurun_out/${1:-r5l}; mkdir -p $out
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
 tail -3 $out/pytest.log
-bash tools/prof_round.sh r05 > $out/prof.log 2>&1; echo "prof rc $?"; tail -12 $out/prof.log
-cp gpurun_out/prof_r05/pmc_traffic.json profiles/pmc_traffic.json
+bash tools/prof_round.sh ${2:-r05} > $out/prof.log 2>&1; echo "prof rc $?"; tail -12 $out/prof.log
+cp gpurun_out/prof_${2:-r05}/pmc_traffic.json profiles/pmc_traffic.json
 timeout -k 10 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc $?"; python - $out/bench.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
