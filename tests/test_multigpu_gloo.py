@@ -80,7 +80,10 @@ def _worker_pipelined(rank, world, port, piece_bytes, K, q, container="raw"):
         dist.barrier()
         dist.destroy_process_group()
         return
-    out, total = multigpu.compress_pipelined(compress_fn, pieces)
+    timing = {}
+    out, total = multigpu.compress_pipelined(compress_fn, pieces, timing=timing)
+    # every rank gets one gather time per round (what bench.py reports as multi_gpu.gather_ms_per_round)
+    assert len(timing["gather_ms"]) == K and all(t >= 0 for t in timing["gather_ms"]), timing
     if rank == 0:
         st, w, back = O.decompress(out[:total].numpy(), whole.size)
         q.put((st, w, bool(np.array_equal(back, whole)), total))
