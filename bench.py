@@ -658,7 +658,7 @@ def main():
                 t = t.repeat(reps)
                 desc += f", repeated x{reps} for throughput"
                 nb *= reps
-            for eff in ("default", "recent", "thorough", "recent_all", "max", "chain4", "best", "ultra", "extreme"):
+            for eff in ("default", "recent", "thorough", "recent_all", "max", "chain2", "chain4", "best", "ultra", "extreme"):
                 others[key if eff == "default" else f"{key}_effort_{eff}"] = secondary_workload(
                     comp, key, nb, dev, 0, effort=eff, data=t, wl=desc)
             del t

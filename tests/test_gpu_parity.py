@@ -268,6 +268,14 @@ def test_stored_fast_path(compressor):
                                      block_bytes=compressor.last_block_bytes())
     assert st == 0 and back == turns.tobytes()
     assert len(compressor.compress(base64ish)) < 0.8 * base64ish.size
+    # every match finder goes through the same fast path (short probe behind a skipped chunk, nothing written for one): the
+    # chains with their ring of links, the step tables with steps of 512, the ordered insertion -- wrapped, too
+    for effort in ("thorough", "max", "best", "recent", "recent_all", "fastest"):
+        for bb in (0, 8 * CHUNK):
+            got = np.frombuffer(compressor.compress(turns, effort=effort, block_bytes=bb), np.uint8)
+            assert np.array_equal(got, O.compress(turns, O.default_params(strip_bytes=bb, **EFFORT_PARAMS[effort]))), (effort, bb)
+    import zlib as _z
+    assert _z.decompress(compressor.compress(turns, container="gzip", effort="recent_all"), 31) == turns.tobytes()
     assert len(compressor.compress(rnd)) == rnd.size + 5 * 6  # six stored blocks
     # a skipped block is not inserted into the hash tables either: the next block of the strip sees none of it
     two = np.concatenate([rnd[:CHUNK], rnd[:CHUNK]])
