@@ -424,7 +424,15 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       // (a match of kMinMatch bytes or more takes two) -- and every lane reads its own back at the start of the parse,
       // before any item of the round is written.  The 16 KiB this frees in LDS hold the larger hash table.  (With the even
       // positions searched only, one slot per even position: an odd position's distance is its successor's.)
-      const uint32_t stage_off = 2u * rc * kRound;  // byte offset of the round's slots in the chunk's item array
+      // WHERE in the item array: right behind the items the chunk has so far, rounded up to a 128-byte line (round 5; before:
+      // at the round's own positions, 2 * rc * kRound).  The round's items then land on the very lines the staged distances
+      // dirtied, a few thousand cycles later, and the L2 writes such a line back once -- at the positions' own place the
+      // staging of a chunk's later rounds lay beyond anything its items ever reach and went out to HBM as it was: WRITE_SIZE
+      // of the kernel 1.81 -> 1.10 GB per GiB of text.  Whole LINES: the same offset rounded to 16 bytes only made the kernel
+      // FETCH 0.64 GB more (1.88 against 1.24 GB: lines shared by the previous round's items and this round's slots).
+      // Never beyond the old offset + what rounding adds inside the array (a chunk has no more items than positions, and
+      // 2 * 3 * kRound is a multiple of 128)
+      const uint32_t stage_off = (2u * tot_items + 127u) & ~127u;  // byte offset of the round's slots in the chunk's item array
       __builtin_amdgcn_s_setprio(2);
       if constexpr (CHAIN) {
         // ---- exact hash chains (the specification's chain_depth > 0) ----
