@@ -57,6 +57,7 @@ struct sfh_ctx {
   int sizes_cap = 0;
   int order_ok[2] = {0, 0};      // sfh_lds_order_check per op (0 exchange: chains, 1 masked-or: recent): 0 not run, 1 holds, -1 does not
   int force_order_fail = 0;      // SFH_FORCE_ORDER_FAIL=1: the library's own check reports failure (tests)
+  int inflate_serial = 0;        // SFH_INFLATE_SERIAL=1: index-only streams through the lane-serial kernel alone (tests, A/B)
   char err[256] = {0};
 };
 
@@ -441,6 +442,8 @@ int sfh_create(sfh_ctx** out, int device) {
     if (b && atoi(b) > 0) ctx->batch_chunks = std::min<uint32_t>((uint32_t)atoi(b), sf::kBatchChunks);
     const char* f = getenv("SFH_FORCE_ORDER_FAIL");
     ctx->force_order_fail = (f && f[0] == '1');
+    const char* q = getenv("SFH_INFLATE_SERIAL");
+    ctx->inflate_serial = (q && q[0] == '1');
   }
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
@@ -631,7 +634,7 @@ int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const u
                                          ctx->ws.tokens, ctx->ws.seginfo, sps, s), "launch k_inflate_tokens_sub");
   else
     SF_HIP(sf::launch_inflate_tokens((const uint8_t*)d_src, src_n, d_index, (uint32_t)nseg, dst_n, ctx->ws.tokens,
-                                     ctx->ws.seginfo, sps, s), "launch k_inflate_tokens");
+                                     ctx->ws.seginfo, sps, !ctx->inflate_serial, s), "launch k_inflate_tokens");
   if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[1], s), "event");
   SF_HIP(sf::launch_inflate_bytes((const uint8_t*)d_src, src_n, (uint32_t)nseg, ctx->ws.tokens, ctx->ws.seginfo,
                                   (uint8_t*)d_dst, sps, s), "launch k_inflate_bytes");

@@ -140,7 +140,7 @@ hipError_t launch_wrap(const uint32_t* sums, uint32_t nchunks, uint64_t n, uint3
 hipError_t init_inflate_kernels();
 // sps: segments per strip (1: every segment independent); a segment's matches may reach its strip's earlier segments
 hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint64_t* index, uint32_t nseg, uint64_t dst_n,
-                                 uint32_t* tokens, SegInfo* info, uint32_t sps, hipStream_t s);
+                                 uint32_t* tokens, SegInfo* info, uint32_t sps, bool speculate, hipStream_t s);
 hipError_t launch_inflate_tokens_sub(const uint8_t* src, uint64_t src_n, const uint64_t* index, const uint32_t* subidx,
                                      uint32_t nseg, uint64_t dst_n, uint32_t* tokens, SegInfo* info, uint32_t sps,
                                      hipStream_t s);

@@ -32,6 +32,7 @@ namespace {
 // of 64 lanes at most (LDS), so what counts is how many waves those lanes are spread over: 4 lanes per wave = 16 waves
 // per CU measured best (1 GiB of text: 23.4 ms; 64 lanes in one wave 28.8, 32: 24.9, 16: 27.2, 8: 24.4, 2: 29.7, 1: 56.4)
 constexpr uint32_t KT_LANES = 4;
+constexpr uint32_t kRetrySerial = 0xFFFFFFFEu;  // SegInfo.status between k_inflate_tokens_spec and k_inflate_tokens: not decoded yet
 constexpr uint32_t KT_LDS = KT_LANES * inflate::LaneLayout::kBytes;
 constexpr uint32_t KB_THREADS = 512;
 constexpr uint32_t KB_TPT = 3;      // tokens per thread per step (2: 4.5 ms per GiB, 3: 3.75, 4: scratch)
@@ -45,10 +46,12 @@ static_assert(KB_SPAN <= KB_RING - kWindow && KB_RING % 16 == 0 && kChunk % 4 ==
 __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __restrict__ src, uint64_t src_n,
                                                             const uint64_t* __restrict__ index, uint32_t nseg,
                                                             uint64_t dst_n, uint32_t* __restrict__ tokens,
-                                                            SegInfo* __restrict__ info, uint32_t sps) {
+                                                            SegInfo* __restrict__ info, uint32_t sps,
+                                                            uint32_t only_retry) {
   extern __shared__ __align__(16) uint8_t s_tables[];
   const uint32_t seg = blockIdx.x * KT_LANES + threadIdx.x;
   if (seg >= nseg) return;
+  if (only_retry && info[seg].status != kRetrySerial) return;  // behind k_inflate_tokens_spec: what that one left
   const uint64_t lo = index[seg], hi = index[seg + 1];
   const uint64_t obase = (uint64_t)seg * kChunk;
   const uint32_t out_n = dst_n > obase ? (uint32_t)(dst_n - obase < kChunk ? dst_n - obase : kChunk) : 0u;
@@ -174,11 +177,21 @@ __device__ __forceinline__ uint32_t long_code(const uint8_t* m, const uint32_t* 
   return hit ? l : 0u;
 }
 
-template <class L>
+struct RegionOut {
+  uint32_t st, ntok;
+  uint32_t bit;    // where the lane stopped (bit offset from the segment's first byte)
+  uint32_t bytes;  // output bytes of its tokens
+  bool eob;        // it met the end-of-block code
+};
+
+// COUNT (k_inflate_tokens_spec's passes before the last): nothing is written and nothing is known about the output
+// position -- the lane's tokens are counted from bit_begin to the first token boundary at or behind bit_end, or to the
+// end-of-block code, which then stays unread (the lanes behind find it again and stand still on it).
+template <class L, bool COUNT>
 __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end,
                                         uint32_t bit_begin, uint32_t bit_end, bool until_eob, uint32_t out_begin,
                                         uint32_t out_end, uint32_t* tokens, const uint8_t* m, uint32_t half, uint32_t hist,
-                                        bool decode, uint32_t lane, RegionLds& R, uint32_t& st_out, uint32_t& ntok_out) {
+                                        bool decode, uint32_t lane, RegionLds& R, RegionOut& out) {
   using namespace inflate;
   uint32_t st = kOk;
   bool active = decode;
@@ -281,6 +294,7 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
     nheld = 0;
   };
   auto flush = [&]() {
+    if (COUNT) return;
     if (made == kPeriod) {
       if (nheld == kHold) {
         store_held();
@@ -344,12 +358,14 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
     const bool emits = ok && !is_eob;
     tok = is_lit ? sym : (kTokMatchBit | ((len - 3) << 16) | (dist - 1));
     out_pos += emits ? (is_lit ? 1u : len) : 0u;
-    ab = ok ? (is_len ? ab3 : ab + l) : ab;
+    ab = ok ? (is_len ? ab3 : ((COUNT && is_eob) ? ab : ab + l)) : ab;
     n += emits ? 1u : 0u;
     made += emits ? 1u : 0u;
     eob = eob || (ok && is_eob);
     st = ok ? st : err;
-    active = ok && !is_eob && ab < end_ab;
+    // (COUNT: no output limit stops a lane that runs off the segment's end on literals -- past the end the last dword
+    // repeats for ever; the position does.  Such a lane reports kSrcTooSmall below.)
+    active = ok && !is_eob && ab < end_ab && (!COUNT || ab <= lim_ab);
   };
 
   // the first window: loaded and waited for on the spot
@@ -367,6 +383,14 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
   }
   flush();
   flush();  // (made is 0 now: this one only lets the kept-back periods go)
+  out.ntok = n;
+  out.bit = ab - bias;
+  out.bytes = out_pos - out_begin;
+  out.eob = eob;
+  if (COUNT) {
+    out.st = (st == kOk && ab > lim_ab) ? (uint32_t)kSrcTooSmall : st;
+    return;
+  }
   if (started) {
     if (st == kOk) {
       if (ab > lim_ab) st = kSrcTooSmall;
@@ -377,8 +401,7 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
     // no token at all: the region must be empty in both views (inflate::decode_region on such a region)
     if (out_pos != out_end || until_eob) st = kError;
   }
-  st_out = st;
-  ntok_out = n;
+  out.st = st;
 }
 
 // Streams of this library: one block per segment and a sub-index naming, for each of the 32 parse regions
@@ -390,11 +413,47 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
 // their compact positions.  The kernel is bound by instruction issue, so full waves matter more than
 // occupancy.  The sub-index is checked against the stream (first code right after the header, every lane ends
 // exactly where the next begins, exact byte and token counts): a wrong sub-index is an error, never wrong output.
-__global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __restrict__ src, uint64_t src_n,
-                                                             const uint64_t* __restrict__ index,
-                                                             const uint32_t* __restrict__ subidx, uint32_t nseg,
-                                                             uint64_t dst_n, uint32_t* __restrict__ tokens,
-                                                             SegInfo* __restrict__ info, uint32_t sps) {
+// (The same wave with SPEC: k_inflate_tokens_spec below -- no sub-index, the lanes find their places themselves.)
+//
+// k_inflate_tokens_spec: streams with the segment index ONLY.  Where a token starts inside a segment is unknown, but a
+// Huffman decoder started at a wrong bit falls in with the true token chain quickly (DEFLATE streams of the text
+// workload: half the wrong starts within 42 bits, 99.9 % within 360), and two decoders that stand on the same bit at a
+// token boundary stay together for good.  So the segment's code bits are cut into 32 spans of equal length, one per lane:
+//   1. look-back: every lane decodes the kSpecLookBack bits before its span, from an arbitrary bit, counting nothing:
+//      the first boundary it reaches inside its span is its guess of where the span's first token starts;
+//   2. count: every lane decodes its span from that guess to the first boundary inside the next span and counts tokens
+//      and bytes.  Lane 0's start is exact (the end of the block header), so every lane whose start equals the end its
+//      predecessor reported is exact by induction; a lane whose start differs takes the predecessor's end and decodes
+//      again, until none differs (at most 32 rounds: one more lane is final after each);
+//   3. the spans are now what a sub-index is to k_inflate_tokens_sub -- first bit, last bit, tokens and bytes before --
+//      and its lockstep pass writes the tokens, with every check the serial decoder makes.
+// Anything but a clean segment of ONE coded (or one stored) block followed by empty stored blocks -- an error of any
+// kind, a second block with output -- is left to k_inflate_tokens (info.status = kRetrySerial, launched behind this kernel
+// for those segments only): statuses and the general case are the serial decoder's by construction.
+constexpr uint32_t kSpecLookBack = 512;
+
+// what follows the segment's block: true if only empty stored blocks (or nothing) do, as the serial decoder sees it
+// (inflate::decode_segment's loop: a block with BFINAL ends the segment whatever follows)
+__device__ bool tail_is_empty(const uint8_t* seg, uint32_t nbits, uint32_t pos, bool last) {
+  while (!last) {
+    if (pos + 3 > nbits) return true;
+    const uint32_t h = (uint32_t)seg[pos >> 3] | ((pos >> 3) + 1 < (nbits >> 3) ? (uint32_t)seg[(pos >> 3) + 1] << 8 : 0u);
+    const uint32_t b3 = (h >> (pos & 7)) & 7u;
+    if (b3 >> 1) return false;  // a coded block (or an invalid type): not for this kernel
+    pos = (pos + 3 + 7) & ~7u;
+    if (pos + 32 > nbits) return false;
+    const uint8_t* q = seg + (pos >> 3);
+    if (q[0] | q[1] | (uint8_t)~q[2] | (uint8_t)~q[3]) return false;  // LEN != 0 or NLEN != ~LEN
+    pos += 32;
+    last = b3 & 1u;
+  }
+  return true;
+}
+
+template <bool SPEC>
+__device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uint64_t src_n, const uint64_t* __restrict__ index,
+                                            const uint32_t* __restrict__ subidx, uint32_t nseg, uint64_t dst_n,
+                                            uint32_t* __restrict__ tokens, SegInfo* __restrict__ info, uint32_t sps) {
   using L = inflate::SharedLayout;
   __shared__ __align__(16) uint8_t s_tab[2][L::kBytes];
   __shared__ __align__(16) RegionLds s_reg;
@@ -445,30 +504,112 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __r
   const bool decode = live && status == inflate::kOk && !raw;
   uint32_t bit0 = 0, bit1 = 0, tok1 = 0, ob = 0, oe = 0;
   bool go = false;
-  if (decode) {
-    const uint32_t* sub = subidx + (uint64_t)seg * 2 * kSubRegions;
-    bit0 = sub[2 * hl];
-    tok0 = sub[2 * hl + 1];
-    bit1 = hl + 1 < kSubRegions ? sub[2 * hl + 2] : 0u;
-    tok1 = hl + 1 < kSubRegions ? sub[2 * hl + 3] : 0u;
-    ob = hl * kSubBytes < out_n ? hl * kSubBytes : out_n;
-    oe = (hl + 1) * kSubBytes < out_n ? (hl + 1) * kSubBytes : out_n;
-    // (tokens before a region) <= (bytes before it) also bounds the token stores
-    if ((hl == 0 && bit0 != s_open64[half][1]) || tok0 > ob) st = inflate::kError;
-    else go = true;
+  bool retry = false;  // SPEC: the segment is left to the serial kernel (uniform over the segment's 32 lanes)
+  const uint32_t seg_bits = (hi - lo) < (1ull << 28) ? 8u * (uint32_t)(hi - lo) : 0x80000000u;
+  const uint32_t hmask_shift = 32 * half;
+  if (!SPEC) {
+    if (decode) {
+      const uint32_t* sub = subidx + (uint64_t)seg * 2 * kSubRegions;
+      bit0 = sub[2 * hl];
+      tok0 = sub[2 * hl + 1];
+      bit1 = hl + 1 < kSubRegions ? sub[2 * hl + 2] : 0u;
+      tok1 = hl + 1 < kSubRegions ? sub[2 * hl + 3] : 0u;
+      ob = hl * kSubBytes < out_n ? hl * kSubBytes : out_n;
+      oe = (hl + 1) * kSubBytes < out_n ? (hl + 1) * kSubBytes : out_n;
+      // (tokens before a region) <= (bytes before it) also bounds the token stores
+      if ((hl == 0 && bit0 != s_open64[half][1]) || tok0 > ob) st = inflate::kError;
+      else go = true;
+    }
+  } else {
+    const uint32_t hdr = (uint32_t)s_open64[half][1];
+    // a segment this kernel does not take: header trouble of any kind, no output, more bits than positions are counted in
+    const bool take = decode && out_n != 0 && hdr <= seg_bits && seg_bits < 0x40000000u;
+    retry = live && !raw && !take;
+    const uint32_t body = take ? seg_bits - hdr : 0u;
+    const uint32_t nom0 = hdr + (uint32_t)(((uint64_t)body * hl) >> 5), nom1 = hdr + (uint32_t)(((uint64_t)body * (hl + 1)) >> 5);
+    const uint8_t* m = s_tab[half];
+    RegionOut o;
+    // 1. look-back
+    uint32_t entry = nom0;
+    {
+      const uint32_t back = nom0 - hdr < kSpecLookBack ? nom0 - hdr : kSpecLookBack;
+      const bool look = take && back != 0;
+      decode_regions_lockstep<L, true>(src, src_n, lo, hi, nom0 - back, nom0, false, 0u, 0x7FFFFFFFu, nullptr, m, half,
+                                       0x40000000u, look, lane, s_reg, o);
+      if (look && o.st == inflate::kOk && !o.eob) entry = o.bit;
+    }
+    // 2. count, until every lane starts where its predecessor ended
+    uint32_t exitb = 0, cnt = 0, nbytes = 0, lst = inflate::kOk;
+    bool leob = false, need = take, settled = false;
+#pragma nounroll
+    for (uint32_t round = 0; round < 34; ++round) {
+      decode_regions_lockstep<L, true>(src, src_n, lo, hi, entry, nom1 < entry ? entry : nom1, hl == 31, 0u, 0x7FFFFFFFu, nullptr, m, half,
+                                       0x40000000u, need, lane, s_reg, o);
+      if (need) {
+        exitb = o.bit;
+        cnt = o.ntok;
+        nbytes = o.bytes;
+        lst = o.st;
+        leob = o.eob;
+      }
+      const uint32_t pe = (uint32_t)__shfl_up((int)exitb, 1);
+      need = take && hl != 0 && entry != pe;
+      if (__ballot(need) == 0) {
+        settled = true;
+        break;
+      }
+      if (need) entry = pe;
+    }
+    // every lane is exact now: an error anywhere, a last lane without its end-of-block code, or a byte total other
+    // than the segment's leaves the segment to the serial kernel
+    uint32_t tsum = cnt, bsum = nbytes;
+#pragma unroll
+    for (uint32_t d = 1; d < 32; d <<= 1) {
+      const uint32_t tu = (uint32_t)__shfl_up((int)tsum, d, 32), bu = (uint32_t)__shfl_up((int)bsum, d, 32);
+      if (hl >= d) {
+        tsum += tu;
+        bsum += bu;
+      }
+    }
+    const uint32_t total_bytes = (uint32_t)__shfl((int)bsum, 31, 32);
+    const bool lane_bad = take && (lst != inflate::kOk || (hl == 31 && !leob));
+    const uint32_t bad_half = (uint32_t)((__ballot(lane_bad) >> hmask_shift) & 0xFFFFFFFFull);
+    if (take && (!settled || bad_half != 0 || total_bytes != out_n)) retry = true;
+    bit0 = entry;
+    bit1 = exitb;
+    tok0 = tsum - cnt;
+    ob = bsum - nbytes;
+    oe = bsum;
+    tok1 = tsum;
+    go = take && !retry;
   }
+  uint32_t end_bit = 0;
   {
-    uint32_t rst = inflate::kOk;
-    decode_regions_lockstep<L>(src, src_n, lo, hi, bit0, bit1, hl + 1 == kSubRegions, ob, oe,
-                               tokens + (uint64_t)seg * kChunk + tok0, s_tab[half], half, (seg % sps) * kChunk, go, lane,
-                               s_reg, rst, n);
+    RegionOut o;
+    decode_regions_lockstep<L, false>(src, src_n, lo, hi, bit0, bit1, hl + 1 == kSubRegions, ob, oe,
+                                      tokens + (uint64_t)seg * kChunk + tok0, s_tab[half], half, (seg % sps) * kChunk, go, lane,
+                                      s_reg, o);
+    n = o.ntok;
+    end_bit = o.bit;
     if (go) {
-      st = rst;
+      st = o.st;
       if (st == inflate::kOk && hl + 1 < kSubRegions && tok0 + n != tok1) st = inflate::kError;
     }
   }
   // per segment: first failing region in stream order, token total from the last region lane
   const uint64_t failed = __ballot(decode && st != inflate::kOk);
+  if (SPEC) {
+    // what follows the block (stored segment: its one block) must be empty stored blocks
+    bool tail_bad = false;
+    if (live && !retry && hl == 31 && (go || raw)) {
+      const uint32_t at = raw ? 40u + 8u * out_n : end_bit;
+      tail_bad = !tail_is_empty(src + lo, seg_bits, at, (src[lo] & 1u) != 0);
+    }
+    if (live && raw && (out_n == 0 || seg_bits >= 0x40000000u)) tail_bad = hl == 31;
+    const uint64_t tb = __ballot(tail_bad);
+    if ((tb >> hmask_shift) & 0xFFFFFFFFull) retry = true;
+    if ((failed >> hmask_shift) & 0xFFFFFFFFull) retry = true;
+  }
 #pragma unroll
   for (uint32_t h = 0; h < 2; ++h) {
     const uint64_t fh = (failed >> (32 * h)) & 0xFFFFFFFFull;
@@ -481,9 +622,25 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __r
       si.raw = raw;
       si.out_n = out_n;
       si.raw_off = s_open64[half][0];
+      if (SPEC && retry) si.status = kRetrySerial;
       info[seg] = si;
     }
   }
+}
+
+__global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __restrict__ src, uint64_t src_n,
+                                                             const uint64_t* __restrict__ index,
+                                                             const uint32_t* __restrict__ subidx, uint32_t nseg,
+                                                             uint64_t dst_n, uint32_t* __restrict__ tokens,
+                                                             SegInfo* __restrict__ info, uint32_t sps) {
+  tokens_wave<false>(src, src_n, index, subidx, nseg, dst_n, tokens, info, sps);
+}
+
+__global__ __launch_bounds__(64, 2) void k_inflate_tokens_spec(const uint8_t* __restrict__ src, uint64_t src_n,
+                                                              const uint64_t* __restrict__ index, uint32_t nseg,
+                                                              uint64_t dst_n, uint32_t* __restrict__ tokens,
+                                                              SegInfo* __restrict__ info, uint32_t sps) {
+  tokens_wave<true>(src, src_n, index, nullptr, nseg, dst_n, tokens, info, sps);
 }
 
 // inclusive wave scan on the DPP network (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips
@@ -808,10 +965,18 @@ hipError_t init_inflate_kernels() {
                              (int)KB_LDS);
 }
 
+// Index-only streams: the speculative wave kernel, then the lane-serial one for the segments that one left (speculate =
+// false: the lane-serial kernel for every segment, the path of rounds 2-4; SFH_INFLATE_SERIAL=1).
 hipError_t launch_inflate_tokens(const uint8_t* src, uint64_t src_n, const uint64_t* index, uint32_t nseg, uint64_t dst_n,
-                                 uint32_t* tokens, SegInfo* info, uint32_t sps, hipStream_t s) {
+                                 uint32_t* tokens, SegInfo* info, uint32_t sps, bool speculate, hipStream_t s) {
+  if (speculate) {
+    hipLaunchKernelGGL(k_inflate_tokens_spec, dim3((nseg + 1) / 2), dim3(64), 0, s, src, src_n, index, nseg, dst_n, tokens,
+                       info, sps);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(k_inflate_tokens, dim3((nseg + KT_LANES - 1) / KT_LANES), dim3(KT_LANES), KT_LDS, s, src, src_n, index,
-                     nseg, dst_n, tokens, info, sps);
+                     nseg, dst_n, tokens, info, sps, speculate ? 1u : 0u);
   return hipGetLastError();
 }
 

@@ -364,3 +364,71 @@ def test_fuzz_decoder_on_zlib_and_own_streams(compressor):
         for s in (None, sub):
             got, st = compressor.decompress(own, idx, data.size, subindex=s, block_bytes=bb)
             assert st == 0 and got == data.tobytes(), (it, total, s is not None, bb)
+
+
+def test_speculative_index_only_equals_lane_serial(compressor, starfleet, monkeypatch):
+    """Index-only streams go through k_inflate_tokens_spec (a wave per two segments: 32 lanes find their token boundaries by
+    decoding ahead of their span, count, and the spans then serve as a sub-index), with k_inflate_tokens -- one lane per
+    segment, the serial decoder itself -- behind it for whatever is not ONE clean block per segment.  Bytes and status must
+    be those of the lane-serial kernel alone (SFH_INFLATE_SERIAL=1) on own streams of every strategy, on zlib streams with
+    several blocks per segment, on damaged streams; and on a large input the speculative kernel must be the faster one."""
+    import torch
+    from starflate_amd import Compressor
+
+    monkeypatch.setenv("SFH_INFLATE_SERIAL", "1")
+    serial = Compressor(0)
+    monkeypatch.delenv("SFH_INFLATE_SERIAL")
+    try:
+        rng = np.random.default_rng(99)
+        cases = []
+        for name, data in _inputs(starfleet).items():
+            for strategy, bb in (("auto", 262144), ("dynamic", 32768), ("dynamic", 131072), ("fixed", 65536)):
+                stream = np.frombuffer(compressor.compress(data, strategy=strategy, block_bytes=bb), np.uint8).copy()
+                cases.append((f"{name}/{strategy}/{bb}", stream, compressor.last_index(), data, bb))
+        # zlib: a sync flush every 32 KiB, level 1 on mixed data closes blocks inside the segments as well
+        mixed = synth.gen_mixed(1 << 20, seed=8, stripe=1 << 14)[: 9 * CHUNK + 321]
+        for level in (1, 6, 9):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 1 if level == 1 else 8)  # memLevel 1: 128-symbol blocks' worth of buffer
+            nch = (mixed.size + CHUNK - 1) // CHUNK
+            zs = [co.compress(mixed[c * CHUNK:(c + 1) * CHUNK].tobytes()) + co.flush(zlib.Z_FINISH if c == nch - 1 else zlib.Z_FULL_FLUSH)
+                  for c in range(nch)]
+            index = np.concatenate([[0], np.cumsum([len(p) for p in zs])]).astype(np.uint64)
+            cases.append((f"zlib{level}", np.frombuffer(b"".join(zs), np.uint8).copy(), index, mixed, 32768))
+        for name, stream, index, data, bb in cases:
+            a = compressor.decompress(stream, index, data.size, block_bytes=bb)
+            b = serial.decompress(stream, index, data.size, block_bytes=bb)
+            assert a == b and a == (data.tobytes(), 0), name
+        # damage: same status, same bytes
+        nsame = 0
+        for name, stream, index, data, bb in cases[::3]:
+            if stream.size < 64:
+                continue
+            for _ in range(12):
+                bad = stream.copy()
+                for _ in range(int(rng.integers(1, 4))):
+                    bad[int(rng.integers(0, bad.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                a = compressor.decompress(bad, index, data.size, block_bytes=bb)
+                b = serial.decompress(bad, index, data.size, block_bytes=bb)
+                assert a == b, name
+                nsame += 1
+        assert nsame > 100
+        # the point of it: time of the token stage, 64 MiB of text
+        data = synth.gen_text(64 << 20, seed=5)
+        src = torch.from_numpy(data).cuda()
+        out, n = compressor.compress_tensor(src)
+        index, bb = compressor.last_index(device="cuda"), compressor.last_block_bytes()
+        stream = out[:n].clone()
+        ms = {}
+        for key, c in (("spec", compressor), ("serial", serial)):
+            c.set_profiling(True)
+            best = 1e9
+            for _ in range(3):
+                back, st = c.decompress_tensor(stream, index, data.size, block_bytes=bb)
+                assert st == 0 and torch.equal(back, src)
+                best = min(best, c.inflate_ms()["k_inflate_tokens"])
+            c.set_profiling(False)
+            ms[key] = best
+        print("index-only token stage, 64 MiB:", ms)
+        assert ms["spec"] < 0.5 * ms["serial"], ms
+    finally:
+        serial.close()
