@@ -695,8 +695,11 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
   uint32_t* s_wpre = s_mark + KB_SPAN / 32;                        // [KB_SPAN / 32] tokens starting before the word
   uint32_t* s_w = s_wpre + KB_SPAN / 32;                           // [8] wave totals, [2] next step
   uint32_t* s_next = s_w + KB_THREADS / 64;
+  uint32_t* s_any = s_next + 2;                                    // [4] wg_any's flags
+  static_assert(4 * (KB_THREADS / 64 + 2 + 4) <= 64, "the tail of KB_AUX holds the wave totals, the step's end and the flags");
   constexpr uint32_t kFinal = 0xFFFFu;
   constexpr uint32_t kWords = KB_SPAN / 32;
+  constexpr uint32_t kListCap = KB_THREADS * KB_TPT * 4 / 2 / (KB_THREADS / 64);  // pointer bytes a wave can list (384)
   static_assert(kWords <= 128 && KB_SPAN % 32 == 0, "one wave scans the bitmap, two words per lane");
   const uint32_t t = threadIdx.x, lane = t & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -752,6 +755,21 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     s_next[0] = 0;  // tokens placed by the step
     s_next[1] = 0;  // where its output ends
   }
+  // "does any thread of the workgroup say so", with ONE barrier (__syncthreads_or is three: the library clears its word,
+  // ORs into it and reads it, a barrier after each; at two to three of them per step that was half the kernel's barriers).
+  // Four flag words in rotation: a call stores 1 into its word where a wave has a taker, and clears the word of two calls
+  // on -- last read before the previous call's barrier, next written behind this one's.  The barrier is the phase barrier
+  // the call sites need anyway.
+  if (t < 4) s_any[t] = 0;  // (the caller's barrier between segments / the first step's barrier orders this)
+  uint32_t any_gen = 0;     // uniform
+  auto wg_any = [&](bool pred) -> bool {
+    const uint32_t slot = any_gen & 3u;
+    ++any_gen;
+    if (__ballot(pred) != 0 && lane == 0) s_any[slot] = 1u;
+    if (t == 64) s_any[(slot + 2u) & 3u] = 0u;
+    __syncthreads();
+    return s_any[slot] != 0u;
+  };
   if (t < kWords) s_mark[t] = 0;
   uint32_t next[KB_TPT];
 #pragma unroll
@@ -815,7 +833,7 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
         atomicOr(&s_mark[r >> 5], 1u << (r & 31));
       }
     }
-    if (__syncthreads_or(bad)) {
+    if (wg_any(bad)) {
       if (t == 0) info[seg].status = inflate::kError;
       return false;
     }
@@ -837,6 +855,7 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
     __syncthreads();
     // ---- every thread takes bytes: find the token, then literal / final copy / step-relative pointer ----
     const uint32_t pbase = ring(pos0);  // (uniform) ring position of the step's first byte: byte j lives at wrap1(pbase + j)
+    uint32_t pm = 0;  // which of the thread's bytes got a pointer
 #pragma unroll
     for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i) {
       const uint32_t j = t + KB_THREADS * i;
@@ -853,12 +872,55 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
         const uint32_t dist = (ti >> 16) + 1u;
         const uint32_t sv = s_out[back1(cur, mt ? dist : 1u)];
         s_out[cur] = (uint8_t)(mt ? sv : ti >> 16);
-        s_ptr[j] = (uint16_t)((!mt || dist > j) ? kFinal : j - dist);
+        const bool fin = !mt || dist > j;
+        s_ptr[j] = (uint16_t)(fin ? kFinal : j - dist);
+        pm |= (fin ? 0u : 1u) << i;
       }
     }
-    __syncthreads();
+    // The bytes with pointers are a third of a step of text: each wave lists its own (kListCap entries in what were the
+    // token records, dead now; the list is the wave's alone, so no barrier stands between writing and reading it) and
+    // jumping and resolving run over the lists, all lanes busy, instead of over every byte (round 5: 1.25 + 0.3 ms of the
+    // kernel's 3.25 per GiB went into those two passes).  A step with more pointers than the lists hold -- runs,
+    // short periods -- takes the passes over every byte, as before.
+    const uint32_t pcnt = (uint32_t)__popc(pm);
+    const uint32_t pincl = wave_scan_incl(pcnt, lane);
+    const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
+    if (!wg_any(wtotal > kListCap)) {
+      uint16_t* lst = reinterpret_cast<uint16_t*>(s_tinfo) + wave * kListCap;
+      {
+        uint32_t at = pincl - pcnt;
+#pragma unroll
+        for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i)
+          if ((pm >> i) & 1u) lst[at++] = (uint16_t)(t + KB_THREADS * i);
+      }
+      // a hop: to the parent unless the entry is final
+      auto hop = [&](uint32_t x) -> uint32_t {
+        const uint32_t y = s_ptr[x];
+        return y != kFinal ? y : x;
+      };
+      // (an entry whose last hop did not move is at a final byte and sits the later rounds out: nine in ten after the first)
+      uint32_t done = 0;  // bit i: the lane's i-th list entry (kListCap / 64 = 6 at most)
+      for (;;) {  // ends: every change moves a pointer to a strictly smaller index; afterwards every pointer is at a final byte
+        bool changed = false;
+        uint32_t it = 0;
+        for (uint32_t k = lane; k < wtotal; k += 64, ++it) {
+          if (!((done >> it) & 1u)) {
+            const uint32_t j = lst[k];
+            const uint32_t p1 = hop(s_ptr[j]), p2 = hop(p1), p3 = hop(p2);
+            s_ptr[j] = (uint16_t)p3;
+            if (p3 == p2) done |= 1u << it;
+            else changed = true;  // the last hop still moved: what it reached may be a pointer itself
+          }
+        }
+        if (!wg_any(changed)) break;
+      }
+      for (uint32_t k = lane; k < wtotal; k += 64) {
+        const uint32_t j = lst[k];
+        s_out[wrap1(pbase + j)] = s_out[wrap1(pbase + s_ptr[j])];
+      }
+    } else {
     // ---- pointer jumping inside the step; a pointer only ever moves to an ancestor, so in place is fine ----
-    for (;;) {  // ends: every change moves a pointer to a strictly smaller index
+    for (;;) {  // ends: every change moves a pointer to a strictly smaller index; afterwards every entry is final or points at one
       bool changed = false;
 #pragma unroll
       for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i) {
@@ -871,10 +933,13 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
           const uint32_t r2 = s_ptr[q != kFinal ? q : j];
           const bool upd = p != kFinal && q != kFinal;
           s_ptr[j] = (uint16_t)(upd ? (r2 != kFinal ? r2 : q) : p);
-          changed = changed || upd;
+          // another round only for an entry that still points at a pointer: one that has just reached a final byte
+          // (r2 final: it points at q now, and a final entry stays final) is done, so the round that finishes the
+          // last entry also ends the loop (round 5; before, one more round in which nothing changed)
+          changed = changed || (upd && r2 != kFinal);
         }
       }
-      if (!__syncthreads_or(changed)) break;
+      if (!wg_any(changed)) break;
     }
 #pragma unroll
     for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i) {
@@ -884,6 +949,7 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
         const uint32_t cur = wrap1(pbase + j);
         s_out[cur] = s_out[p != kFinal ? wrap1(pbase + p) : cur];  // (a final byte is written back as it is)
       }
+    }
     }
     if (t == 0) {
       s_next[0] = 0;
