@@ -893,12 +893,10 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
         for (uint32_t i = 0; i < (KB_SPAN + KB_THREADS - 1) / KB_THREADS; ++i)
           if ((pm >> i) & 1u) lst[at++] = (uint16_t)(t + KB_THREADS * i);
       }
-      // a hop: to the parent unless the entry is final
-      auto hop = [&](uint32_t x) -> uint32_t {
-        const uint32_t y = s_ptr[x];
-        return y != kFinal ? y : x;
-      };
-      // (an entry whose last hop did not move is at a final byte and sits the later rounds out: nine in ten after the first)
+      // The kernel is bound by its LDS instructions (scattered 16-bit accesses), so a lane stops hopping as soon as it
+      // reads "final" (two thirds of the entries at their first probe) and an entry that has reached a final byte sits the
+      // later rounds out (1.4 rounds per step of text); up to four hops a round (2 / 3 / 4 / 6 unconditional hops on one
+      // box: 2.78 / 2.75 / 2.68 / 2.72 ms per GiB)
       uint32_t done = 0;  // bit i: the lane's i-th list entry (kListCap / 64 = 6 at most)
       for (;;) {  // ends: every change moves a pointer to a strictly smaller index; afterwards every pointer is at a final byte
         bool changed = false;
@@ -906,10 +904,18 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
         for (uint32_t k = lane; k < wtotal; k += 64, ++it) {
           if (!((done >> it) & 1u)) {
             const uint32_t j = lst[k];
-            const uint32_t p1 = hop(s_ptr[j]), p2 = hop(p1), p3 = hop(p2);
-            s_ptr[j] = (uint16_t)p3;
-            if (p3 == p2) done |= 1u << it;
-            else changed = true;  // the last hop still moved: what it reached may be a pointer itself
+            const uint32_t p = s_ptr[j];
+            uint32_t cur = p, nxt = s_ptr[cur];
+#pragma unroll
+            for (uint32_t h = 1; h < 4; ++h) {
+              if (nxt != kFinal) {
+                cur = nxt;
+                nxt = s_ptr[cur];
+              }
+            }
+            if (cur != p) s_ptr[j] = (uint16_t)cur;
+            if (nxt == kFinal) done |= 1u << it;
+            else changed = true;  // what the last hop reached is a pointer itself
           }
         }
         if (!wg_any(changed)) break;
