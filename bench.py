@@ -611,7 +611,8 @@ def main():
                              "status": dstatus, "equal_to_input": bool(torch.equal(back, data)),
                              "kernel_ms": {k: round(v, 4) for k, v in comp.inflate_ms().items()}}
         decomp["note"] = ("sub_indexed: chunk offsets + 32 entries per chunk (sfh_copy_index, sfh_copy_subindex), 32 lanes per "
-                          "segment; segment_indexed: chunk offsets only, one lane per segment (any indexed stream); "
+                          "segment; segment_indexed: chunk offsets only, 32 lanes per segment that find their token boundaries speculatively "
+                          "(k_inflate_tokens_spec; any indexed stream, the lane-serial kernel behind it for multi-block segments); "
                           f"byte copies strip by strip (block_bytes {bb})")
         del back, stream_t
 

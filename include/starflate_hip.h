@@ -234,9 +234,13 @@ int sfh_copy_index(sfh_ctx* ctx, uint64_t* dst, size_t entries, int dst_on_devic
 /* Sub-index of the last sfh_compress* call: per segment, for each of its 32 regions of 1024 bytes of output
  * (no match of this library's streams crosses them) {bit offset of the region's first token code counted from
  * the segment's first byte, tokens before the region}: SFH_SUBINDEX_WORDS uint32 per segment, all zero for a
- * stored segment.  Optional side information: with it 32 lanes decode one segment's Huffman codes side by
- * side instead of one (the decoder checks it against the stream: a wrong sub-index is an error, never wrong
- * output).  Streams from elsewhere have none and take the one-lane-per-segment path. */
+ * stored segment.  Optional side information: with it the 32 lanes that decode one segment's Huffman codes side
+ * by side are TOLD where their regions start (the decoder checks it against the stream: a wrong sub-index is an
+ * error, never wrong output).  Streams from elsewhere have none: their segments are decoded by 32 lanes as well,
+ * which find their token boundaries speculatively (a segment of one coded or stored block followed by empty stored
+ * blocks, what Z_FULL_FLUSH leaves; about 1.6 x the sub-indexed time), and by one lane per segment where a
+ * segment holds several blocks or is damaged -- the serial decoder itself, statuses included
+ * (SFH_INFLATE_SERIAL=1 in the environment of sfh_create: that kernel for every segment). */
 #define SFH_SUBINDEX_WORDS 64u
 int sfh_copy_subindex(sfh_ctx* ctx, uint32_t* dst, size_t words, int dst_on_device, void* stream);
 

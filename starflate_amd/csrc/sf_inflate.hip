@@ -5,11 +5,15 @@
 // produces), and e.g. zlib streams with Z_SYNC_FLUSH every 32 KiB and Z_FULL_FLUSH at the strip boundaries.
 // Arbitrary DEFLATE is serial (README.md:5-6); the index is what makes it parallel.
 //
-//   k_inflate_tokens  the bit-serial half.  Huffman decoding cannot be split inside a segment, so the SIMT
-//                     mapping is one LANE per segment: 64 segments per wave, each lane running
-//                     decode_segment() (sf_inflate_core.h) with its own code tables in a 2,308-byte slice
-//                     of LDS (144 KiB per workgroup) and its own 64-bit bit buffer fed by dword loads one
-//                     refill ahead.  Output: the k_lz77 token format, four tokens per 16-byte store.
+//   k_inflate_tokens_sub   the bit-serial half with the region sub-index this library's compressor writes: 32 lanes per
+//                     segment, one per 1024 bytes of output, 64 bit streams decoded side by side in lockstep.
+//   k_inflate_tokens_spec  the same wave with the segment index only: the lanes find their token boundaries themselves
+//                     (a decoder started on a wrong bit falls in with the true token chain within a few hundred bits),
+//                     count, and the spans they settled on then serve as the sub-index.
+//   k_inflate_tokens  behind k_inflate_tokens_spec, for the segments that are not one clean block: Huffman decoding cannot
+//                     be split inside a segment in general, so one LANE per segment runs decode_segment()
+//                     (sf_inflate_core.h) with its own code tables in a 2,308-byte slice of LDS and its own 64-bit bit
+//                     buffer fed by dword loads one refill ahead.  Output of all three: the k_lz77 token format.
 //   k_inflate_bytes   the byte-copy half (src/decompress.cpp:157-187,388-398), one 512-thread workgroup per
 //                     strip, its segments in order, the output window a 36 KiB ring in LDS (the 32 KiB a match
 //                     may reach back + the step in flight), steps of <= 1024 tokens / 3968 bytes: a
