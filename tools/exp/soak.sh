@@ -2,3 +2,4 @@
 cd "${GRAFT_REPO_ROOT:-.}"; out=gpurun_out/${1:-r5m}; mkdir -p $out
 SF_FUZZ_N=${2:-20000} timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fuzz" > $out/fuzz_c.log 2>&1; echo "compressor fuzz rc $?"; tail -3 $out/fuzz_c.log
 SF_FUZZ_N=${3:-5000} timeout -k 10 600 python -m pytest tests/test_gpu_inflate.py -m gpu -x -q -k "fuzz" > $out/fuzz_d.log 2>&1; echo "decoder fuzz rc $?"; tail -3 $out/fuzz_d.log
+SF_SPEC_FUZZ=${4:-400} timeout -k 10 900 python -m pytest tests/test_gpu_inflate.py -m gpu -x -q -k "speculative" > $out/fuzz_s.log 2>&1; echo "speculative against lane-serial, damaged streams rc $?"; tail -3 $out/fuzz_s.log
