@@ -4,5 +4,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 for name in "$@"; do
   echo "== $name" | tee -a gpurun_out/dvariants.log
-  SFH_LIB="$PWD/build/variants/lib_$name.so" timeout -k 10 240 python tools/d1_time.py 2>&1 | grep "^sub" | tee -a gpurun_out/dvariants.log
+  SFH_LIB="$PWD/build/variants/lib_$name.so" timeout -k 10 240 python tools/d1_time.py 2>&1 | grep "^sub\|^idx" | tee -a gpurun_out/dvariants.log
 done
