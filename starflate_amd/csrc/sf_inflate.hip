@@ -527,7 +527,9 @@ __device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uin
   } else {
     const uint32_t hdr = (uint32_t)s_open64[half][1];
     // a segment this kernel does not take: header trouble of any kind, no output, more bits than positions are counted in
-    const bool take = decode && out_n != 0 && hdr <= seg_bits && seg_bits < 0x40000000u;
+    // (a segment of more than 512 KiB for 32 KiB of output is not what this kernel is for either: the counting passes have
+    // no business reading megabytes that the serial decoder would give up on after 32 KiB of output)
+    const bool take = decode && out_n != 0 && hdr <= seg_bits && seg_bits < (1u << 22);
     retry = live && !raw && !take;
     const uint32_t body = take ? seg_bits - hdr : 0u;
     const uint32_t nom0 = hdr + (uint32_t)(((uint64_t)body * hl) >> 5), nom1 = hdr + (uint32_t)(((uint64_t)body * (hl + 1)) >> 5);
@@ -538,7 +540,7 @@ __device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uin
     {
       const uint32_t back = nom0 - hdr < kSpecLookBack ? nom0 - hdr : kSpecLookBack;
       const bool look = take && back != 0;
-      decode_regions_lockstep<L, true>(src, src_n, lo, hi, nom0 - back, nom0, false, 0u, 0x7FFFFFFFu, nullptr, m, half,
+      decode_regions_lockstep<L, true>(src, src_n, lo, hi, nom0 - back, nom0, false, 0u, kChunk, nullptr, m, half,
                                        0x40000000u, look, lane, s_reg, o);
       if (look && o.st == inflate::kOk && !o.eob) entry = o.bit;
     }
@@ -547,7 +549,8 @@ __device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uin
     bool leob = false, need = take, settled = false;
 #pragma nounroll
     for (uint32_t round = 0; round < 34; ++round) {
-      decode_regions_lockstep<L, true>(src, src_n, lo, hi, entry, nom1 < entry ? entry : nom1, hl == 31, 0u, 0x7FFFFFFFu, nullptr, m, half,
+      // (out_n bytes at most: no lane of a segment can produce more, and a speculative one on a wrong chain stops there)
+      decode_regions_lockstep<L, true>(src, src_n, lo, hi, entry, nom1 < entry ? entry : nom1, hl == 31, 0u, out_n, nullptr, m, half,
                                        0x40000000u, need, lane, s_reg, o);
       if (need) {
         exitb = o.bit;
@@ -609,7 +612,7 @@ __device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uin
       const uint32_t at = raw ? 40u + 8u * out_n : end_bit;
       tail_bad = !tail_is_empty(src + lo, seg_bits, at, (src[lo] & 1u) != 0);
     }
-    if (live && raw && (out_n == 0 || seg_bits >= 0x40000000u)) tail_bad = hl == 31;
+    if (live && raw && (out_n == 0 || seg_bits >= (1u << 22))) tail_bad = hl == 31;
     const uint64_t tb = __ballot(tail_bad);
     if ((tb >> hmask_shift) & 0xFFFFFFFFull) retry = true;
     if ((failed >> hmask_shift) & 0xFFFFFFFFull) retry = true;
