@@ -615,6 +615,35 @@ def main():
                           "(k_inflate_tokens_spec; any indexed stream, the lane-serial kernel behind it for multi-block segments); "
                           f"byte copies strip by strip (block_bytes {bb})")
         del back, stream_t
+        # a FOREIGN indexed stream: zlib -6 with Z_FULL_FLUSH every 32 KiB over the first 64 MiB of the same input -- what the
+        # reference's own flushed fixtures are (tools/deflate_compress.py --flush); segment index only, every segment independent
+        if not args.no_secondary:
+            import zlib
+            import numpy as np
+            zn = min(n, 64 << 20)
+            host = data[:zn].cpu().numpy()
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            nseg = (zn + 32767) // 32768
+            parts = [co.compress(host[c * 32768:(c + 1) * 32768].tobytes()) + co.flush(zlib.Z_FINISH if c == nseg - 1 else zlib.Z_FULL_FLUSH)
+                     for c in range(nseg)]
+            zidx = torch.from_numpy(np.concatenate([[0], np.cumsum([len(q) for q in parts])]).astype(np.int64)).to(dev)
+            zraw = np.frombuffer(b"".join(parts), np.uint8)
+            zstream = torch.from_numpy(zraw.copy()).to(dev)
+            zback = torch.empty(zn, dtype=torch.uint8, device=dev)
+            comp.decompress_tensor(zstream, zidx, zn, out=zback, block_bytes=32768)  # warm-up
+            torch.cuda.synchronize()
+            reps = 5
+            td = time.perf_counter()
+            for _ in range(reps):
+                _, zstatus = comp.decompress_tensor(zstream, zidx, zn, out=zback, block_bytes=32768)
+            torch.cuda.synchronize()
+            td = (time.perf_counter() - td) / reps
+            decomp["zlib_made_segment_indexed"] = {
+                "value": round(zn / td / 2**20, 1), "unit": "MiB/s of output", "ms": round(td * 1e3, 3), "bytes": zn,
+                "stream_bytes": int(zraw.size), "status": zstatus, "equal_to_input": bool(torch.equal(zback, data[:zn])),
+                "kernel_ms": {k: round(v, 4) for k, v in comp.inflate_ms().items()},
+                "made_by": "zlib.compressobj(6, DEFLATED, -15), Z_FULL_FLUSH every 32768 bytes of input"}
+            del zback, zstream
 
     # ---- end to end from pinned host memory (H2D + kernels + D2H), and the other two workloads ----
     e2e, others = None, None

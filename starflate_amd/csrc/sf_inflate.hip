@@ -287,7 +287,9 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
   // of this kernel 4.7 GB per GiB of output with kHold = 0, 2.5 GB with 3 (the tokens are 1.6 GB); the time is the same
   // within the noise of the pool (2.68 / 2.74 / 2.87 / 2.87 ms for 0 / 1 / 2 / 3 in one run, 2.80 against 2.60 for 0 / 1 in
   // another) -- kept for the traffic.
-  constexpr uint32_t kHold = 3;
+  // (Round 5: two held periods, not three: with the four registers that frees the kernel fits 96 VGPRs -- five waves per SIMD
+  // instead of four, which is what its 7.7 KB of LDS allow per CU: 2.90 -> 2.79 ms, index-only 4.55 -> 4.33.)
+  constexpr uint32_t kHold = 2;
   static_assert(kHold <= 3, "held periods live in named registers");
   Dwords4 h0{0, 0, 0, 0}, h1{0, 0, 0, 0}, h2{0, 0, 0, 0};  // h0: the newest held period
   uint32_t nheld = 0;
@@ -635,6 +637,7 @@ __device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uin
   }
 }
 
+__attribute__((amdgpu_waves_per_eu(5, 5)))  // 96 VGPRs: what the workgroup's LDS allows per SIMD
 __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __restrict__ src, uint64_t src_n,
                                                              const uint64_t* __restrict__ index,
                                                              const uint32_t* __restrict__ subidx, uint32_t nseg,
@@ -643,6 +646,7 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __r
   tokens_wave<false>(src, src_n, index, subidx, nseg, dst_n, tokens, info, sps);
 }
 
+__attribute__((amdgpu_waves_per_eu(5, 5)))
 __global__ __launch_bounds__(64, 2) void k_inflate_tokens_spec(const uint8_t* __restrict__ src, uint64_t src_n,
                                                               const uint64_t* __restrict__ index, uint32_t nseg,
                                                               uint64_t dst_n, uint32_t* __restrict__ tokens,
