@@ -295,6 +295,8 @@ enum sfh_debug_what {
   SFH_DBG_LENS = 4,   /* uint8[320] per chunk: ll lens [0..287], d lens [288..319] */
   SFH_DBG_OFFSETS = 5, /* uint64 per chunk */
   SFH_DBG_SUBINDEX = 7, /* uint32[64] per chunk */
+  SFH_DBG_SEGINFO = 10, /* decoder: uint32[6] per segment {status, tokens, bit 0 stored segment | bit 1 decoded by the
+                           lane-serial kernel, bytes, offset of a stored segment's bytes (u64)} */
   SFH_DBG_STAMPS = 6   /* uint64[2][nchunks][8] (k_lz77, k_plan); only with env SFH_K1_STAMPS=1 at sfh_create
                           (diagnostic k_lz77 build: cycles per phase, never a timing claim) */
 };

@@ -16,6 +16,7 @@ CONTAINER = {"raw": 0, "zlib": 1, "gzip": 2}
 DBG_NTOK, DBG_TOKENS, DBG_HIST, DBG_PLAN, DBG_LENS, DBG_OFFSETS, DBG_STAMPS = range(7)
 DBG_SUBINDEX = 7
 DBG_ITEMS, DBG_NITEMS = 8, 9
+DBG_SEGINFO = 10
 DEFAULT_BLOCK_BYTES = 262144
 LARGE_BLOCK_BYTES = 1 << 19
 CHAIN_BLOCK_BYTES = 1 << 20

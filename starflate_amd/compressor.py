@@ -236,6 +236,7 @@ class Compressor:
             _capi.DBG_SUBINDEX: ((nchunks, 32, 2), np.uint32),
             _capi.DBG_ITEMS: ((nchunks, CHUNK_BYTES), np.uint16),
             _capi.DBG_NITEMS: ((nchunks,), np.uint32),
+            _capi.DBG_SEGINFO: ((nchunks, 6), np.uint32),  # decoder: status, tokens, raw | serial << 1, bytes, raw offset (u64)
         }
         shape, dt = shapes[what]
         a = np.empty(shape, dtype=dt)

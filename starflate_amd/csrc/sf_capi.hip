@@ -947,6 +947,7 @@ int sfh_debug_read(sfh_ctx* ctx, int what, void* host_dst, size_t bytes) {
     case SFH_DBG_OFFSETS: p = ctx->ws.offsets; avail = nall * 8; break;
     case SFH_DBG_SUBINDEX: p = ctx->ws.subidx; avail = nall * SFH_SUBINDEX_WORDS * 4; break;
     case SFH_DBG_STAMPS: p = ctx->ws.stamps; avail = p ? nc * 128 : 0; break;
+    case SFH_DBG_SEGINFO: p = ctx->ws.seginfo; avail = nall * sizeof(sf::SegInfo); break;
     case SFH_DBG_LENS: {
       if (bytes > nc * 320) return SFH_E_INVALID_ARG;
       SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");

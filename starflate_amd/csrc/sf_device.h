@@ -76,10 +76,12 @@ struct ChunkCodes {
 };
 
 // per-segment record of the decoder (sf_inflate.hip): written by k_inflate_tokens, read by k_inflate_bytes
+constexpr uint32_t kSegRaw = 1u, kSegSerial = 2u;
 struct SegInfo {
   uint32_t status;   // DecompressStatus of the reference (src/decompress.hpp:13-23), 0 = Success
   uint32_t ntok;
-  uint32_t raw;      // 1: one stored block holding the whole segment, bytes at raw_off of the stream
+  uint32_t raw;      // bit 0 (kSegRaw): one stored block holding the whole segment, bytes at raw_off of the stream;
+                     // bit 1 (kSegSerial): decoded by the lane-serial kernel (diagnostic, SFH_DBG_SEGINFO)
   uint32_t out_n;    // bytes this segment produces
   uint64_t raw_off;
 };

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(KT_LANES) void k_inflate_tokens(const uint8_t* __re
   SegInfo si;
   si.status = r.status;
   si.ntok = r.ntok;
-  si.raw = r.raw;
+  si.raw = (r.raw ? kSegRaw : 0u) | kSegSerial;
   si.out_n = out_n;
   si.raw_off = r.raw_off;
   info[seg] = si;
@@ -419,7 +419,6 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
 // their compact positions.  The kernel is bound by instruction issue, so full waves matter more than
 // occupancy.  The sub-index is checked against the stream (first code right after the header, every lane ends
 // exactly where the next begins, exact byte and token counts): a wrong sub-index is an error, never wrong output.
-// (The same wave with SPEC: k_inflate_tokens_spec below -- no sub-index, the lanes find their places themselves.)
 //
 // k_inflate_tokens_spec: streams with the segment index ONLY.  Where a token starts inside a segment is unknown, but a
 // Huffman decoder started at a wrong bit falls in with the true token chain quickly (DEFLATE streams of the text
@@ -433,31 +432,14 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
 //      again, until none differs (at most 32 rounds: one more lane is final after each);
 //   3. the spans are now what a sub-index is to k_inflate_tokens_sub -- first bit, last bit, tokens and bytes before --
 //      and its lockstep pass writes the tokens, with every check the serial decoder makes.
-// Anything but a clean segment of ONE coded (or one stored) block followed by empty stored blocks -- an error of any
-// kind, a second block with output -- is left to k_inflate_tokens (info.status = kRetrySerial, launched behind this kernel
-// for those segments only): statuses and the general case are the serial decoder's by construction.
+// A segment's blocks are taken one after the other, as the serial decoder reads them (tokens_wave_spec below): a stored
+// block becomes the raw copy (the first block, holding the whole segment) or literal tokens, a coded block goes through 1-3,
+// the empty stored blocks a flush leaves are read on the spot.  A segment is finished here only if everything about it was
+// in order; an error of any kind leaves it to k_inflate_tokens (info.status = kRetrySerial, launched behind this kernel for
+// those segments only): statuses are the serial decoder's by construction.
 constexpr uint32_t kSpecLookBack = 512;
 
-// what follows the segment's block: true if only empty stored blocks (or nothing) do, as the serial decoder sees it
-// (inflate::decode_segment's loop: a block with BFINAL ends the segment whatever follows)
-__device__ bool tail_is_empty(const uint8_t* seg, uint32_t nbits, uint32_t pos, bool last) {
-  while (!last) {
-    if (pos + 3 > nbits) return true;
-    const uint32_t h = (uint32_t)seg[pos >> 3] | ((pos >> 3) + 1 < (nbits >> 3) ? (uint32_t)seg[(pos >> 3) + 1] << 8 : 0u);
-    const uint32_t b3 = (h >> (pos & 7)) & 7u;
-    if (b3 >> 1) return false;  // a coded block (or an invalid type): not for this kernel
-    pos = (pos + 3 + 7) & ~7u;
-    if (pos + 32 > nbits) return false;
-    const uint8_t* q = seg + (pos >> 3);
-    if (q[0] | q[1] | (uint8_t)~q[2] | (uint8_t)~q[3]) return false;  // LEN != 0 or NLEN != ~LEN
-    pos += 32;
-    last = b3 & 1u;
-  }
-  return true;
-}
-
-template <bool SPEC>
-__device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uint64_t src_n, const uint64_t* __restrict__ index,
+__device__ __forceinline__ void tokens_wave_sub(const uint8_t* __restrict__ src, uint64_t src_n, const uint64_t* __restrict__ index,
                                             const uint32_t* __restrict__ subidx, uint32_t nseg, uint64_t dst_n,
                                             uint32_t* __restrict__ tokens, SegInfo* __restrict__ info, uint32_t sps) {
   using L = inflate::SharedLayout;
@@ -510,40 +492,286 @@ __device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uin
   const bool decode = live && status == inflate::kOk && !raw;
   uint32_t bit0 = 0, bit1 = 0, tok1 = 0, ob = 0, oe = 0;
   bool go = false;
-  bool retry = false;  // SPEC: the segment is left to the serial kernel (uniform over the segment's 32 lanes)
-  const uint32_t seg_bits = (hi - lo) < (1ull << 28) ? 8u * (uint32_t)(hi - lo) : 0x80000000u;
-  const uint32_t hmask_shift = 32 * half;
-  if (!SPEC) {
-    if (decode) {
-      const uint32_t* sub = subidx + (uint64_t)seg * 2 * kSubRegions;
-      bit0 = sub[2 * hl];
-      tok0 = sub[2 * hl + 1];
-      bit1 = hl + 1 < kSubRegions ? sub[2 * hl + 2] : 0u;
-      tok1 = hl + 1 < kSubRegions ? sub[2 * hl + 3] : 0u;
-      ob = hl * kSubBytes < out_n ? hl * kSubBytes : out_n;
-      oe = (hl + 1) * kSubBytes < out_n ? (hl + 1) * kSubBytes : out_n;
-      // (tokens before a region) <= (bytes before it) also bounds the token stores
-      if ((hl == 0 && bit0 != s_open64[half][1]) || tok0 > ob) st = inflate::kError;
-      else go = true;
+  if (decode) {
+    const uint32_t* sub = subidx + (uint64_t)seg * 2 * kSubRegions;
+    bit0 = sub[2 * hl];
+    tok0 = sub[2 * hl + 1];
+    bit1 = hl + 1 < kSubRegions ? sub[2 * hl + 2] : 0u;
+    tok1 = hl + 1 < kSubRegions ? sub[2 * hl + 3] : 0u;
+    ob = hl * kSubBytes < out_n ? hl * kSubBytes : out_n;
+    oe = (hl + 1) * kSubBytes < out_n ? (hl + 1) * kSubBytes : out_n;
+    // (tokens before a region) <= (bytes before it) also bounds the token stores
+    if ((hl == 0 && bit0 != s_open64[half][1]) || tok0 > ob) st = inflate::kError;
+    else go = true;
+  }
+  {
+    RegionOut o;
+    decode_regions_lockstep<L, false>(src, src_n, lo, hi, bit0, bit1, hl + 1 == kSubRegions, ob, oe,
+                                      tokens + (uint64_t)seg * kChunk + tok0, s_tab[half], half, (seg % sps) * kChunk, go, lane,
+                                      s_reg, o);
+    n = o.ntok;
+    if (go) {
+      st = o.st;
+      if (st == inflate::kOk && hl + 1 < kSubRegions && tok0 + n != tok1) st = inflate::kError;
     }
-  } else {
-    const uint32_t hdr = (uint32_t)s_open64[half][1];
-    // a segment this kernel does not take: header trouble of any kind, no output, more bits than positions are counted in
-    // (a segment of more than 512 KiB for 32 KiB of output is not what this kernel is for either: the counting passes have
-    // no business reading megabytes that the serial decoder would give up on after 32 KiB of output)
-    const bool take = decode && out_n != 0 && hdr <= seg_bits && seg_bits < (1u << 22);
-    retry = live && !raw && !take;
-    const uint32_t body = take ? seg_bits - hdr : 0u;
-    const uint32_t nom0 = hdr + (uint32_t)(((uint64_t)body * hl) >> 5), nom1 = hdr + (uint32_t)(((uint64_t)body * (hl + 1)) >> 5);
+  }
+  // per segment: first failing region in stream order, token total from the last region lane
+  const uint64_t failed = __ballot(decode && st != inflate::kOk);
+#pragma unroll
+  for (uint32_t h = 0; h < 2; ++h) {
+    const uint64_t fh = (failed >> (32 * h)) & 0xFFFFFFFFull;
+    const uint32_t first_st = fh ? (uint32_t)__builtin_amdgcn_readlane(st, __builtin_amdgcn_readfirstlane(__builtin_ctzll(fh)) + 32 * h) : 0u;
+    const uint32_t total = __builtin_amdgcn_readlane(tok0 + n, 32 * h + 31);
+    if (lane == 32 * h && live) {
+      SegInfo si;
+      si.status = status != inflate::kOk ? status : (fh ? first_st : (uint32_t)inflate::kOk);
+      si.ntok = (status == inflate::kOk && !raw) ? total : 0u;
+      si.raw = raw;
+      si.out_n = out_n;
+      si.raw_off = s_open64[half][0];
+      info[seg] = si;
+    }
+  }
+}
+
+__attribute__((amdgpu_waves_per_eu(5, 5)))  // 96 VGPRs: what the workgroup's LDS allows per SIMD
+__global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __restrict__ src, uint64_t src_n,
+                                                             const uint64_t* __restrict__ index,
+                                                             const uint32_t* __restrict__ subidx, uint32_t nseg,
+                                                             uint64_t dst_n, uint32_t* __restrict__ tokens,
+                                                             SegInfo* __restrict__ info, uint32_t sps) {
+  tokens_wave_sub(src, src_n, index, subidx, nseg, dst_n, tokens, info, sps);
+}
+
+// ---- k_inflate_tokens_spec: the wave, block after block ----
+// header of the block that starts at bit `at` of the segment (one lane); a coded block's code lengths go to m
+struct BlockOpen {
+  uint32_t st;         // inflate status of the header
+  uint32_t kind;       // kBlkNone: the half sits this round out, kBlkEnd: no header bits left, kBlkStored, kBlkCoded
+  uint32_t final;      // BFINAL
+  uint32_t len;        // stored: bytes
+  uint32_t data_byte;  // stored: the first data byte, counted from the segment's first byte
+  uint32_t hdr_end;    // coded: bit offset of the first token code
+};
+constexpr uint32_t kBlkNone = 0, kBlkEnd = 1, kBlkStored = 2, kBlkCoded = 3;
+// Blocks WITH OUTPUT of a segment this kernel follows (the empty stored blocks of a flush are not counted).  Every coded block
+// costs the wave its tables and three passes, so a segment cut into dozens of small blocks (zlib with memLevel 1: a block
+// every 127 symbols) is the lane-serial kernel's, and is handed over after four turns rather than after dozens.
+constexpr uint32_t kSpecMaxBlocks = 4;
+
+template <class L>
+__device__ BlockOpen open_block(const uint8_t* src, uint64_t src_n, uint64_t lo, uint64_t hi, uint32_t at, uint8_t* m) {
+  using namespace inflate;
+  BlockOpen b{kOk, kBlkEnd, 0, 0, 0, 0};
+  BitReader br;
+  br.open(src, src_n, lo, hi);
+  if (at + 3 > br.nbits) return b;  // out of input (inflate::decode_segment's loop head)
+  br.seek(at >> 3);
+  br.bitpos = at & ~7u;
+  br.refill();
+  br.drop(at & 7u);
+  br.refill();
+  b.final = br.get(1);
+  const uint32_t type = br.get(2);
+  if (type == 3) {
+    b.st = kInvalidBlockHeader;
+    return b;
+  }
+  if (type == 0) {  // src/decompress.cpp:416-436
+    br.drop((8u - (br.bitpos & 7u)) & 7u);
+    br.refill();
+    if (br.bitpos + 32 > br.nbits) {
+      b.st = kSrcTooSmall;
+      return b;
+    }
+    const uint32_t len = br.get(16);
+    br.refill();
+    const uint32_t nlen = br.get(16);
+    if ((len ^ nlen) != 0xFFFFu) {
+      b.st = kNoCompressionLenMismatch;
+      return b;
+    }
+    if (br.bitpos + 8 * len > br.nbits) {
+      b.st = kSrcTooSmall;
+      return b;
+    }
+    b.kind = kBlkStored;
+    b.len = len;
+    b.data_byte = br.bitpos >> 3;
+    return b;
+  }
+  b.st = read_lengths<L>(br, m, type);
+  b.kind = kBlkCoded;
+  b.hdr_end = br.bitpos;
+  return b;
+}
+
+// One wave, two segments (32 lanes each), every segment block after block as the serial decoder reads them
+// (inflate::decode_segment): a stored block becomes the segment's raw copy (the first block, holding all its bytes) or
+// literal tokens; a coded block is decoded by the 32 lanes as described above.  A segment is finished HERE only when
+// everything about it was in order; else it is left to k_inflate_tokens (kRetrySerial).
+// where a segment stands between its blocks.  In LDS, and re-read after every pass (kept in registers across the passes it
+// costs the token loops their registers: 236 bytes of scratch, some of it inside them, 6 % of the kernel's time)
+struct SegState {
+  uint64_t lo, hi;     // the segment's stream bytes
+  uint64_t raw_off;
+  uint32_t seg_bits, out_n;
+  uint32_t at;         // bit offset of the next block header
+  uint32_t out_base, tok_base;  // bytes / tokens of the blocks before
+  uint32_t state, raw;
+};
+enum : uint32_t { kSegRun = 0, kSegDone = 1, kSegRetry = 2 };
+
+__device__ __forceinline__ void tokens_wave_spec(const uint8_t* __restrict__ src, uint64_t src_n, const uint64_t* __restrict__ index,
+                                                 uint32_t nseg, uint64_t dst_n, uint32_t* __restrict__ tokens,
+                                                 SegInfo* __restrict__ info, uint32_t sps) {
+  using L = inflate::SharedLayout;
+  __shared__ __align__(16) uint8_t s_tab[2][L::kBytes];
+  __shared__ __align__(16) RegionLds s_reg;
+  __shared__ BlockOpen s_blk[2];
+  __shared__ SegState s_st[2];
+  const uint32_t lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
+  const uint32_t seg = 2 * blockIdx.x + half;
+  {
+    // RFC 1951 3.2.5 as a table: base | extra bits << 16
+    uint32_t base = 0, extra = 0;
+    if (lane < 29) inflate::length_info(257 + lane, base, extra);
+    else if (lane >= 32 && lane < 62) inflate::distance_info(lane - 32, base, extra);
+    s_reg.lut[lane] = base | (extra << 16);
+  }
+  if (hl == 0) {
+    const bool live = seg < nseg;
+    const uint64_t lo = live ? index[seg] : 0, hi = live ? index[seg + 1] : 0;
+    const uint64_t obase = (uint64_t)seg * kChunk;
+    const uint32_t out_n = (live && dst_n > obase) ? (uint32_t)(dst_n - obase < kChunk ? dst_n - obase : kChunk) : 0u;
+    const uint32_t seg_bits = (hi > lo && hi - lo < (1ull << 19)) ? 8u * (uint32_t)(hi - lo) : 0u;
+    SegState z;
+    z.lo = lo;
+    z.hi = hi;
+    z.raw_off = 0;
+    z.seg_bits = seg_bits;
+    z.out_n = out_n;
+    z.at = 0;
+    z.out_base = 0;
+    z.tok_base = 0;
+    // not for this kernel: no output, no input, an index that does not hold, more than 512 KiB of stream for 32 KiB of output
+    z.state = !live ? (uint32_t)kSegDone : ((out_n == 0 || seg_bits == 0 || hi > src_n) ? (uint32_t)kSegRetry : (uint32_t)kSegRun);
+    z.raw = 0;
+    s_st[half] = z;
+  }
+  const uint32_t hshift = 32 * half;
+  SegState& S = s_st[half];
+  // (what the compiler knows of S is void behind this: the state is re-read from LDS, not carried in registers)
+  auto fresh = []() { asm volatile("" ::: "memory"); };
+  // Behind a block: the empty stored blocks a flush leaves (Z_SYNC_FLUSH / Z_FULL_FLUSH, this library's byte alignment) are
+  // read on the spot, as the serial decoder would read them, so that the usual segment -- one coded block, one empty stored
+  // block -- is one turn of the loop below.  Anything else stays where it is for open_block.  Returns the state; at: in / out.
+  auto behind_block = [&](uint32_t& at, bool fin, uint32_t out_base) -> uint32_t {
+    const uint8_t* sp = src + S.lo;
+    const uint32_t seg_bits = S.seg_bits;
+    while (!fin) {
+      if (at + 3 > seg_bits) break;
+      const uint32_t by = at >> 3;
+      const uint32_t h = (uint32_t)sp[by] | (8 * (by + 1) < seg_bits ? (uint32_t)sp[by + 1] << 8 : 0u);
+      const uint32_t b3 = (h >> (at & 7u)) & 7u;
+      if (b3 >> 1) break;  // a coded block (or an invalid type)
+      const uint32_t p = (at + 3u + 7u) & ~7u;
+      if (p + 32 > seg_bits) break;
+      const uint8_t* q = sp + (p >> 3);
+      if (q[0] | q[1] | (uint8_t)~q[2] | (uint8_t)~q[3]) break;  // LEN != 0 or NLEN != ~LEN
+      at = p + 32;
+      fin = (b3 & 1u) != 0;
+    }
+    // BFINAL seen, or no header bits left: the segment is complete if it has all its bytes (else the serial decoder says what is wrong)
+    if (fin || at + 3 > seg_bits) return out_base == S.out_n ? (uint32_t)kSegDone : (uint32_t)kSegRetry;
+    return kSegRun;
+  };
+#pragma nounroll
+  for (uint32_t blk = 0; blk < kSpecMaxBlocks; ++blk) {
+    __syncthreads();  // (the tables and records of the block before are read, the states are written)
+    fresh();
+    if (__ballot(S.state == kSegRun) == 0) break;
+    if (hl == 0) {
+      if (S.state == kSegRun) s_blk[half] = open_block<L>(src, src_n, S.lo, S.hi, S.at, s_tab[half]);
+      else s_blk[half].kind = kBlkNone;
+    }
+    __syncthreads();
+    fresh();
+    bool coded = false;
+    if (S.state == kSegRun) {
+      // every lane of the segment works out the same new state; lane 0 of it writes it down
+      const BlockOpen b = s_blk[half];
+      uint32_t state = kSegRun, at = S.at, out_base = S.out_base, tok_base = S.tok_base, raw = S.raw;
+      uint64_t raw_off = S.raw_off;
+      const uint32_t out_n = S.out_n;
+      if (b.st != inflate::kOk) state = kSegRetry;
+      else if (b.kind == kBlkEnd) state = out_base == out_n ? (uint32_t)kSegDone : (uint32_t)kSegRetry;
+      else if (b.kind == kBlkStored) {
+        if (b.len > out_n - out_base) state = kSegRetry;
+        else {
+          if (blk == 0 && b.len == out_n) {  // the whole segment is this block: the byte-copy kernel takes it from the stream
+            raw = 1;
+            raw_off = S.lo + b.data_byte;
+          } else if (raw) {
+            state = b.len ? (uint32_t)kSegRetry : state;  // (cannot happen: a raw segment has no bytes left)
+          } else {
+            uint32_t* seg_tokens = tokens + (uint64_t)seg * kChunk + tok_base;
+            const uint8_t* from = src + S.lo + b.data_byte;
+            for (uint32_t k = hl; k < b.len; k += 32) seg_tokens[k] = from[k];
+            tok_base += b.len;
+          }
+          out_base += b.len;
+          at = 8u * (b.data_byte + b.len);
+          if (state == kSegRun) state = behind_block(at, b.final != 0, out_base);
+        }
+      } else {
+        coded = true;
+        if (raw || b.hdr_end > S.seg_bits) state = kSegRetry;  // (tokens behind a raw copy: the serial decoder's business)
+      }
+      coded = coded && state == kSegRun;
+      if (hl == 0) {
+        S.state = state;
+        S.at = at;
+        S.out_base = out_base;
+        S.tok_base = tok_base;
+        S.raw = raw;
+        S.raw_off = raw_off;
+      }
+    }
+    // the code tables, by the whole wave for either half (uniform conditions: they sit in LDS)
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+      if (s_blk[h].kind == kBlkCoded && s_blk[h].st == inflate::kOk) {
+        build_tables_wave<true>(s_tab[h], lane);
+        build_tables_wave<false>(s_tab[h], lane);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+      if (s_blk[h].kind == kBlkCoded && s_blk[h].st == inflate::kOk) {
+        build_limits<true>(s_tab[h], s_reg.lim[h][0], s_reg.base[h][0], lane);
+        build_limits<false>(s_tab[h], s_reg.lim[h][1], s_reg.base[h][1], lane);
+      }
+    }
+    __syncthreads();
+    fresh();
+    const bool take = coded;
+    if (__ballot(take) == 0) continue;
     const uint8_t* m = s_tab[half];
+    uint32_t entry, nom1;
     RegionOut o;
     // 1. look-back
-    uint32_t entry = nom0;
     {
+      const uint32_t hdr = s_blk[half].hdr_end;
+      const uint32_t body = take ? S.seg_bits - hdr : 0u;
+      const uint32_t nom0 = hdr + (uint32_t)(((uint64_t)body * hl) >> 5);
+      nom1 = hdr + (uint32_t)(((uint64_t)body * (hl + 1)) >> 5);
+      entry = nom0;
       const uint32_t back = nom0 - hdr < kSpecLookBack ? nom0 - hdr : kSpecLookBack;
       const bool look = take && back != 0;
-      decode_regions_lockstep<L, true>(src, src_n, lo, hi, nom0 - back, nom0, false, 0u, kChunk, nullptr, m, half,
-                                       0x40000000u, look, lane, s_reg, o);
+      decode_regions_lockstep<L, true>(src, src_n, S.lo, S.hi, nom0 - back, nom0, false, 0u, kChunk, nullptr, m, half, 0x40000000u,
+                                       look, lane, s_reg, o);
       if (look && o.st == inflate::kOk && !o.eob) entry = o.bit;
     }
     // 2. count, until every lane starts where its predecessor ended
@@ -551,9 +779,10 @@ __device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uin
     bool leob = false, need = take, settled = false;
 #pragma nounroll
     for (uint32_t round = 0; round < 34; ++round) {
-      // (out_n bytes at most: no lane of a segment can produce more, and a speculative one on a wrong chain stops there)
-      decode_regions_lockstep<L, true>(src, src_n, lo, hi, entry, nom1 < entry ? entry : nom1, hl == 31, 0u, out_n, nullptr, m, half,
-                                       0x40000000u, need, lane, s_reg, o);
+      fresh();
+      // (the bytes the segment has left, at most: no lane can produce more, and a speculative one on a wrong chain stops there)
+      decode_regions_lockstep<L, true>(src, src_n, S.lo, S.hi, entry, nom1 < entry ? entry : nom1, hl == 31, 0u,
+                                       S.out_n - S.out_base, nullptr, m, half, 0x40000000u, need, lane, s_reg, o);
       if (need) {
         exitb = o.bit;
         cnt = o.ntok;
@@ -569,8 +798,8 @@ __device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uin
       }
       if (need) entry = pe;
     }
-    // every lane is exact now: an error anywhere, a last lane without its end-of-block code, or a byte total other
-    // than the segment's leaves the segment to the serial kernel
+    // every lane is exact now: an error anywhere, a last lane without its end-of-block code, or more bytes than the segment
+    // has left leaves the segment to the serial kernel
     uint32_t tsum = cnt, bsum = nbytes;
 #pragma unroll
     for (uint32_t d = 1; d < 32; d <<= 1) {
@@ -580,70 +809,49 @@ __device__ __forceinline__ void tokens_wave(const uint8_t* __restrict__ src, uin
         bsum += bu;
       }
     }
+    fresh();
     const uint32_t total_bytes = (uint32_t)__shfl((int)bsum, 31, 32);
     const bool lane_bad = take && (lst != inflate::kOk || (hl == 31 && !leob));
-    const uint32_t bad_half = (uint32_t)((__ballot(lane_bad) >> hmask_shift) & 0xFFFFFFFFull);
-    if (take && (!settled || bad_half != 0 || total_bytes != out_n)) retry = true;
-    bit0 = entry;
-    bit1 = exitb;
-    tok0 = tsum - cnt;
-    ob = bsum - nbytes;
-    oe = bsum;
-    tok1 = tsum;
-    go = take && !retry;
-  }
-  uint32_t end_bit = 0;
-  {
-    RegionOut o;
-    decode_regions_lockstep<L, false>(src, src_n, lo, hi, bit0, bit1, hl + 1 == kSubRegions, ob, oe,
-                                      tokens + (uint64_t)seg * kChunk + tok0, s_tab[half], half, (seg % sps) * kChunk, go, lane,
-                                      s_reg, o);
-    n = o.ntok;
-    end_bit = o.bit;
-    if (go) {
-      st = o.st;
-      if (st == inflate::kOk && hl + 1 < kSubRegions && tok0 + n != tok1) st = inflate::kError;
+    const uint32_t bad_half = (uint32_t)((__ballot(lane_bad) >> hshift) & 0xFFFFFFFFull);
+    const bool go = take && settled && bad_half == 0 && total_bytes <= S.out_n - S.out_base;
+    // 3. the spans as a sub-index: the lockstep pass with every check, writing
+    {
+      const uint32_t ob = S.out_base + bsum - nbytes;
+      decode_regions_lockstep<L, false>(src, src_n, S.lo, S.hi, entry, exitb, hl == 31, ob, ob + nbytes,
+                                        tokens + (uint64_t)seg * kChunk + S.tok_base + (tsum - cnt), m, half, (seg % sps) * kChunk, go,
+                                        lane, s_reg, o);
+    }
+    fresh();
+    const bool lane_failed = go && (o.st != inflate::kOk || o.ntok != cnt);
+    const uint32_t failed_half = (uint32_t)((__ballot(lane_failed) >> hshift) & 0xFFFFFFFFull);
+    uint32_t at = (uint32_t)__shfl((int)o.bit, 31, 32);  // behind the end-of-block code
+    const uint32_t total_tok = (uint32_t)__shfl((int)tsum, 31, 32);
+    if (take) {
+      uint32_t state = kSegRetry, out_base = S.out_base, tok_base = S.tok_base;
+      if (go && !failed_half) {
+        out_base += total_bytes;
+        tok_base += total_tok;
+        state = behind_block(at, s_blk[half].final != 0, out_base);
+      }
+      if (hl == 0) {
+        S.state = state;
+        S.at = at;
+        S.out_base = out_base;
+        S.tok_base = tok_base;
+      }
     }
   }
-  // per segment: first failing region in stream order, token total from the last region lane
-  const uint64_t failed = __ballot(decode && st != inflate::kOk);
-  if (SPEC) {
-    // what follows the block (stored segment: its one block) must be empty stored blocks
-    bool tail_bad = false;
-    if (live && !retry && hl == 31 && (go || raw)) {
-      const uint32_t at = raw ? 40u + 8u * out_n : end_bit;
-      tail_bad = !tail_is_empty(src + lo, seg_bits, at, (src[lo] & 1u) != 0);
-    }
-    if (live && raw && (out_n == 0 || seg_bits >= (1u << 22))) tail_bad = hl == 31;
-    const uint64_t tb = __ballot(tail_bad);
-    if ((tb >> hmask_shift) & 0xFFFFFFFFull) retry = true;
-    if ((failed >> hmask_shift) & 0xFFFFFFFFull) retry = true;
+  __syncthreads();
+  fresh();
+  if (hl == 0 && seg < nseg) {
+    SegInfo si;
+    si.status = S.state == kSegDone ? (uint32_t)inflate::kOk : kRetrySerial;  // (still running: more blocks than this kernel follows)
+    si.ntok = S.raw ? 0u : S.tok_base;
+    si.raw = S.raw;
+    si.out_n = S.out_n;
+    si.raw_off = S.raw_off;
+    info[seg] = si;
   }
-#pragma unroll
-  for (uint32_t h = 0; h < 2; ++h) {
-    const uint64_t fh = (failed >> (32 * h)) & 0xFFFFFFFFull;
-    const uint32_t first_st = fh ? (uint32_t)__builtin_amdgcn_readlane(st, __builtin_amdgcn_readfirstlane(__builtin_ctzll(fh)) + 32 * h) : 0u;
-    const uint32_t total = __builtin_amdgcn_readlane(tok0 + n, 32 * h + 31);
-    if (lane == 32 * h && live) {
-      SegInfo si;
-      si.status = status != inflate::kOk ? status : (fh ? first_st : (uint32_t)inflate::kOk);
-      si.ntok = (status == inflate::kOk && !raw) ? total : 0u;
-      si.raw = raw;
-      si.out_n = out_n;
-      si.raw_off = s_open64[half][0];
-      if (SPEC && retry) si.status = kRetrySerial;
-      info[seg] = si;
-    }
-  }
-}
-
-__attribute__((amdgpu_waves_per_eu(5, 5)))  // 96 VGPRs: what the workgroup's LDS allows per SIMD
-__global__ __launch_bounds__(64, 2) void k_inflate_tokens_sub(const uint8_t* __restrict__ src, uint64_t src_n,
-                                                             const uint64_t* __restrict__ index,
-                                                             const uint32_t* __restrict__ subidx, uint32_t nseg,
-                                                             uint64_t dst_n, uint32_t* __restrict__ tokens,
-                                                             SegInfo* __restrict__ info, uint32_t sps) {
-  tokens_wave<false>(src, src_n, index, subidx, nseg, dst_n, tokens, info, sps);
 }
 
 __attribute__((amdgpu_waves_per_eu(5, 5)))
@@ -651,7 +859,7 @@ __global__ __launch_bounds__(64, 2) void k_inflate_tokens_spec(const uint8_t* __
                                                               const uint64_t* __restrict__ index, uint32_t nseg,
                                                               uint64_t dst_n, uint32_t* __restrict__ tokens,
                                                               SegInfo* __restrict__ info, uint32_t sps) {
-  tokens_wave<true>(src, src_n, index, nullptr, nseg, dst_n, tokens, info, sps);
+  tokens_wave_spec(src, src_n, index, nseg, dst_n, tokens, info, sps);
 }
 
 // inclusive wave scan on the DPP network (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips
@@ -729,7 +937,7 @@ __device__ bool inflate_segment_bytes(const uint8_t* __restrict__ src, uint64_t 
   const uint32_t out_n = si.out_n;
   uint8_t* o = dst + (uint64_t)seg * kChunk;  // 16-byte aligned
 
-  if (si.raw) {
+  if (si.raw & kSegRaw) {
     // stored segment: dword copy from an arbitrarily aligned stream position
     const uint32_t mis = (uint32_t)(si.raw_off & 3);
     const uint64_t w0 = si.raw_off >> 2;

@@ -368,10 +368,11 @@ def test_fuzz_decoder_on_zlib_and_own_streams(compressor):
 
 def test_speculative_index_only_equals_lane_serial(compressor, starfleet, monkeypatch):
     """Index-only streams go through k_inflate_tokens_spec (a wave per two segments: 32 lanes find their token boundaries by
-    decoding ahead of their span, count, and the spans then serve as a sub-index), with k_inflate_tokens -- one lane per
-    segment, the serial decoder itself -- behind it for whatever is not ONE clean block per segment.  Bytes and status must
-    be those of the lane-serial kernel alone (SFH_INFLATE_SERIAL=1) on own streams of every strategy, on zlib streams with
-    several blocks per segment, on damaged streams; and on a large input the speculative kernel must be the faster one."""
+    decoding ahead of their span, count, and the spans then serve as a sub-index; block after block), with k_inflate_tokens
+    -- one lane per segment, the serial decoder itself -- behind it for damaged segments and for segments cut into more than
+    four blocks.  Bytes and status must be those of the lane-serial kernel alone (SFH_INFLATE_SERIAL=1) on own streams of
+    every strategy, on zlib streams with one, several and dozens of blocks per segment, on damaged streams; which kernel
+    finished a segment is checked (SFH_DBG_SEGINFO); and on a large input the speculative kernel must be the faster one."""
     import os
 
     import torch
@@ -387,18 +388,32 @@ def test_speculative_index_only_equals_lane_serial(compressor, starfleet, monkey
             for strategy, bb in (("auto", 262144), ("dynamic", 32768), ("dynamic", 131072), ("fixed", 65536)):
                 stream = np.frombuffer(compressor.compress(data, strategy=strategy, block_bytes=bb), np.uint8).copy()
                 cases.append((f"{name}/{strategy}/{bb}", stream, compressor.last_index(), data, bb))
-        # zlib: a sync flush every 32 KiB, level 1 on mixed data closes blocks inside the segments as well
+        # zlib with a full flush every 32 KiB.  memLevel 6 closes a block every 4,095 symbols -- two to four blocks per
+        # segment, which the speculative kernel follows; memLevel 1 every 127 -- dozens, which it leaves to the serial one
         mixed = synth.gen_mixed(1 << 20, seed=8, stripe=1 << 14)[: 9 * CHUNK + 321]
-        for level in (1, 6, 9):
-            co = zlib.compressobj(level, zlib.DEFLATED, -15, 1 if level == 1 else 8)  # memLevel 1: 128-symbol blocks' worth of buffer
-            nch = (mixed.size + CHUNK - 1) // CHUNK
-            zs = [co.compress(mixed[c * CHUNK:(c + 1) * CHUNK].tobytes()) + co.flush(zlib.Z_FINISH if c == nch - 1 else zlib.Z_FULL_FLUSH)
+        text = synth.gen_text(6 * CHUNK + 77, seed=12)
+        for zname, zdata, level, mem in (("zlib6m8", mixed, 6, 8), ("zlib9m8", mixed, 9, 8), ("zlib6m6", text, 6, 6), ("zlib1m1", mixed, 1, 1)):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, mem)
+            nch = (zdata.size + CHUNK - 1) // CHUNK
+            zs = [co.compress(zdata[c * CHUNK:(c + 1) * CHUNK].tobytes()) + co.flush(zlib.Z_FINISH if c == nch - 1 else zlib.Z_FULL_FLUSH)
                   for c in range(nch)]
             index = np.concatenate([[0], np.cumsum([len(p) for p in zs])]).astype(np.uint64)
-            cases.append((f"zlib{level}", np.frombuffer(b"".join(zs), np.uint8).copy(), index, mixed, 32768))
+            cases.append((zname, np.frombuffer(b"".join(zs), np.uint8).copy(), index, zdata, 32768))
         for name, stream, index, data, bb in cases:
             a = compressor.decompress(stream, index, data.size, block_bytes=bb)
+            # who finished each segment (SFH_DBG_SEGINFO: bit 1 of word 2 = the lane-serial kernel): every valid segment with
+            # output is the speculative kernel's, with up to four blocks that hold output; an empty input is the serial kernel's
+            nseg = index.size - 1
+            info = compressor.debug(_capi.DBG_SEGINFO, nseg)
+            by_serial = int(((info[:, 2] >> 1) & 1).sum())
+            if name == "zlib1m1":
+                assert by_serial >= nseg - 1, name  # (the ragged last segment has few enough blocks)
+            else:
+                assert by_serial == (0 if data.size else nseg), (name, by_serial)
+            if name == "zlib6m6":
+                assert int(info[:-1, 1].min()) > 4096, "more symbols than zlib keeps per block: several blocks in every whole segment"
             b = serial.decompress(stream, index, data.size, block_bytes=bb)
+            assert int(((serial.debug(_capi.DBG_SEGINFO, nseg)[:, 2] >> 1) & 1).sum()) == nseg, name
             assert a == b and a == (data.tobytes(), 0), name
         # damage: same status, same bytes
         nsame = 0
