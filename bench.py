@@ -612,7 +612,7 @@ def main():
                              "kernel_ms": {k: round(v, 4) for k, v in comp.inflate_ms().items()}}
         decomp["note"] = ("sub_indexed: chunk offsets + 32 entries per chunk (sfh_copy_index, sfh_copy_subindex), 32 lanes per "
                           "segment; segment_indexed: chunk offsets only, 32 lanes per segment that find their token boundaries speculatively "
-                          "(k_inflate_tokens_spec; any indexed stream, the lane-serial kernel behind it for multi-block segments); "
+                          "(k_inflate_tokens_spec; any indexed stream, the lane-serial kernel behind it for segments of more than four blocks); "
                           f"byte copies strip by strip (block_bytes {bb})")
         del back, stream_t
         # a FOREIGN indexed stream: zlib -6 with Z_FULL_FLUSH every 32 KiB over the first 64 MiB of the same input -- what the

@@ -237,9 +237,9 @@ int sfh_copy_index(sfh_ctx* ctx, uint64_t* dst, size_t entries, int dst_on_devic
  * stored segment.  Optional side information: with it the 32 lanes that decode one segment's Huffman codes side
  * by side are TOLD where their regions start (the decoder checks it against the stream: a wrong sub-index is an
  * error, never wrong output).  Streams from elsewhere have none: their segments are decoded by 32 lanes as well,
- * which find their token boundaries speculatively (a segment of one coded or stored block followed by empty stored
- * blocks, what Z_FULL_FLUSH leaves; about 1.6 x the sub-indexed time), and by one lane per segment where a
- * segment holds several blocks or is damaged -- the serial decoder itself, statuses included
+ * which find their token boundaries speculatively, block after block (up to four blocks with output per segment
+ * plus the empty stored blocks a flush leaves; about 1.5 x the sub-indexed time), and by one lane per segment where
+ * a segment is cut into more blocks or is damaged -- the serial decoder itself, statuses included
  * (SFH_INFLATE_SERIAL=1 in the environment of sfh_create: that kernel for every segment). */
 #define SFH_SUBINDEX_WORDS 64u
 int sfh_copy_subindex(sfh_ctx* ctx, uint32_t* dst, size_t words, int dst_on_device, void* stream);
