@@ -615,12 +615,12 @@ def main():
                           "(k_inflate_tokens_spec; any indexed stream, the lane-serial kernel behind it for segments of more than four blocks); "
                           f"byte copies strip by strip (block_bytes {bb})")
         del back, stream_t
-        # a FOREIGN indexed stream: zlib -6 with Z_FULL_FLUSH every 32 KiB over the first 64 MiB of the same input -- what the
+        # a FOREIGN indexed stream: zlib -6 with Z_FULL_FLUSH every 32 KiB over the first 256 MiB of the same input -- what the
         # reference's own flushed fixtures are (tools/deflate_compress.py --flush); segment index only, every segment independent
         if not args.no_secondary:
             import zlib
             import numpy as np
-            zn = min(n, 64 << 20)
+            zn = min(n, 256 << 20)
             host = data[:zn].cpu().numpy()
             co = zlib.compressobj(6, zlib.DEFLATED, -15)
             nseg = (zn + 32767) // 32768
@@ -638,7 +638,10 @@ def main():
                 _, zstatus = comp.decompress_tensor(zstream, zidx, zn, out=zback, block_bytes=32768)
             torch.cuda.synchronize()
             td = (time.perf_counter() - td) / reps
+            from starflate_amd import _capi
+            by_serial = int(((comp.debug(_capi.DBG_SEGINFO, nseg)[:, 2] >> 1) & 1).sum())
             decomp["zlib_made_segment_indexed"] = {
+                "segments": nseg, "segments_finished_by_the_lane_serial_kernel": by_serial,
                 "value": round(zn / td / 2**20, 1), "unit": "MiB/s of output", "ms": round(td * 1e3, 3), "bytes": zn,
                 "stream_bytes": int(zraw.size), "status": zstatus, "equal_to_input": bool(torch.equal(zback, data[:zn])),
                 "kernel_ms": {k: round(v, 4) for k, v in comp.inflate_ms().items()},
