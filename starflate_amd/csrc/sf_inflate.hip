@@ -186,6 +186,8 @@ struct RegionOut {
   uint32_t bit;    // where the lane stopped (bit offset from the segment's first byte)
   uint32_t bytes;  // output bytes of its tokens
   bool eob;        // it met the end-of-block code
+  // COUNT: a checkpoint -- the first period start at or behind cp_target: its bit offset (0: none), tokens and bytes before it
+  uint32_t cp_bit, cp_tok, cp_bytes;
 };
 
 // COUNT (k_inflate_tokens_spec's passes before the last): nothing is written and nothing is known about the output
@@ -195,7 +197,7 @@ template <class L, bool COUNT>
 __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint64_t seg_begin, uint64_t seg_end,
                                         uint32_t bit_begin, uint32_t bit_end, bool until_eob, uint32_t out_begin,
                                         uint32_t out_end, uint32_t* tokens, const uint8_t* m, uint32_t half, uint32_t hist,
-                                        bool decode, uint32_t lane, RegionLds& R, RegionOut& out) {
+                                        bool decode, uint32_t lane, RegionLds& R, RegionOut& out, uint32_t cp_target = ~0u) {
   using namespace inflate;
   uint32_t st = kOk;
   bool active = decode;
@@ -376,7 +378,15 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
 
   // the first window: loaded and waited for on the spot
   load_window(true);
+  uint32_t cp_ab = 0, cp_tok = 0, cp_bytes = 0;  // COUNT: see RegionOut
+  const uint32_t cp_at = (COUNT && cp_target != ~0u) ? bias + cp_target : ~0u;
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    if (COUNT) {
+      const bool hit = active && cp_ab == 0 && ab >= cp_at;
+      cp_ab = hit ? ab : cp_ab;
+      cp_tok = hit ? n : cp_tok;
+      cp_bytes = hit ? out_pos - out_begin : cp_bytes;
+    }
     // period start: last period's window (arrived meanwhile) into LDS, last period's tokens out, next window's loads
     window_to_lds();
     flush();
@@ -393,6 +403,9 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
   out.bit = ab - bias;
   out.bytes = out_pos - out_begin;
   out.eob = eob;
+  out.cp_bit = cp_ab ? cp_ab - bias : 0u;
+  out.cp_tok = cp_tok;
+  out.cp_bytes = cp_bytes;
   if (COUNT) {
     out.st = (st == kOk && ab > lim_ab) ? (uint32_t)kSrcTooSmall : st;
     return;
@@ -438,6 +451,7 @@ __device__ void decode_regions_lockstep(const uint8_t* src, uint64_t src_n, uint
 // in order; an error of any kind leaves it to k_inflate_tokens (info.status = kRetrySerial, launched behind this kernel for
 // those segments only): statuses are the serial decoder's by construction.
 constexpr uint32_t kSpecLookBack = 512;
+constexpr uint32_t kSpecCheck = 1024;  // the checkpoint of a counting pass: this many bits behind the lane's start
 
 __device__ __forceinline__ void tokens_wave_sub(const uint8_t* __restrict__ src, uint64_t src_n, const uint64_t* __restrict__ index,
                                             const uint32_t* __restrict__ subidx, uint32_t nseg, uint64_t dst_n,
@@ -774,29 +788,54 @@ __device__ __forceinline__ void tokens_wave_spec(const uint8_t* __restrict__ src
                                        look, lane, s_reg, o);
       if (look && o.st == inflate::kOk && !o.eob) entry = o.bit;
     }
-    // 2. count, until every lane starts where its predecessor ended
+    // 2. count, until every lane starts where its predecessor ended.  A lane that has to start over has usually been right
+    // from a few hundred bits into its span on (the wrong start fell in with the true chain there), so the first attempt
+    // leaves a checkpoint kSpecCheck bits into the span -- a token boundary of ITS chain with the tokens and bytes before it
+    // -- and the second attempt stops at the first boundary at or behind it: the same bit, and what the first attempt counted
+    // from there on stands (zlib-made streams: four waves in ten start a lane over; a whole pass each before this, a quarter).
     uint32_t exitb = 0, cnt = 0, nbytes = 0, lst = inflate::kOk;
-    bool leob = false, need = take, settled = false;
+    uint32_t cp_bit = 0, cp_tok = 0, cp_bytes = 0;
+    bool leob = false, need = take, settled = false, tried_short = false;
 #pragma nounroll
-    for (uint32_t round = 0; round < 34; ++round) {
+    for (uint32_t round = 0; round < 66; ++round) {
       fresh();
+      const bool shortcut = need && cp_bit != 0 && !tried_short && cp_bit > entry;
       // (the bytes the segment has left, at most: no lane can produce more, and a speculative one on a wrong chain stops there)
-      decode_regions_lockstep<L, true>(src, src_n, S.lo, S.hi, entry, nom1 < entry ? entry : nom1, hl == 31, 0u,
-                                       S.out_n - S.out_base, nullptr, m, half, 0x40000000u, need, lane, s_reg, o);
-      if (need) {
+      decode_regions_lockstep<L, true>(src, src_n, S.lo, S.hi, entry, shortcut ? cp_bit : (nom1 < entry ? entry : nom1),
+                                       hl == 31 && !shortcut, 0u, S.out_n - S.out_base, nullptr, m, half, 0x40000000u, need, lane,
+                                       s_reg, o, shortcut ? ~0u : entry + kSpecCheck);
+      bool again = false;  // the shortcut did not meet the checkpoint: the whole span next round
+      if (need && shortcut) {
+        tried_short = true;
+        if (o.st == inflate::kOk && !o.eob && o.bit == cp_bit) {
+          cnt = o.ntok + (cnt - cp_tok);
+          nbytes = o.bytes + (nbytes - cp_bytes);
+          cp_tok = o.ntok;  // the checkpoint, seen from the new start
+          cp_bytes = o.bytes;
+        } else {
+          again = true;
+        }
+      } else if (need) {
         exitb = o.bit;
         cnt = o.ntok;
         nbytes = o.bytes;
         lst = o.st;
         leob = o.eob;
+        cp_bit = o.cp_bit;
+        cp_tok = o.cp_tok;
+        cp_bytes = o.cp_bytes;
+        tried_short = false;
       }
       const uint32_t pe = (uint32_t)__shfl_up((int)exitb, 1);
-      need = take && hl != 0 && entry != pe;
+      need = take && hl != 0 && (entry != pe || again);
       if (__ballot(need) == 0) {
         settled = true;
         break;
       }
-      if (need) entry = pe;
+      if (need) {
+        tried_short = tried_short && entry == pe;  // (a new start may take the shortcut again)
+        entry = pe;
+      }
     }
     // every lane is exact now: an error anywhere, a last lane without its end-of-block code, or more bytes than the segment
     // has left leaves the segment to the serial kernel
