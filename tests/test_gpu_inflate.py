@@ -392,7 +392,11 @@ def test_speculative_index_only_equals_lane_serial(compressor, starfleet, monkey
         # segment, which the speculative kernel follows; memLevel 1 every 127 -- dozens, which it leaves to the serial one
         mixed = synth.gen_mixed(1 << 20, seed=8, stripe=1 << 14)[: 9 * CHUNK + 321]
         text = synth.gen_text(6 * CHUNK + 77, seed=12)
-        for zname, zdata, level, mem in (("zlib6m8", mixed, 6, 8), ("zlib9m8", mixed, 9, 8), ("zlib6m6", text, 6, 6), ("zlib1m1", mixed, 1, 1)):
+        # (level 1 and periodic data: wrong starts fall in late or never, lanes start over many times in a row -- the
+        # checkpoint shortcut and its fall-back to the whole span)
+        periodic = np.concatenate([np.tile(rng.integers(0, 256, p, dtype=np.uint8), 3 * CHUNK // p + 1)[: 3 * CHUNK] for p in (7, 300, 4099)])
+        for zname, zdata, level, mem in (("zlib6m8", mixed, 6, 8), ("zlib9m8", mixed, 9, 8), ("zlib6m6", text, 6, 6), ("zlib1m1", mixed, 1, 1),
+                                         ("zlib1m8", text, 1, 8), ("zlib6m8p", periodic, 6, 8), ("zlib1m8p", periodic, 1, 8)):
             co = zlib.compressobj(level, zlib.DEFLATED, -15, mem)
             nch = (zdata.size + CHUNK - 1) // CHUNK
             zs = [co.compress(zdata[c * CHUNK:(c + 1) * CHUNK].tobytes()) + co.flush(zlib.Z_FINISH if c == nch - 1 else zlib.Z_FULL_FLUSH)
