@@ -658,7 +658,7 @@ __device__ __forceinline__ void tokens_wave_spec(const uint8_t* __restrict__ src
     const uint64_t lo = live ? index[seg] : 0, hi = live ? index[seg + 1] : 0;
     const uint64_t obase = (uint64_t)seg * kChunk;
     const uint32_t out_n = (live && dst_n > obase) ? (uint32_t)(dst_n - obase < kChunk ? dst_n - obase : kChunk) : 0u;
-    const uint32_t seg_bits = (hi > lo && hi - lo < (1ull << 19)) ? 8u * (uint32_t)(hi - lo) : 0u;
+    const uint32_t seg_bits = (hi > lo && hi - lo < (1ull << 16)) ? 8u * (uint32_t)(hi - lo) : 0u;
     SegState z;
     z.lo = lo;
     z.hi = hi;
@@ -668,7 +668,9 @@ __device__ __forceinline__ void tokens_wave_spec(const uint8_t* __restrict__ src
     z.at = 0;
     z.out_base = 0;
     z.tok_base = 0;
-    // not for this kernel: no output, no input, an index that does not hold, more than 512 KiB of stream for 32 KiB of output
+    // not for this kernel: no output, no input, an index that does not hold, 64 KiB or more of stream for 32 KiB of output (a
+    // stored segment is 32 KiB + 5 bytes, a coded one smaller: nothing well-formed is that long, and the counting rounds
+    // have no business walking what the serial decoder gives up on after 32 KiB of output)
     z.state = !live ? (uint32_t)kSegDone : ((out_n == 0 || seg_bits == 0 || hi > src_n) ? (uint32_t)kSegRetry : (uint32_t)kSegRun);
     z.raw = 0;
     s_st[half] = z;

@@ -419,6 +419,15 @@ def test_speculative_index_only_equals_lane_serial(compressor, starfleet, monkey
             b = serial.decompress(stream, index, data.size, block_bytes=bb)
             assert int(((serial.debug(_capi.DBG_SEGINFO, nseg)[:, 2] >> 1) & 1).sum()) == nseg, name
             assert a == b and a == (data.tobytes(), 0), name
+        # a segment of 64 KiB or more of stream (here: 14,000 empty stored blocks behind the data) is the serial kernel's
+        small = text[:5000]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        padded = co.compress(small.tobytes()) + co.flush(zlib.Z_SYNC_FLUSH) + 14000 * b"\x00\x00\x00\xff\xff" + b"\x01\x00\x00\xff\xff"
+        pidx = np.array([0, len(padded)], np.uint64)
+        for c in (compressor, serial):
+            assert c.decompress(padded, pidx, small.size, block_bytes=32768) == (small.tobytes(), 0)
+        compressor.decompress(padded, pidx, small.size, block_bytes=32768)
+        assert int(compressor.debug(_capi.DBG_SEGINFO, 1)[0, 2]) & 2
         # damage: same status, same bytes
         nsame = 0
         for name, stream, index, data, bb in cases[::3]:
