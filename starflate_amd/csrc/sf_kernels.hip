@@ -209,6 +209,27 @@ __device__ __forceinline__ void rank8x2(const uint32_t* d32, uint32_t a0, uint32
   lb = rank_of(a0, a1, q0, q1, q2, cb & 3, maxlen);
 }
 
+// SENSITIVITY PROBE (diagnostic builds only: -DSF_PROBE_STAGE / _MATCH / _PARSE / _EMIT=<n>, tools/exp/probe_phases.sh): n dead
+// vector instructions (v_xor of a register with itself, the cheap issue class) in one phase of k_lz77 -- what a phase's
+// time costs the kernel per instruction says whether taking instructions OUT of it can pay.  Compiled out otherwise.
+template <int N>
+__device__ __forceinline__ void probe_valu(uint32_t& r) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("v_xor_b32 %0, %0, %0" : "+v"(r));
+}
+#ifndef SF_PROBE_STAGE
+#define SF_PROBE_STAGE 0
+#endif
+#ifndef SF_PROBE_MATCH
+#define SF_PROBE_MATCH 0
+#endif
+#ifndef SF_PROBE_PARSE
+#define SF_PROBE_PARSE 0
+#endif
+#ifndef SF_PROBE_EMIT
+#define SF_PROBE_EMIT 0
+#endif
+
 // Workgroup barrier that orders LDS traffic only: the match step keeps a global store (the position's distance, see
 // k_lz77) in flight across its barriers, which __syncthreads() would wait for twice per step
 __device__ __forceinline__ void lds_barrier() {
@@ -294,7 +315,6 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
   const uint32_t n = (uint32_t)((n_total - sbase) < (uint64_t)strip_bytes ? (n_total - sbase) : strip_bytes);
   const uint32_t chunk0 = strip * (strip_bytes / kChunk);
   const uint8_t* const sp = src + sbase;
-
   // four bytes of the strip at `pos` (multiple of 4), zero beyond n
   auto load4 = [&](uint32_t pos) -> uint32_t {
     if (pos + 4 <= n) return *reinterpret_cast<const uint32_t*>(sp + pos);
@@ -329,6 +349,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
   bool skip = false;                     // stored fast path (uniform): set after kSkipSpan positions of a chunk
   bool short_probe = false;              // (uniform) the strip's previous chunk took it: only kSkipProbe positions of this one's span are searched
 
+  // @phase round.head trips=1 note=round bookkeeping
   for (uint32_t r = 0; r < nrounds; ++r) {
     const uint32_t rb = r * kRound;                         // strip position of the round's first byte
     const uint32_t rc = r % kRoundsPerChunk;                // round within its chunk
@@ -344,6 +365,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
 
     // RECENT: the histogram's place holds the match phase's posts; its counts wait here meanwhile
     [[maybe_unused]] uint32_t hsave = 0;
+    // @phase stage trips=1
     // ---- stage: shift the window down by one round, append the prefetched 4 KiB ----
     {
       uint4* s4 = reinterpret_cast<uint4*>(smem + L_DATA);
@@ -357,6 +379,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       s4[K1_THREADS + t] = c1;
       if (t < kUnits - 2 * K1_THREADS) s4[2 * K1_THREADS + t] = c2;
       *reinterpret_cast<uint2*>(&s_data[(kWindow + kLook) / 4 + 2 * t]) = make_uint2(pre_lo, pre_hi);
+      if constexpr (SF_PROBE_STAGE > 0) { uint32_t pr = t; probe_valu<SF_PROBE_STAGE>(pr); }
       // (RECENT asks for them behind the match phase, whose serial pass wants the registers: parse and emit hide the latency)
       if (!RECENT && r + 1 < nrounds) {
         pre_lo = load4(rb + kRound + kLook + 8 * t);
@@ -364,6 +387,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       }
       // age the step codes: all move down by kEpochSteps steps, saturating at 0 -- ONE packed 16-bit instruction per
       // bucket (v_pk_sub_u16 clamp).  What falls below 1 << 10 (step field 0) is older than the window: empty
+      // @phase stage.ageing trips=1 depth=2 note=two iterations every second round
       if (rb / STEP - ebase >= kEpMax) {
         constexpr uint32_t kSub2 = (kEpS << SH) * 0x00010001u;
         uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
@@ -378,12 +402,14 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         }
         ebase += kEpS;
       }
+      // @phase stage.end trips=1 note=closing barrier
       // (the barrier at the top of the stage follows the previous round's last histogram update)
       if constexpr (RECENT) hsave = t < kHistStride ? s_hist[t] : 0u;
       __syncthreads();
     }
     stamp(0);
 
+    // @phase skip trips=0 note=stored fast path (never on text)
     if (skip) {
       // the chunk's first kSkipSpan positions were (almost) all literals: no search, no insertion,
       // every position is a literal
@@ -407,6 +433,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       tot_tok += qn;
       tot_items += qn;
     } else {
+      // @phase match.setup trips=1
       // ---- match finding over this round ----
       uint32_t nsteps = (qn + STEP - 1) / STEP;
       if (short_probe && rc == 0) {
@@ -434,6 +461,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       // 2 * 3 * kRound is a multiple of 128)
       const uint32_t stage_off = (2u * tot_items + 127u) & ~127u;  // byte offset of the round's slots in the chunk's item array
       __builtin_amdgcn_s_setprio(2);
+      // @phase match.chain trips=0
       if constexpr (CHAIN) {
         // ---- exact hash chains (the specification's chain_depth > 0) ----
         // A step is 1024 positions, one per thread.  INSERTION is serial in the position -- a position's link is the latest
@@ -737,6 +765,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
           pre_hi = load4(rb + kRound + kLook + 8 * t + 4);
         }
       } else {
+        // @phase match.setup2 trips=1
         // A step has 512 searches for 1024 threads: the even positions of 1024 (STRIDE2), or all of 512 (thorough).  The
         // two halves of the workgroup (waves 0..7 and 8..15) take the steps in turn and split a search in two: in the
         // INTERVAL before step `it` is inserted, the half whose turn it is does the first part of step `it` -- bytes,
@@ -767,6 +796,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         uint8_t* const gst = reinterpret_cast<uint8_t*>(gi) + stage_off;
         // first part -> second part.  (LONG: f_m0.. f_q1 carry the four far candidates as KEYS rank << 16 | 0xFFFF - distance)
         uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;
+        // @phase match.loop trips=9 depth=2 note=nine intervals for eight steps
         for (uint32_t it = 0; it <= nsteps; ++it) {
           uint32_t ins_h = 0, ins_v = 0;
           [[maybe_unused]] uint32_t ins2_h = 0, ins2_v = 0;  // LONG: the same for the seven-byte table; STRIDE2: for the odd position behind
@@ -780,6 +810,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
           };
           if ((it & 1) == grp) {
             if (it < nsteps) {
+              // @phase match.first trips=4 depth=2 note=a wave does the first part of every second step
               // ---- first part of the search at position ps of step `it` ----
               const uint32_t sb = it * STEP;            // (uniform) the step's first position, round-relative
               const uint32_t wb = sb + pswK;
@@ -844,6 +875,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             }
           } else {
             if (it >= 1) {
+              // @phase match.second trips=4 depth=2
               // ---- second part of the search at position ps of step it - 1 ----
               const uint32_t sb = (it - 1) * STEP;      // (uniform) that step's first position, round-relative
               const uint32_t ad1 = sb + psK1;           // LDS address of the byte before the position
@@ -914,8 +946,11 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
               }
             }
           }
+          if constexpr (SF_PROBE_MATCH > 0) { uint32_t pr = t; probe_valu<SF_PROBE_MATCH>(pr); }
+          // @phase match.barrier trips=8 depth=2
           if (it == nsteps) break;
           lds_barrier();  // every read of the table as it stands before step `it` precedes the step's insertions
+          // @phase match.insert trips=4 depth=2
           if (has_ins) {  // (the half that did the step's first part)
             // {code, old newest}: the upper half of code:bucket.  (Positions without kMinMatch bytes left insert like the
             // rest, which nothing can observe: every position after them in the strip is such a position too and takes no
@@ -935,12 +970,15 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
               if (hp2 != ins2_h && ins2_h != ins_h) atomicMax(&s_table[ins2_h], ins2_v);
             }
           }
+          // @phase match.barrier2 trips=8 depth=2
           lds_barrier();  // insertions complete before the near reads
         }
+        // @phase match.tail trips=1
         // STRIDE2: the last position of the last step that ran is odd and has no successor in its step: no match.  Its length
         // lives in the low half of the byte behind the step's (nobody wrote it in this round; after all steps it is the pad)
         if (STRIDE2 && t == 0 && nsteps < kRound / STEP) smem[L_LEN4 + nsteps * (STEP / 2)] = 0;
       }
+      // @phase parse.begin trips=1 note=barrier, staged-distance load
       __builtin_amdgcn_s_setprio(1);  // the parse: behind the other workgroup's match, ahead of its emit
       __syncthreads();  // (also: the staged distances are visible to the whole workgroup)
       stamp(1);
@@ -956,6 +994,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       } else {
         Dld = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(gi) + (uint64_t)(stage_off + 16u * t));
       }
+      // @phase inherit
       auto staged_arrive = [&]() {
         D0 = Dld.x; D1 = Dld.y;
         if constexpr (STRIDE2) {
@@ -978,6 +1017,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         }
       };
 
+      // @phase parse.take trips=1
       // ---- parse: wave-local.  Thread t owns the eight positions [8t, 8t+8) of the round, a wave one
       // kRegion-byte parse region (matches never cross it), so the greedy/lazy chain of a region is
       // resolved inside one wave, in registers, with no barrier:
@@ -993,6 +1033,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       // then one barrier and
       //   emit    : every lane writes its (at most eight) items at their compact place, + histogram
       const uint32_t pb = 8 * t;                       // the lane's first position, round-relative
+      if constexpr (SF_PROBE_PARSE > 0) { uint32_t pr = t; probe_valu<SF_PROBE_PARSE>(pr); }
       const uint32_t nv = qn > pb ? (qn - pb < 8 ? qn - pb : 8u) : 0u;  // its valid positions
       uint32_t T;                                      // take bits of the eight positions
       uint32_t N;                                      // their 4-bit lengths
@@ -1041,6 +1082,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         T = bits;
       }
       stamp(2);
+      // @phase parse.transfer trips=1
       uint32_t marks = 0;                              // chain positions among the eight
       uint32_t cap_mp = 8, cap_len = 0;                // the capped chain match that was extended (at most one per lane)
       bool cap_run = false;                            // ... and whether it turned out to be a run (distance 1)
@@ -1075,6 +1117,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             ehi = (tm1 & ehi) | (~tm1 & g1);
           }
         }
+        // @phase inherit
         const uint32_t vmask = (1u << nv) - 1u;          // the lane's valid positions
         // The chain enters at local offset e (< nv).  A match that was capped at match time (kCap bytes or more: it leaves
         // the lane whatever its length) is extended here, once per position: the lane itself looks at the next kLaneExt
@@ -1086,6 +1129,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
           cap_mp = cap_mp >= 16 ? 8u : cap_mp;           // a request of an earlier walk is void
           const uint32_t ex = __builtin_amdgcn_perm(ehi, elo, e) & 0xFFu;
           uint32_t pos = ex;
+          // @phase +ext trips=0.5 note=some lane enters at a capped match
           if (ex & 0x80u) {                              // capped at match time: extend (once per position)
             const uint32_t mp = ex & 7u;
             uint32_t len;
@@ -1123,6 +1167,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             }
             pos = mp + len;
           }
+          // @phase inherit
           marks = __builtin_amdgcn_perm(mhi, mlo, e) & vmask;
           exit_abs = lb + pos;                           // (pos >= 8: the chain has left the lane)
         };
@@ -1134,6 +1179,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         auto extend_first = [&]() {
           const uint64_t need = __builtin_amdgcn_ballot_w64(cap_mp >= 16);
           if (need == 0) return false;
+          // @phase +serve trips=0.1 note=a lane's match is still open after 32 bytes: the wave extends it
           const uint32_t src_lane = (uint32_t)__builtin_ctzll(need);
           const uint32_t xat = (uint32_t)__builtin_amdgcn_readlane((int)(pb + cap_mp - 16), (int)src_lane);  // round-relative position
           const uint32_t xd = (uint32_t)__builtin_amdgcn_readlane((int)dm1_of((cap_mp - 16) & 7), (int)src_lane) + 1u;
@@ -1182,9 +1228,11 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
           }
           return true;
         };
+        // @phase parse.walk0 trips=1 note=speculative walk from entry 0
         staged_arrive();
         uint32_t entry = 0;
         if (nv) walk(0);
+        // @phase parse.reconcile trips=3.5 depth=2 note=2.5 rounds on text + the round that finds nothing changed
 #pragma unroll 1
         for (uint32_t round = 0; round < 128; ++round) {
           const bool served = extend_first();
@@ -1201,6 +1249,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         }
       }
       stamp(3);
+      // @phase parse.counts trips=1
       // tokens (low half) and matches (high half: a match takes two items) before this lane, per wave, per round
       const uint32_t cm = marks & T;                   // chain positions that are matches
       const uint32_t mine = (uint32_t)__popc(marks) | ((uint32_t)__popc(cm) << 16);
@@ -1227,6 +1276,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       stamp(4);
       __builtin_amdgcn_s_setprio(0);  // emit, flush and the next round's stage: nothing waits for them
 
+      // @phase skip_now trips=0
       if (skip_now) {
         // (qn == kRound here: the chunk is longer than the span)
         const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + 8 * t]);
@@ -1236,8 +1286,10 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         skip = true;
         rtotal = kRound;  // tokens = items = positions
       } else
+      // @phase emit.head trips=1
       // ---- emit: the lane's chain positions -> items (compact, chunk order) + histogram ----
       if (marks) {
+        if constexpr (SF_PROBE_EMIT > 0) { uint32_t pr = t; probe_valu<SF_PROBE_EMIT>(pr); }
         const uint32_t before = wbase + incl - mine;
         const uint32_t ib0 = 2u * (tot_items + (before & 0xFFFFu) + (before >> 16));  // byte offset of the lane's first item
         // items of the lane before position k: one per token before it, one more per match before it -- one
@@ -1256,6 +1308,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         auto put_item = [&](uint32_t byte_off, uint32_t v) {
           *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)byte_off) = (uint16_t)v;
         };
+        // @phase emit.literals trips=1 note=eight slots
         // the literals, slot by slot (a match head only moves the item offset on)
         const uint32_t lits = marks & ~cm;
 #pragma unroll
@@ -1266,6 +1319,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             atomicAdd(&s_hist[b], 1u);
           }
         }
+        // @phase emit.matches trips=1 note=two rounds
         // the matches: a lane's eight positions hold at most two taken ones (kMinMatch = 4), so two rounds over
         // the match bits cost less than a match path in each of the eight slots.  Lengths are counted raw (k_plan
         // folds them into symbols)
@@ -1290,12 +1344,14 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
           }
         }
       }
+      // @phase emit.end trips=1
       tot_tok += rtotal & 0xFFFFu;
       tot_items += (rtotal & 0xFFFFu) + (rtotal >> 16);
       if constexpr (STAMPS) __syncthreads();
       stamp(5);
     }
 
+    // @phase chunk.end trips=0.25 note=once per chunk of four rounds
     // ---- end of a chunk: its counts and histogram go out, the histogram starts over ----
     if (rc == kRoundsPerChunk - 1 || r + 1 == nrounds) {
       __syncthreads();  // this round's histogram updates are complete
@@ -1310,6 +1366,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
     }
     // the next round's first barrier orders this round's LDS reads before its writes
   }
+  // @phase (prologue/epilogue) trips=0
   if (nrounds == 0) {  // empty input: one empty chunk
     for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) hist_out[(uint64_t)chunk0 * kHistStride + idx] = (idx == 256) ? 1u : 0u;
     if (t == 0) { ntok_out[chunk0] = 0; nitems_out[chunk0] = 0; }
