@@ -346,8 +346,9 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
   static_assert(kEpMax - kEpS >= kWindow / STEP, "the epoch stays a window behind");
   uint32_t ebase = 0u - kWindow / STEP;
   uint32_t tot_tok = 0, tot_items = 0;   // of the chunk in flight (uniform)
-  bool skip = false;                     // stored fast path (uniform): set after kSkipSpan positions of a chunk
+  bool skip = false;                     // stored fast path (uniform): the chunk in hand took it (decided behind its first round's parse)
   bool short_probe = false;              // (uniform) the strip's previous chunk took it: only kSkipProbe positions of this one's span are searched
+  bool lds_stale = false;                // (uniform) the rounds behind a chunk's probe round were taken in one go: the window in LDS is not the strip's
 
   // @phase round.head trips=1 note=round bookkeeping
   for (uint32_t r = 0; r < nrounds; ++r) {
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
     }
     // (the stored fast path is decided at the end of a chunk's first round, behind its parse: skip_now below)
 
+    bool chunk_done = false;  // (uniform) stored fast path: the chunk's later rounds were taken together with this one (skip_now)
     // RECENT: the histogram's place holds the match phase's posts; its counts wait here meanwhile
     [[maybe_unused]] uint32_t hsave = 0;
     // @phase stage trips=1
@@ -371,14 +373,33 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       uint4* s4 = reinterpret_cast<uint4*>(smem + L_DATA);
       constexpr uint32_t kUnits = (kWindow + kLook) / 16, kOff = kRound / 16;  // 2050 units move down by 512
       static_assert(kUnits > 2 * K1_THREADS && kUnits <= 3 * K1_THREADS, "shift: three units per thread");
-      const uint4 c0 = s4[kOff + t], c1 = s4[kOff + K1_THREADS + t];
-      uint4 c2 = make_uint4(0, 0, 0, 0);
-      if (t < kUnits - 2 * K1_THREADS) c2 = s4[kOff + 2 * K1_THREADS + t];
-      __syncthreads();  // every read of the old window (this shift, the previous round's emit) precedes the writes
-      s4[t] = c0;
-      s4[K1_THREADS + t] = c1;
-      if (t < kUnits - 2 * K1_THREADS) s4[2 * K1_THREADS + t] = c2;
-      *reinterpret_cast<uint2*>(&s_data[(kWindow + kLook) / 4 + 2 * t]) = make_uint2(pre_lo, pre_hi);
+      const bool reload = lds_stale;  // (uniform)
+      if (reload) {
+        // behind a chunk that took the stored fast path (its later rounds never came through here): the window, this
+        // round and the look-ahead come from the input again -- the strip's last 32 KiB, read a few microseconds ago --
+        // instead of from three shifts per skipped chunk.  (rb >= kChunk: the skipped chunk lies in this strip.  Every
+        // reader of the old LDS bytes is behind the barrier at the skipped chunk's end.)
+        constexpr uint32_t kAll = (kWindow + kRound + kLook) / 16;
+        static_assert(kAll <= 3 * K1_THREADS, "reload: three units per thread");
+        const uint8_t* const wp = sp + (rb - kWindow);
+        if (rb + kRound + kLook <= n) {
+#pragma unroll
+          for (uint32_t k = 0; k < 3; ++k)
+            if (k * K1_THREADS + t < kAll) s4[k * K1_THREADS + t] = reinterpret_cast<const uint4*>(wp)[k * K1_THREADS + t];
+        } else {  // the strip ends inside: word by word, zeros beyond the end
+          for (uint32_t i = t; i < 4 * kAll; i += K1_THREADS) s_data[i] = load4(rb - kWindow + 4 * i);
+        }
+        lds_stale = false;
+      } else {
+        const uint4 c0 = s4[kOff + t], c1 = s4[kOff + K1_THREADS + t];
+        uint4 c2 = make_uint4(0, 0, 0, 0);
+        if (t < kUnits - 2 * K1_THREADS) c2 = s4[kOff + 2 * K1_THREADS + t];
+        __syncthreads();  // every read of the old window (this shift, the previous round's emit) precedes the writes
+        s4[t] = c0;
+        s4[K1_THREADS + t] = c1;
+        if (t < kUnits - 2 * K1_THREADS) s4[2 * K1_THREADS + t] = c2;
+      }
+      if (!reload) *reinterpret_cast<uint2*>(&s_data[(kWindow + kLook) / 4 + 2 * t]) = make_uint2(pre_lo, pre_hi);
       if constexpr (SF_PROBE_STAGE > 0) { uint32_t pr = t; probe_valu<SF_PROBE_STAGE>(pr); }
       // (RECENT asks for them behind the match phase, whose serial pass wants the registers: parse and emit hide the latency)
       if (!RECENT && r + 1 < nrounds) {
@@ -389,7 +410,12 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       // bucket (v_pk_sub_u16 clamp).  What falls below 1 << 10 (step field 0) is older than the window: empty
       // @phase stage.ageing trips=1 depth=2 note=two iterations every second round
       if (rb / STEP - ebase >= kEpMax) {
-        constexpr uint32_t kSub2 = (kEpS << SH) * 0x00010001u;
+        // (behind a chunk whose later rounds were taken in one go the epoch is further back than one move mends: the moves
+        // that were due meanwhile are made up in this one -- at most three, 3 * kEpS << SH < 2^16; what ageing removes is
+        // older than the window either way, so when it happens shows nowhere)
+        const uint32_t moves = (rb / STEP - ebase - kEpMax) / kEpS + 1u;
+        static_assert(3 * (kEpS << SH) < 65536 && (kRoundsPerChunk * (kRound / STEP) - 1) / kEpS + 1 <= 3, "ageing: one packed subtract makes up for a skipped chunk");
+        const uint32_t kSub2 = moves * ((kEpS << SH) * 0x00010001u);
         uint4* t4 = reinterpret_cast<uint4*>(smem + L_TABLE);
         static_assert((1u << kHashBits) % (4 * K1_THREADS) == 0, "ageing: whole 16-byte units per thread");
         for (uint32_t idx = t; idx < (1u << kHashBits) / 4; idx += K1_THREADS) {
@@ -400,7 +426,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
           asm("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(e.w) : "s"(kSub2));
           t4[idx] = e;
         }
-        ebase += kEpS;
+        ebase += moves * kEpS;
       }
       // @phase stage.end trips=1 note=closing barrier
       // (the barrier at the top of the stage follows the previous round's last histogram update)
@@ -409,30 +435,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
     }
     stamp(0);
 
-    // @phase skip trips=0 note=stored fast path (never on text)
-    if (skip) {
-      // the chunk's first kSkipSpan positions were (almost) all literals: no search, no insertion,
-      // every position is a literal
-      if (RECENT && r + 1 < nrounds) {  // (the other kernels asked for the next round's bytes in the stage)
-        pre_lo = load4(rb + kRound + kLook + 8 * t);
-        pre_hi = load4(rb + kRound + kLook + 8 * t + 4);
-      }
-      // No item is written: an item of this span IS the position's byte, and k_emit takes it from the input in the rare
-      // case that such a chunk is not stored (kItemsSkipped in nitems).  What the plan needs is the byte histogram
-      {
-        const uint32_t rel0 = 8 * t;
-        if (rel0 < qn) {
-          const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + rel0]);
-          const uint32_t nvb = qn - rel0 < 8 ? qn - rel0 : 8u;
-#pragma unroll
-          for (uint32_t k = 0; k < 8; ++k)
-            if (k < nvb) atomicAdd(&s_hist[((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu], 1u);
-        }
-      }
-      if (t < kRSubs) rtok_out[chunk * kSubRegions + rc * kRSubs + t] = tot_tok + (t * kSubBytes < qn ? t * kSubBytes : qn);
-      tot_tok += qn;
-      tot_items += qn;
-    } else {
+    {  // (a round: match, parse, emit)
       // @phase match.setup trips=1
       // ---- match finding over this round ----
       uint32_t nsteps = (qn + STEP - 1) / STEP;
@@ -985,7 +988,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       // the lane's eight staged distances: asked for now, used by the extensions and the emit.  Every wave has them
       // before any wave writes an item (the barrier between walk and emit waits for outstanding loads)
       // (the load is only waited for behind the take pass and the transfer functions, which do not need it)
-      uint32_t D0, D1, D2 = 0, D3 = 0;
+      uint32_t D0 = 0, D1 = 0, D2 = 0, D3 = 0;
       uint4 Dld = make_uint4(0, 0, 0, 0);
       if constexpr (STRIDE2) {
         // four slots: the lane's even positions; position 7's successor is the next lane's position 0
@@ -1035,10 +1038,13 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       const uint32_t pb = 8 * t;                       // the lane's first position, round-relative
       if constexpr (SF_PROBE_PARSE > 0) { uint32_t pr = t; probe_valu<SF_PROBE_PARSE>(pr); }
       const uint32_t nv = qn > pb ? (qn - pb < 8 ? qn - pb : 8u) : 0u;  // its valid positions
-      uint32_t T;                                      // take bits of the eight positions
-      uint32_t N;                                      // their 4-bit lengths
-      uint32_t c0, c1, k0, k1;                         // a byte per position: 4-bit length (0..13) | 0x80 where T says take
-      {
+      uint32_t T = 0;                                  // take bits of the eight positions
+      uint32_t N = 0;                                  // their 4-bit lengths
+      uint32_t c0 = 0, c1 = 0, k0 = 0, k1 = 0;         // a byte per position: 4-bit length (0..13) | 0x80 where T says take
+      // (uniform per wave) behind a chunk that took the stored fast path only the first kSkipProbe positions of the span were
+      // searched: the waves behind them have nothing to parse -- every position a literal
+      const bool lit_wave = short_probe && rc == 0 && wave >= kSkipProbe / kRegion;
+      if (!lit_wave) {
         // lazy deferral looks up to `lazy` positions ahead, inside the region and the input
         uint64_t W;
         if constexpr (STRIDE2) {
@@ -1087,7 +1093,9 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       uint32_t cap_mp = 8, cap_len = 0;                // the capped chain match that was extended (at most one per lane)
       bool cap_run = false;                            // ... and whether it turned out to be a run (distance 1)
       uint32_t exit_abs = 0;                           // region-relative position where the chain leaves this lane (0: not on it)
-      {
+      if (lit_wave) {
+        marks = (1u << nv) - 1u;
+      } else {
         const uint32_t lb = 8 * lane;                  // the lane's first position, region-relative
         const uint32_t rend = (pb & ~(kRegion - 1)) + kRegion < qn ? (pb & ~(kRegion - 1)) + kRegion : qn;  // region end, round-relative
         // The lane's TRANSFER FUNCTION, for all eight possible entries at once (a byte per entry, SWAR): where the chain
@@ -1278,13 +1286,57 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
 
       // @phase skip_now trips=0
       if (skip_now) {
-        // (qn == kRound here: the chunk is longer than the span)
+        // (qn == kRound here: the chunk is longer than the span.)  The REST of the chunk is taken right here, in one go: its
+        // bytes are only counted, so its rounds need no window, no table and no barrier of their own -- three loads per
+        // thread in flight together instead of three rounds of a stage each waiting for its own; the window the next
+        // chunk's probe needs comes from the input again (lds_stale, see the stage).  Schedule only: the chunk's tokens,
+        // counts and sub-index are what the round-by-round version wrote
+        const uint32_t clen = (n - cstart) < kChunk ? (n - cstart) : kChunk;  // the chunk's bytes
         const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + 8 * t]);
+        if (clen == kChunk) {
+          uint2 w[kRoundsPerChunk - 1];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) atomicAdd(&s_hist[((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu], 1u);
-        if (t < kRSubs) rtok_out[chunk * kSubRegions + t] = t * kSubBytes;
+          for (uint32_t k = 1; k < kRoundsPerChunk; ++k) w[k - 1] = *reinterpret_cast<const uint2*>(sp + cstart + k * kRound + 8 * t);
+          // The chunk's 32,768 byte counts.  On the histogram itself a wave's 64 random bytes pile up on the LDS banks (one
+          // atomic instruction: six to eight cycles; 0.060 of the fast path's 0.186 ms per 256 MiB, 0.043 now).  The window is dead from
+          // here on (lds_stale), so its 32 KiB hold 32 COPIES of the 256 counters, copy = lane mod 32 at dword
+          // byte * 32 + copy: every lane of a half-wave has a bank of its own whatever the bytes are.  Then 1024 threads
+          // fold eight copies each and four neighbours meet over the DPP network.
+          static_assert(256 * 32 * 4 <= kWindow && kWindow / 16 == 2 * K1_THREADS, "the copies fill the window");
+          uint4* const z4 = reinterpret_cast<uint4*>(smem + L_DATA);
+          z4[t] = make_uint4(0, 0, 0, 0);
+          z4[K1_THREADS + t] = make_uint4(0, 0, 0, 0);
+          __syncthreads();
+          uint32_t* const rep = s_data + (lane & 31u);
+          auto count8 = [&](uint32_t lo, uint32_t hi) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) atomicAdd(&rep[(((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xFFu) * 32u], 1u);
+          };
+          count8(B.x, B.y);
+#pragma unroll
+          for (uint32_t k = 1; k < kRoundsPerChunk; ++k) count8(w[k - 1].x, w[k - 1].y);
+          __syncthreads();
+          {
+            const uint4 p = z4[2 * t], q = z4[2 * t + 1];  // thread t: copies 8 (t mod 4) .. + 8 of byte value t / 4
+            uint32_t sum = (p.x + p.y) + (p.z + p.w) + (q.x + q.y) + (q.z + q.w);
+            sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+            sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true);
+            if ((t & 3u) == 0) s_hist[t >> 2] = sum;  // (this chunk has counted nothing else: its first round's emit was dropped)
+          }
+        } else {  // a strip's short last chunk: byte by byte
+#pragma unroll
+          for (uint32_t k = 0; k < 8; ++k) atomicAdd(&s_hist[((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu], 1u);
+          for (uint32_t pos = cstart + kRound + t; pos < cstart + clen; pos += K1_THREADS) atomicAdd(&s_hist[sp[pos]], 1u);
+        }
+        const uint32_t r_last = (r + kRoundsPerChunk - 1 < nrounds ? r + kRoundsPerChunk - 1 : nrounds - 1);  // the chunk's last round
+        if (t < kSubRegions) rtok_out[chunk * kSubRegions + t] = t * kSubBytes < clen ? t * kSubBytes : clen;
         skip = true;
-        rtotal = kRound;  // tokens = items = positions
+        lds_stale = true;
+        chunk_done = true;
+        tot_tok = clen;  // tokens = items = positions
+        tot_items = clen;
+        rtotal = 0;
+        r = r_last;
       } else
       // @phase emit.head trips=1
       // ---- emit: the lane's chain positions -> items (compact, chunk order) + histogram ----
@@ -1353,14 +1405,14 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
 
     // @phase chunk.end trips=0.25 note=once per chunk of four rounds
     // ---- end of a chunk: its counts and histogram go out, the histogram starts over ----
-    if (rc == kRoundsPerChunk - 1 || r + 1 == nrounds) {
+    if (chunk_done || rc == kRoundsPerChunk - 1 || r + 1 == nrounds) {
       __syncthreads();  // this round's histogram updates are complete
       for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) {
         hist_out[(uint64_t)chunk * kHistStride + idx] = s_hist[idx];
         s_hist[idx] = (idx == 256) ? 1u : 0u;
       }
       if (t == 0) { ntok_out[chunk] = tot_tok; nitems_out[chunk] = tot_items | (skip ? kItemsSkipped : 0u); }
-      const uint32_t covered = (rc + 1) * kRSubs;  // sub-index regions of the rounds that ran
+      const uint32_t covered = chunk_done ? kSubRegions : (rc + 1) * kRSubs;  // sub-index regions of the rounds that ran
       if (t < kSubRegions && t >= covered) rtok_out[chunk * kSubRegions + t] = tot_tok;
       stamp(6);
     }
