@@ -328,6 +328,49 @@ def self_launch(gpus):
     return rc
 
 
+LINE_LIMIT = 8192  # the driver keeps the last 8 KB of a bench line: the whole line stays below that (tests/test_bench_launch.py)
+
+
+def compact_workload(res, n_bytes=None, basis=None):
+    """A secondary workload as the line carries it: throughput, ratio against zlib -6, round trip, per-kernel times and its
+    own roofline fraction -- `basis` "N+C over k_lz77" (a coded workload: the dominant kernel, like the headline) or
+    "2N+5/chunk over the path" (the stored path: a copy, every kernel of the step)."""
+    if res is None or "skipped" in res:
+        return res
+    out = {"workload": res["workload"].split(" (")[0][:60], "value": res["value"], "unit": "MiB/s", "ms": res["ms"], "ratio": res["ratio"],
+           "ratio_vs_zlib6": res["ratio_vs_zlib6"], "roundtrip_ok": res["roundtrip_ok"], "kernel_ms": res["kernel_ms"]}
+    if n_bytes and basis:
+        km = res["kernel_ms"]
+        if basis.startswith("2N"):
+            alg, t_ms = 2 * n_bytes + 5 * ((n_bytes + SEG - 1) // SEG), sum(km.values())
+        else:
+            alg, t_ms = n_bytes + int(n_bytes / res["ratio"]), km.get("k_lz77", 0.0)
+        if t_ms > 0:
+            out["roofline"] = {"basis": basis, "bytes": alg, "ms": round(t_ms, 4), "frac": round(alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def assemble_line(head, kernel_ms, roofline, cpu, e2e, decomp, real_bytes, multi_gpu, configs, extra=None):
+    """The ONE JSON line, in the order a reader -- and the driver's 8 KB tail -- needs it: the contract's keys, the dominant
+    kernel's roofline, the CPU baseline, the short legs (e2e, decompress, real bytes, multi_gpu), and LAST the BASELINE
+    configs at their default effort (`configs`: config[2] = the headline again in brief, config[3]'s bytes on one GPU,
+    config[4])."""
+    line = dict(head)
+    line["kernel_ms"] = {k: round(v, 4) for k, v in kernel_ms.items()}
+    line["kernels_total_ms"] = round(sum(kernel_ms.values()), 4)
+    line["roofline"] = roofline
+    line["cpu_baseline"] = cpu
+    line["e2e"] = e2e
+    line["decompress"] = decomp
+    line["real_bytes"] = real_bytes
+    if multi_gpu is not None:
+        line["multi_gpu"] = multi_gpu
+    if extra:
+        line.update(extra)
+    line["configs"] = configs
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -339,7 +382,10 @@ def main():
     ap.add_argument("--block-bytes", type=int, default=0, help="sfh_options.block_bytes (0 = the library's default: 512 KiB at 1 GiB, 1 MiB with the chain efforts)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the e2e leg and the other two workloads")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the e2e leg, the other BASELINE workloads and the real-bytes workloads")
+    ap.add_argument("--sweep", nargs="?", const="gpurun_out/sweep.json", default=None, metavar="PATH",
+                    help="also run every effort level on the text, mixed and real-bytes workloads (minutes) and write the table to PATH "
+                         "(default gpurun_out/sweep.json; the committed copy is profiles/rNN_sweep.json); the JSON line itself stays compact")
     ap.add_argument("--cpu-sample-bytes", type=int, default=512 << 20)
     ap.add_argument("--secondary-bytes", type=int, default=256 << 20)
     ap.add_argument("--rounds", type=int, default=4, help="N > 1: block-cyclic rounds per rank (gather/compute overlap)")
@@ -573,17 +619,20 @@ def main():
     text_default = args.effort == "default" and args.workload == "text" and not corpus and args.container == "raw" and not multi
     if not text_default:  # the profile is of the default command: another workload's traffic is not in it
         traffic, traffic_info = None, None
+    issue = issue_from_profile(dom, stage_ms[dom], n, dp, stamp) if text_default and "error" not in dp else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None, "traffic_info": traffic_info,
+                "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
                 "read_frac": round(n / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "issue": issue_from_profile(dom, stage_ms[dom], n, dp, stamp) if text_default and "error" not in dp else None}
+                # where `traffic` comes from: the committed counter passes of this command, and whether they are of the running sources
+                "traffic_info": None if not traffic_info else {k: traffic_info[k] for k in ("commit", "csrc_sha256", "current", "read_bytes", "write_bytes")},
+                "issue": None if not issue else {k: issue[k] for k in ("valu_wave_instructions_per_launch", "cycles_per_instruction_per_simd",
+                                                                         "lds_busy_frac", "lds_bank_conflict_frac")}}
     if "error" in dp:
         roofline["device"] = dp
     else:
         roofline["device"] = {"name": dp["name"], "arch": dp["arch"], "compute_units": dp["compute_units"], "clock_khz": dp.get("clock_khz"),
-                              "memory_clock_khz": dp["memory_clock_khz"], "memory_bus_bits": dp["memory_bus_bits"],
                               # HBM3E moves 8 Gb/s per pin = 4 transfers per reported 2 GHz memory clock
                               "hbm_peak_from_props_GBs": round(4 * dp["memory_clock_khz"] * 1e3 * dp["memory_bus_bits"] / 8 / 1e9, 1)}
     kern_total_ms = sum(stage_ms.values())
@@ -610,10 +659,8 @@ def main():
             decomp[label] = {"value": round(n / td / 2**20, 1), "unit": "MiB/s of output", "ms": round(td * 1e3, 3),
                              "status": dstatus, "equal_to_input": bool(torch.equal(back, data)),
                              "kernel_ms": {k: round(v, 4) for k, v in comp.inflate_ms().items()}}
-        decomp["note"] = ("sub_indexed: chunk offsets + 32 entries per chunk (sfh_copy_index, sfh_copy_subindex), 32 lanes per "
-                          "segment; segment_indexed: chunk offsets only, 32 lanes per segment that find their token boundaries speculatively "
-                          "(k_inflate_tokens_spec; any indexed stream, the lane-serial kernel behind it for segments of more than four blocks); "
-                          f"byte copies strip by strip (block_bytes {bb})")
+        # (sub_indexed: chunk offsets + 32 sub-index entries per chunk, sfh_copy_index / sfh_copy_subindex; segment_indexed: chunk offsets
+        # only -- 32 lanes per segment find their token boundaries speculatively, k_inflate_tokens_spec)
         del back, stream_t
         # a FOREIGN indexed stream: zlib -6 with Z_FULL_FLUSH every 32 KiB over the first 256 MiB of the same input -- what the
         # reference's own flushed fixtures are (tools/deflate_compress.py --flush); segment index only, every segment independent
@@ -640,12 +687,12 @@ def main():
             td = (time.perf_counter() - td) / reps
             from starflate_amd import _capi
             by_serial = int(((comp.debug(_capi.DBG_SEGINFO, nseg)[:, 2] >> 1) & 1).sum())
+            # (made by zlib.compressobj(6, DEFLATED, -15) with Z_FULL_FLUSH every 32768 bytes of input)
             decomp["zlib_made_segment_indexed"] = {
-                "segments": nseg, "segments_finished_by_the_lane_serial_kernel": by_serial,
+                "segments": nseg, "by_lane_serial_kernel": by_serial,
                 "value": round(zn / td / 2**20, 1), "unit": "MiB/s of output", "ms": round(td * 1e3, 3), "bytes": zn,
-                "stream_bytes": int(zraw.size), "status": zstatus, "equal_to_input": bool(torch.equal(zback, data[:zn])),
-                "kernel_ms": {k: round(v, 4) for k, v in comp.inflate_ms().items()},
-                "made_by": "zlib.compressobj(6, DEFLATED, -15), Z_FULL_FLUSH every 32768 bytes of input"}
+                "status": zstatus, "equal_to_input": bool(torch.equal(zback, data[:zn])),
+                "kernel_ms": {k: round(v, 4) for k, v in comp.inflate_ms().items()}}
             del zback, zstream
 
     # ---- end to end from pinned host memory (H2D + kernels + D2H), and the other two workloads ----
@@ -666,15 +713,17 @@ def main():
         for _ in range(reps):
             call()
         te = (time.perf_counter() - t0) / reps
-        e2e = {"value": round(n / te / 2**20, 1), "unit": "MiB/s", "ms": round(te * 1e3, 3), "bytes_out": int(out_n.value),
-               "note": "sfh_compress from/to pinned host buffers, the call as a whole (synchronous): inside it 64 MiB batches are pipelined -- "
-                       "H2D of batch b beside the kernels of batch b-1 beside the D2H of batch b-2's stream bytes"}
+        # (sfh_compress from / to pinned host buffers, the call as a whole: inside it 64 MiB batches are pipelined -- H2D of batch b
+        # beside the kernels of batch b-1 beside the D2H of batch b-2's stream bytes; PCIe-bound, never `value`)
+        e2e = {"value": round(n / te / 2**20, 1), "unit": "MiB/s", "ms": round(te * 1e3, 3), "bytes_out": int(out_n.value), "what": "sfh_compress, pinned host buffers"}
         del hin, hout
         others = {w: secondary_workload(comp, w, args.secondary_bytes, dev, 0) for w in ("text", "mixed", "random", "runs") if w != args.workload}
         # REAL bytes (starflate_amd/realbytes.py): source text and x86-64 machine code from files of this image -- the
-        # generators above have no long-range structure, these do (ratio_vs_zlib6 on real data is what a user will see)
+        # generators above have no long-range structure, these do (ratio_vs_zlib6 on real data is what a user will see).
+        # The line carries the default effort and the one INTEGRATION.md recommends for such data (recent_all); --sweep: all
         from starflate_amd import realbytes
 
+        sweep = {} if args.sweep else None
         for key, buf, what in (("real_source", realbytes.source(96 << 20), "Python / C++ source text (stdlib, torch, ROCm headers)"),
                                ("real_binary", realbytes.binary(min(args.secondary_bytes, 256 << 20)), "x86-64 code + data (head of libtorch_cpu.so)")):
             nb = buf.size // (1 << 20) * (1 << 20)  # whole MiB: a multiple of every strip size the default rule picks here
@@ -691,29 +740,19 @@ def main():
                 t = t.repeat(reps)
                 desc += f", repeated x{reps} for throughput"
                 nb *= reps
-            for eff in ("default", "recent", "thorough", "recent_all", "max", "chain2", "chain4", "best", "ultra", "extreme"):
-                others[key if eff == "default" else f"{key}_effort_{eff}"] = secondary_workload(
-                    comp, key, nb, dev, 0, effort=eff, data=t, wl=desc)
+            for eff in ("default", "recent_all") + (("thorough", "max", "chain2", "chain4", "best", "ultra", "extreme") if args.sweep else ()):
+                res = secondary_workload(comp, key, nb, dev, 0, effort=eff, data=t, wl=desc)
+                if eff in ("default", "recent_all"):
+                    others[key if eff == "default" else f"{key}_effort_{eff}"] = res
+                if sweep is not None:
+                    sweep[f"{key}_effort_{eff}"] = res
             del t
-        # the same bytes at sfh_options.effort = SFH_EFFORT_FAST (one history level per hash bucket)
-        others["effort_fast"] = secondary_workload(comp, args.workload, n, dev, bb, effort="fast", data=data, wl=wl)
-        # and at SFH_EFFORT_FASTEST (that, and no step-local candidate)
-        others["effort_fastest"] = secondary_workload(comp, args.workload, n, dev, bb, effort="fastest", data=data, wl=wl)
-        # SFH_EFFORT_THOROUGH: every position searched, not every other one (the timed steps' effort is in config.effort)
-        others["effort_thorough"] = secondary_workload(comp, args.workload, n, dev, bb, effort="thorough", data=data, wl=wl)
-        others["mixed_effort_thorough"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort="thorough")
-        # SFH_EFFORT_MAX: thorough with a second hash table keyed by seven bytes
-        others["effort_max"] = secondary_workload(comp, args.workload, n, dev, bb, effort="max", data=data, wl=wl)
-        others["mixed_effort_max"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort="max")
-        # SFH_EFFORT_RECENT / _RECENT_ALL: the step tables with exact recency (buckets filled by ordered LDS atomics)
-        for eff in ("recent", "recent_all"):
-            others[f"effort_{eff}"] = secondary_workload(comp, args.workload, n, dev, bb, effort=eff, data=data, wl=wl)
-            others[f"mixed_effort_{eff}"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort=eff)
-        # SFH_EFFORT_BEST / _ULTRA / _EXTREME: exact hash chains of depth 8 / 16 / 32 (zlib's structure) instead of the step tables
-        for eff in ("chain4", "best", "ultra", "extreme"):  # chain4: sfh_options.chain_depth = 4 with a chain effort
-            # (block_bytes 0: the chain efforts' own default strip, 1 MiB at this size)
-            others[f"effort_{eff}"] = secondary_workload(comp, args.workload, n, dev, 0, effort=eff, data=data, wl=wl)
-            others[f"mixed_effort_{eff}"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort=eff)
+        if sweep is not None:
+            # every effort on the headline bytes and on the mixed workload (block_bytes 0 for the chain efforts: their own default strip)
+            for eff in ("fastest", "fast", "default", "thorough", "max", "recent_all", "chain4", "best", "ultra", "extreme"):
+                chain = eff in ("chain4", "best", "ultra", "extreme")
+                sweep[f"{args.workload}_effort_{eff}"] = secondary_workload(comp, args.workload, n, dev, 0 if chain else bb, effort=eff, data=data, wl=wl)
+                sweep[f"mixed_effort_{eff}"] = secondary_workload(comp, "mixed", args.secondary_bytes, dev, 0, effort=eff)
 
     # ---- CPU baseline: oracle restatement of the reference decompress(), 1 thread ----
     cpu = None
@@ -730,9 +769,8 @@ def main():
         tc = time.perf_counter() - tc
         good = st == 0 and w == cs and np.array_equal(back, sample.cpu().numpy())
         cpu = {"value": round(cs / tc / 2**20, 2), "unit": "MiB/s", "cores": 1, "kind": "port",
-               "sample": f"oracle sfo_decompress (restates reference src/decompress.cpp:402-461) of the GPU-made stream "
-                         f"of the first {cs >> 20} MiB of the workload; output MiB/s; round-trip equal={good}; "
-                         f"host has {os.cpu_count()} logical cores",
+               "sample": f"oracle sfo_decompress (restates reference src/decompress.cpp:402-461) on the GPU-made stream of the first "
+                         f"{cs >> 20} MiB of the workload; output MiB/s; equal={good}; host has {os.cpu_count()} logical cores",
                "zlib6_compress_MiBps_1core": round(zs / tz / 2**20, 2)}
         # block-parallel zlib -6 on this host's cores (1 MiB independent slices; zlib releases the GIL)
         from concurrent.futures import ThreadPoolExecutor
@@ -752,7 +790,7 @@ def main():
         tiled = os.path.getsize(corpus) < n
         metric = (f"compress MiB/s + ratio vs zlib -6 on {n / 2**30:g} GiB of FILE {os.path.basename(corpus)}"
                   + (" (shorter than that: repeated; the ratio is taken on the first 64 MiB at most)" if tiled else ""))
-    line = {
+    head = {
         "metric": metric,
         "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -763,15 +801,40 @@ def main():
         "ratio": round(ratio, 4), "ratio_zlib6": round(ratio_zlib6, 4),
         "ratio_vs_zlib6": round(ratio_ours_sample / ratio_zlib6, 4),
         "compressed_bytes": total_out, "roundtrip_ok": ok,
-        "kernel_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "kernels_total_ms": round(kern_total_ms, 4),
-        "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "workloads": others, "decompress": decomp,
     }
+    mg = None
     if multi_info is not None:
         # RCCL saw these devices; the gather of one step as measured (events around each round's transfers on rank 0) beside
         # what the xGMI arithmetic of DESIGN.md section 4 predicts for this step's own numbers
-        line["multi_gpu"] = dict(multi_info, gather_ms_per_step=round(sum(multi_info["gather_ms_per_round"] or [0.0]), 4),
-                                 prediction=predict_scaling(world, K, kern_total_ms, local_n))
-    print(json.dumps(line), flush=True)
+        mg = dict(multi_info, gather_ms_per_step=round(sum(multi_info["gather_ms_per_round"] or [0.0]), 4),
+                  prediction=predict_scaling(world, K, kern_total_ms, local_n))
+    # the BASELINE configs at the default effort, LAST on the line (the driver keeps a line's tail): config[2] = the timed workload
+    # in brief, config[3]'s bytes on this one GPU (the 8-rank run is `--gpus 8 --workload mixed`), config[4] = the stored path
+    this = {"workload": wl.split(" (")[0][:60], "value": round(value, 1), "unit": "MiB/s", "ms": round(ms_per_step, 3), "n_gpus": world,
+            "ratio_vs_zlib6": round(ratio_ours_sample / ratio_zlib6, 4), "roundtrip_ok": ok, "roofline_frac": roofline["frac"],
+            "roofline_read_frac": roofline["read_frac"]}
+    oth = others or {}
+    key_of = {"text": "config2_text", "mixed": "config3_mixed_1gpu" if world == 1 else f"config3_mixed_{world}gpu", "random": "config4_random", "runs": "runs"}
+    configs = {key_of[args.workload] if not corpus else "file": this}
+    sb = args.secondary_bytes
+    for w, basis in (("text", "N+C over k_lz77"), ("mixed", "N+C over k_lz77"), ("random", "2N+5/chunk over the path")):
+        if w in oth:
+            configs[key_of[w]] = compact_workload(oth[w], sb, basis)
+    real = {k: compact_workload(v) for k, v in oth.items() if k.startswith("real_")} or None
+    extra = {"runs": compact_workload(oth["runs"])} if "runs" in oth else None
+    line = assemble_line(head, stage_ms, roofline, cpu, e2e, decomp, real, mg, configs, extra)
+    if args.sweep and others is not None:
+        os.makedirs(os.path.dirname(os.path.abspath(args.sweep)), exist_ok=True)
+        with open(args.sweep, "w") as f:
+            json.dump({"_meta": {"source": stamp, "bytes": n, "secondary_bytes": sb, "what": "every effort level on the timed workload, the mixed workload and "
+                                 "the real-bytes workloads (bench.py --sweep); MiB/s of the whole path, ratio against zlib -6 on the first 32 MiB"},
+                       "headline": this, "sweep": sweep}, f, indent=1)
+        line["sweep_file"] = args.sweep
+        line["configs"] = line.pop("configs")  # stays last
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:
+        print(f"bench.py: the line is {len(text)} bytes, over the {LINE_LIMIT} the driver keeps", file=sys.stderr)
+    print(text, flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -106,3 +106,79 @@ def test_bench_self_launch_has_a_deadline():
              env={"STARFLATE_BENCH_LAUNCH_TIMEOUT": "8", "STARFLATE_BENCH_KILL_GRACE": "2"})
     assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
     assert "still running" in r.stderr
+
+
+def _mock_workload(name, kernels=("k_lz77", "k_plan", "k_scan", "k_emit", "k_checksum")):
+    return {"workload": f"0.25 GiB {name} per GPU (generator seed 4, stripes of text / binary / noise)", "value": 1234567.8, "unit": "MiB/s", "ms": 1.234,
+            "timed_steps": 20, "ratio": 2.6294, "ratio_vs_zlib6": 0.9275, "roundtrip_ok": True, "kernel_ms": {k: 1.2345 for k in kernels}}
+
+
+def test_bench_line_layout_and_size():
+    """The driver keeps the last 8 KB of bench.py's line: the whole line stays below that, the BASELINE configs come LAST, and the
+    keys the contract names are there (round 6: the effort sweep moved behind --sweep, into a file)."""
+    import bench
+
+    head = {"metric": "compress MiB/s + ratio vs zlib -6, 1 GiB synthetic; 1/2/4/8 GPU", "value": 210000.1, "unit": "MiB/s", "n_gpus": 8, "steps": 20,
+            "warmup": 3, "ms_per_step": 4.876, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1 GiB synthetic enwik-like text per GPU (gen_text_torch seed 3)", "effort": "default", "block_bytes": 524288,
+                       "deflate_block_bytes": 32768, "window_bytes": 32768, "strategy": "auto", "container": "raw",
+                       "parallelism": "shard8 block-cyclic x4, gather overlapped"},
+            "ratio": 2.6294, "ratio_zlib6": 2.8349, "ratio_vs_zlib6": 0.9275, "compressed_bytes": 3266918912, "roundtrip_ok": True}
+    kernel_ms = {k: 3.7612 for k in ("k_lz77", "k_plan", "k_scan", "k_emit", "k_checksum")}
+    roofline = {"bound": "hbm", "kernel": "k_lz77", "achieved": 394.05, "peak": 8000.0, "unit": "GB/s", "frac": 0.04926, "traffic": 2328207360,
+                "traffic_over_algorithmic": 1.571, "algorithmic_bytes_per_launch": 1482106740, "kernel_ms": 3.7612, "read_frac": 0.03568,
+                "traffic_info": {"commit": "616a83f", "csrc_sha256": "4be98d6392ec4dae", "current": True, "read_bytes": 1225961472, "write_bytes": 1101819904},
+                "issue": {"valu_wave_instructions_per_launch": 2262057677, "cycles_per_instruction_per_simd": 4.09, "lds_busy_frac": 0.562, "lds_bank_conflict_frac": 0.457},
+                "device": {"name": "AMD Instinct MI355X", "arch": "gfx950:sramecc+:xnack-", "compute_units": 256, "clock_khz": 2400000, "hbm_peak_from_props_GBs": 8192.0}}
+    cpu = {"value": 145.75, "unit": "MiB/s", "cores": 1, "kind": "port",
+           "sample": "oracle sfo_decompress (restates reference src/decompress.cpp:402-461) on the GPU-made stream of the first 512 MiB of the workload; "
+                     "output MiB/s; equal=True; host has 256 logical cores", "zlib6_compress_MiBps_1core": 30.61,
+           "zlib6_compress_MiBps_block_parallel": {"value": 327.1, "threads": 16, "ratio": 2.8311}}
+    dk = {k: 2.6123 for k in ("k_inflate_tokens", "k_inflate_tokens_retry", "k_inflate_bytes", "k_inflate_status")}
+    decomp = {lab: {"value": 187000.1, "unit": "MiB/s of output", "ms": 5.471, "status": 0, "equal_to_input": True, "kernel_ms": dk}
+              for lab in ("sub_indexed", "segment_indexed")}
+    decomp["zlib_made_segment_indexed"] = {"segments": 8192, "by_lane_serial_kernel": 0, "value": 139000.1, "unit": "MiB/s of output", "ms": 1.851, "bytes": 268435456,
+                                           "status": 0, "equal_to_input": True, "kernel_ms": dk}
+    e2e = {"value": 49900.1, "unit": "MiB/s", "ms": 20.512, "bytes_out": 408364916, "what": "sfh_compress, pinned host buffers"}
+    real = {k: bench.compact_workload(_mock_workload(k)) for k in ("real_source", "real_source_effort_recent_all", "real_binary", "real_binary_effort_recent_all")}
+    devices = [f"AMD Instinct MI355X pci 0000:{b:02x}:00 uuid GPU-0123456789abcdef0123456789abcdef" for b in range(8)]
+    mg = {"ranks_seen": 8, "distinct_devices": 8, "devices": devices, "gather_ms_per_round": [1.2345] * 4, "rounds": 4, "gather_ms_per_step": 4.938,
+          "prediction": bench.predict_scaling(8, 4, 4.9, 408364916)}
+    configs = {"config2_text": {"workload": "1 GiB synthetic enwik-like text per GPU", "value": 210000.1, "unit": "MiB/s", "ms": 4.876, "n_gpus": 8,
+                                "ratio_vs_zlib6": 0.9275, "roundtrip_ok": True, "roofline_frac": 0.04926, "roofline_read_frac": 0.03568},
+               "config3_mixed_1gpu": bench.compact_workload(_mock_workload("mixed"), 256 << 20, "N+C over k_lz77"),
+               "config4_random": bench.compact_workload(_mock_workload("high-entropy"), 256 << 20, "2N+5/chunk over the path")}
+    line = bench.assemble_line(head, kernel_ms, roofline, cpu, e2e, decomp, real, mg, configs, {"runs": bench.compact_workload(_mock_workload("runs"))})
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    assert list(line)[-1] == "configs" and set(line["configs"]) == {"config2_text", "config3_mixed_1gpu", "config4_random"}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "decompress", "multi_gpu"):
+        assert k in line, k
+    c4 = line["configs"]["config4_random"]
+    assert {"value", "ratio_vs_zlib6", "roundtrip_ok", "roofline", "kernel_ms"} <= set(c4) and c4["roofline"]["basis"].startswith("2N")
+    assert c4["roofline"]["bytes"] == 2 * (256 << 20) + 5 * 8192 and 0 < c4["roofline"]["frac"] < 1
+    assert line["configs"]["config3_mixed_1gpu"]["roofline"]["basis"].startswith("N+C")
+
+
+@pytest.mark.gpu
+def test_bench_line_on_the_gpu_is_compact(tmp_path):
+    """The real command at a reduced size: one line under the driver's 8 KB, `configs` last with config[3]'s bytes and config[4], and --sweep
+    writes its table to a file instead of the line."""
+    sweep = tmp_path / "sweep.json"
+    r = _run("--bytes", str(64 << 20), "--secondary-bytes", str(32 << 20), "--cpu-sample-bytes", str(16 << 20), "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 8192, len(lines[0])
+    d = json.loads(lines[0])
+    assert list(d)[-1] == "configs" and {"config2_text", "config3_mixed_1gpu", "config4_random"} <= set(d["configs"])
+    assert d["roundtrip_ok"] is True and all(c["roundtrip_ok"] for c in d["configs"].values())
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["decompress"]["sub_indexed"]["equal_to_input"]
+    assert d["configs"]["config4_random"]["roofline"]["frac"] > 0.05 and d["configs"]["config4_random"]["ratio"] < 1.001
+    assert "real_source" in d["real_bytes"] and "real_binary_effort_recent_all" in d["real_bytes"]
+    r = _run("--bytes", str(32 << 20), "--secondary-bytes", str(32 << 20), "--no-cpu-baseline", "--no-decompress", "--steps", "1", "--warmup", "1", "--sweep", str(sweep))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip())
+    assert len(r.stdout.strip()) < 8192 and d["sweep_file"] == str(sweep) and list(d)[-1] == "configs"
+    sw = json.load(open(sweep))
+    assert {"text_effort_best", "mixed_effort_recent_all", "real_source_effort_extreme", "real_binary_effort_max"} <= set(sw["sweep"])
