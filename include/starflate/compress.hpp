@@ -39,7 +39,8 @@ enum class BlockStrategy : std::uint8_t { Auto, Stored, Fixed, Dynamic };
 ///   Best / Ultra / Extreme: exact hash chains of depth 8 / 16 / 32 (zlib's structure) instead of the step tables
 ///   Recent / RecentAll: the step tables with EXACT RECENCY -- a bucket holds the latest position with the hash and the one
 ///             before the latest inserting step, a position's nearest earlier occurrence is its third candidate; every
-///             other position searched (Recent) or every position (RecentAll)
+///             other position searched (Recent: DEPRECATED -- Thorough's ratio at Thorough's speed on every workload
+///             measured, kept for compatibility) or every position (RecentAll: the effort for real source text / machine code)
 enum class Effort : std::uint8_t {
   Default = SFH_EFFORT_DEFAULT,
   Fast = SFH_EFFORT_FAST,
@@ -49,7 +50,7 @@ enum class Effort : std::uint8_t {
   Best = SFH_EFFORT_BEST,    // exact hash chains, the 8 most recent positions with the hash
   Ultra = SFH_EFFORT_ULTRA,  // ... the 16 most recent
   Extreme = SFH_EFFORT_EXTREME,  // ... the 32 most recent: zlib -6's own ratio
-  Recent = SFH_EFFORT_RECENT,
+  Recent [[deprecated("no point of its own on the speed / ratio curve: use Thorough or RecentAll")]] = SFH_EFFORT_RECENT,
   RecentAll = SFH_EFFORT_RECENT_ALL,
 };
 

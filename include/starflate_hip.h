@@ -94,10 +94,13 @@ typedef struct sfh_options {
                             position / every position, three candidates each) but fill the buckets in POSITION ORDER:
                             a bucket holds the latest position with the hash and the one before the latest inserting
                             step, and a position's third candidate is its exact predecessor -- the nearest earlier
-                            position with its hash, inside the step or before it.  RECENT is the default's pattern
-                            (about thorough's ratio on real data); RECENT_ALL is thorough's (on real bytes max's ratio
-                            or better -- machine code +3 points -- for a tenth less time).  Both rest on the LDS
-                            executing the lanes of one returning atomic in ascending order (sfh_lds_order_check) */
+                            position with its hash, inside the step or before it.  RECENT_ALL is thorough's pattern (on
+                            real bytes max's ratio or better -- machine code +3 points -- for a tenth less time): the
+                            effort for real source text and machine code.  RECENT (the default's pattern) is DEPRECATED:
+                            measured, it is thorough's ratio at thorough's speed on every workload (round 5), i.e. no
+                            point of its own on the speed / ratio curve; it stays accepted and bit-exact, new callers use
+                            THOROUGH or RECENT_ALL.  Both rest on the LDS executing the lanes of one returning atomic in
+                            ascending order (sfh_lds_order_check) */
   uint32_t chain_depth;  /* 0: what the effort implies.  With a chain effort (SFH_EFFORT_BEST / _ULTRA / _EXTREME) any depth
                             1..255 -- candidates per position, most recent first (the specification's chain_depth): 4 is
                             SFH_EFFORT_MAX's ratio on text and the chains' on real data at 80 K MiB/s.  Must be 0 with the
@@ -106,6 +109,7 @@ typedef struct sfh_options {
 
 enum sfh_effort { SFH_EFFORT_DEFAULT = 0, SFH_EFFORT_FAST = 1, SFH_EFFORT_FASTEST = 2, SFH_EFFORT_THOROUGH = 3, SFH_EFFORT_MAX = 4,
                   SFH_EFFORT_BEST = 5, SFH_EFFORT_ULTRA = 6, SFH_EFFORT_EXTREME = 7, SFH_EFFORT_RECENT = 8, SFH_EFFORT_RECENT_ALL = 9 };
+/* (SFH_EFFORT_RECENT is deprecated: see the `effort` field above) */
 
 #define SFH_DEFAULT_BLOCK_BYTES 262144u
 /* block_bytes = 0 on inputs large enough to fill the device four times over with strips of that size (2048 / 1024 of them):
@@ -135,8 +139,11 @@ int sfh_create(sfh_ctx** out, int device);
 /* The chain efforts (SFH_EFFORT_BEST / _ULTRA / _EXTREME) and SFH_EFFORT_RECENT insert 64 positions into their hash buckets
  * with ONE returning LDS atomic and rely on the LDS executing that wave-instruction's lanes in ascending order where they
  * meet at one address (op 0: ds_wrxchg_rtn_b32, op 1: ds_mskor_rtn_b32) -- measured behaviour of gfx950, not an ISA
- * promise.  This runs the check the library itself runs (cached per context) before the first call with such an effort:
- * `blocks` workgroups x `iters` insertion steps x five collision densities in the match kernel's own access pattern
+ * promise.  This runs the check the library itself runs ONCE PER CONTEXT, inside sfh_create (two launches of well under a
+ * millisecond on the context's own stream and one synchronisation there; the verdict is cached, so no compress call -- the
+ * asynchronous ones included -- ever blocks or launches anything for it):
+ * `blocks` (1..4096) workgroups x `iters` (1..128) insertion steps x five collision densities (the kernel counts in 32 bits:
+ * larger arguments are SFH_E_INVALID_ARG) in the match kernel's own access pattern
  * (partial exec masks, sixteen back-to-back instructions by one wave on shared buckets, the other waves reading the
  * table meanwhile), every position compared with the sequential model.  *mismatches == 0: the order holds.  A compress
  * call with one of those efforts on a context whose check failed returns SFH_E_UNSUPPORTED and changes nothing
@@ -252,7 +259,11 @@ int sfh_copy_subindex(sfh_ctx* ctx, uint32_t* dst, size_t words, int dst_on_devi
  * 0 = 32768, every segment independent): a match of segment i may reach back to the first byte of its strip,
  * a farther one is InvalidDistance.  Returns SFH_OK when the kernels ran; *status is then the reference's
  * DecompressStatus (0 = Success) of the first failing segment in stream order; dst is complete only on 0.
- * Synchronises `stream` (NULL = the ctx's own). */
+ * Synchronises `stream` (NULL = the ctx's own).
+ * Scratch: the decoder keeps 4 bytes of tokens per output byte -- of ONE batch of whole strips, at most 1 GiB of output (round
+ * 6; before: of the whole call): 4 GiB at most whatever dst_n is (sfh_last_decode_scratch_bytes), the two kernels alternating
+ * batch after batch on the stream; bytes and status are those of one pass over everything
+ * (/root/reference/src/decompress.cpp:197-242 semantics: the first failing block in stream order). */
 int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const uint64_t* d_index,
                           const uint32_t* d_subindex, size_t nseg, void* d_dst, size_t dst_n, uint32_t block_bytes,
                           uint32_t* status, void* stream);
@@ -260,8 +271,11 @@ int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const u
 int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* index, const uint32_t* subindex,
                    size_t nseg, void* dst, size_t dst_n, uint32_t block_bytes, uint32_t* status);
 
+/* bytes of decoder token scratch the last sfh_decompress* call on this ctx used (0 before the first) */
+size_t sfh_last_decode_scratch_bytes(const sfh_ctx* ctx);
+
 #define SFH_INFLATE_NSTAGES 2 /* 0 k_inflate_tokens (Huffman decode), 1 k_inflate_bytes (match copies) */
-/* with profiling on: milliseconds per decoder kernel of the last sfh_decompress* call */
+/* with profiling on: milliseconds per decoder kernel of the last sfh_decompress* call (summed over its batches) */
 int sfh_last_inflate_ms(sfh_ctx* ctx, float ms[SFH_INFLATE_NSTAGES]);
 const char* sfh_inflate_stage_name(int stage);
 

@@ -26,7 +26,7 @@ SUBINDEX_WORDS = 64
 EXPORTS = [
     "sfh_default_options", "sfh_device_count", "sfh_get_device_props", "sfh_create", "sfh_destroy", "sfh_last_error",
     "sfh_compress_bound", "sfh_compress", "sfh_compress_multi", "sfh_compress_device", "sfh_compress_device_async",
-    "sfh_last_block_bytes", "sfh_index_entries", "sfh_copy_index", "sfh_copy_subindex", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms",
+    "sfh_last_block_bytes", "sfh_index_entries", "sfh_copy_index", "sfh_copy_subindex", "sfh_decompress_device", "sfh_decompress", "sfh_last_inflate_ms", "sfh_last_decode_scratch_bytes",
     "sfh_inflate_stage_name", "sfh_checksum_device", "sfh_crc32_combine", "sfh_adler32_combine",
     "sfh_set_profiling", "sfh_last_stage_ms", "sfh_stage_name", "sfh_debug_read",
     "sfh_gather_offsets", "sfh_gather_streams", "sfh_comm_ranks", "sfh_lds_order_check",
@@ -98,6 +98,8 @@ def lib():
     L.sfh_gather_streams.restype = C.c_int
     L.sfh_last_block_bytes.argtypes = [vp]
     L.sfh_last_block_bytes.restype = C.c_uint32
+    L.sfh_last_decode_scratch_bytes.argtypes = [vp]
+    L.sfh_last_decode_scratch_bytes.restype = sz
     L.sfh_index_entries.argtypes = [vp]
     L.sfh_index_entries.restype = sz
     L.sfh_copy_index.argtypes = [vp, vp, sz, C.c_int, vp]

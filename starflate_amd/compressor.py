@@ -104,6 +104,15 @@ class Compressor:
         """Strip size the last compress call used (block_bytes after defaulting)."""
         return int(self._lib.sfh_last_block_bytes(self._h))
 
+    def last_error(self):
+        """sfh_last_error: what the last failing call (or the last decode with a non-zero status) said."""
+        e = self._lib.sfh_last_error(self._h)
+        return e.decode() if e else ""
+
+    def last_decode_scratch_bytes(self):
+        """Bytes of token scratch the last decompress call used: one batch of whole strips (at most 4 GiB), whatever its size."""
+        return int(self._lib.sfh_last_decode_scratch_bytes(self._h))
+
     def last_index(self, device=None):
         """Index of the last compress call: segments + 1 stream offsets.  numpy uint64 array, or (device given)
         an int64 tensor on that CUDA device."""

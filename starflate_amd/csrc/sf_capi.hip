@@ -30,8 +30,11 @@ struct sfh_ctx {
   size_t d_index_cap = 0;
   uint32_t* d_sub = nullptr;
   size_t d_sub_cap = 0;
-  hipEvent_t ev_inf[SFH_INFLATE_NSTAGES + 1] = {};
+  // per-stage events of the last profiled decode call: SFH_INFLATE_NSTAGES + 1 per batch, grown on demand
+  std::vector<hipEvent_t> ev_inf;
+  uint32_t ev_inf_batches = 0;
   bool ev_inf_valid = false;
+  size_t last_dtok_bytes = 0;    // bytes of decoder token scratch the last decode call used (bounded: one batch)
   uint8_t* d_in = nullptr;       // staging for the host-buffer entry points (capacities in bytes)
   uint8_t* d_out = nullptr;
   size_t d_in_cap = 0, d_out_cap = 0;
@@ -192,8 +195,10 @@ int check_opt(const sfh_options* o) {
 }
 
 // The returning LDS atomic of the exact-recency match finders (op 0: chains, op 1: recent) executes a wave's lanes in
-// ascending order on this device?  Checked once per context, on the context's own stream, before the first call that
-// needs it (64 workgroups x 4 steps x 5 densities: 1.2 M positions, well under a millisecond of kernels).
+// ascending order on this device?  Checked once per context IN sfh_create, on the context's own stream (64 workgroups x 4
+// steps x 5 densities: 1.2 M positions, well under a millisecond of kernels), so that no compress call -- an asynchronous
+// one on the caller's stream, possibly under capture -- ever launches or waits for it; ensure_order() reads the verdict
+// (and runs the check itself only if sfh_create could not).
 int check_order(sfh_ctx* ctx, int op, uint64_t* bad, uint64_t* checked, uint32_t blocks, uint32_t iters) {
   SF_HIP(sf::run_lds_order_check(op, blocks, iters, ctx->d_value, ctx->stream), "lds order check");
   uint32_t r[2] = {0, 0};
@@ -458,11 +463,12 @@ int sfh_create(sfh_ctx** out, int device) {
     sfh_destroy(ctx);
     return SFH_E_HIP;
   }
-  for (int k = 0; k <= SFH_INFLATE_NSTAGES; ++k)
-    if (hipEventCreate(&ctx->ev_inf[k]) != hipSuccess) {
-      sfh_destroy(ctx);
-      return SFH_E_HIP;
-    }
+  for (int op = 0; op < 2; ++op) {  // the LDS ordering the chain and recent efforts rest on: settled here, once (see ensure_order)
+    uint64_t bad = 0, checked = 0;
+    if (check_order(ctx, op, &bad, &checked, 64, 4) == SFH_OK)
+      ctx->order_ok[op] = (bad == 0 && checked != 0 && !ctx->force_order_fail) ? 1 : -1;
+    ctx->err[0] = 0;  // (a check that could not run is run again by the first call that needs it, which then reports)
+  }
   *out = ctx;
   return SFH_OK;
 }
@@ -478,8 +484,7 @@ void sfh_destroy(sfh_ctx* ctx) {
   (void)hipFree(ctx->d_value);
   (void)hipFree(ctx->d_index);
   (void)hipFree(ctx->d_sub);
-  for (int k = 0; k <= SFH_INFLATE_NSTAGES; ++k)
-    if (ctx->ev_inf[k]) (void)hipEventDestroy(ctx->ev_inf[k]);
+  for (hipEvent_t e : ctx->ev_inf) (void)hipEventDestroy(e);
   (void)hipFree(ctx->d_in);
   (void)hipFree(ctx->d_out);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
@@ -500,8 +505,10 @@ void sfh_destroy(sfh_ctx* ctx) {
 const char* sfh_last_error(const sfh_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
 
 int sfh_lds_order_check(sfh_ctx* ctx, uint32_t op, uint32_t blocks, uint32_t iters, uint64_t* mismatches, uint64_t* checked) {
-  if (!ctx || op > 1 || !blocks || blocks > 65535 || !iters || iters > 4096 || !mismatches || !checked)
-    return fail(ctx, SFH_E_INVALID_ARG, "argument", hipSuccess);
+  // (the kernel counts mismatches and checked positions with 32-bit atomics: blocks * iters * 1024 positions * 5 densities must fit,
+  // and a launch at the bound still ends within seconds)
+  if (!ctx || op > 1 || !blocks || blocks > 4096 || !iters || iters > 128 || !mismatches || !checked)
+    return fail(ctx, SFH_E_INVALID_ARG, "argument (blocks 1..4096, iters 1..128)", hipSuccess);
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   return check_order(ctx, (int)op, mismatches, checked, blocks, iters);
 }
@@ -621,24 +628,50 @@ int sfh_decompress_device(sfh_ctx* ctx, const void* d_src, size_t src_n, const u
   SF_HIP(hipSetDevice(ctx->device), "hipSetDevice");
   (void)hipGetLastError();  // see enqueue()
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  // Batches of whole strips, like the compressor: the token scratch (4 bytes per output byte) holds ONE batch of at most
+  // kBatchChunks segments -- 4 GiB for any size of call -- and the two kernels alternate on the stream, batch after batch.
+  // Strips decode independently (a match never reaches before its strip, /root/reference/src/decompress.cpp:178 within one), the
+  // segment records and the statuses cover the whole call, so the result -- bytes, first failing segment, its status -- is
+  // that of one pass over everything.
+  const uint32_t batch = std::max(sps, ctx->batch_chunks / sps * sps);  // (a strip larger than a batch is its own batch)
+  const uint32_t nbatches = (uint32_t)((nseg + batch - 1) / batch);
   int rc = ensure_ws(ctx, (uint32_t)nseg);
-  if (!rc) rc = ensure_dtok(ctx, (uint32_t)nseg);
+  if (!rc) rc = ensure_dtok(ctx, (uint32_t)std::min<size_t>(nseg, batch));
   if (rc) return rc;
+  ctx->last_dtok_bytes = std::min<size_t>(nseg, batch) * sf::kChunk * sizeof(uint32_t);
   ctx->index_valid = false;  // the decoder reuses the scratch: what sfh_debug_read returns now belongs to this call
   ctx->last_chunks = (uint32_t)nseg;
   const bool prof = ctx->profiling != 0;
   if ((rc = order_behind_last_call(ctx, s)) != SFH_OK) return rc;
-  if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[0], s), "event");
-  if (d_subindex)
-    SF_HIP(sf::launch_inflate_tokens_sub((const uint8_t*)d_src, src_n, d_index, d_subindex, (uint32_t)nseg, dst_n,
-                                         ctx->ws.tokens, ctx->ws.seginfo, sps, s), "launch k_inflate_tokens_sub");
-  else
-    SF_HIP(sf::launch_inflate_tokens((const uint8_t*)d_src, src_n, d_index, (uint32_t)nseg, dst_n, ctx->ws.tokens,
-                                     ctx->ws.seginfo, sps, !ctx->inflate_serial, s), "launch k_inflate_tokens");
-  if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[1], s), "event");
-  SF_HIP(sf::launch_inflate_bytes((const uint8_t*)d_src, src_n, (uint32_t)nseg, ctx->ws.tokens, ctx->ws.seginfo,
-                                  (uint8_t*)d_dst, sps, s), "launch k_inflate_bytes");
-  if (prof) SF_HIP(hipEventRecord(ctx->ev_inf[2], s), "event");
+  ctx->ev_inf_valid = false;
+  if (prof) {
+    const size_t need = (size_t)nbatches * (SFH_INFLATE_NSTAGES + 1);
+    while (ctx->ev_inf.size() < need) {
+      hipEvent_t e = nullptr;
+      SF_HIP(hipEventCreate(&e), "event");
+      ctx->ev_inf.push_back(e);
+    }
+  }
+  uint32_t bi = 0;
+  for (size_t g0 = 0; g0 < nseg; g0 += batch, ++bi) {
+    const uint32_t nb = (uint32_t)std::min<size_t>(batch, nseg - g0);
+    const uint64_t bdst_n = std::min<uint64_t>((uint64_t)nb * sf::kChunk, dst_n - (uint64_t)g0 * sf::kChunk);  // this batch's output bytes
+    const uint64_t* bindex = d_index + g0;           // (stream offsets are absolute: src stays what it is)
+    sf::SegInfo* binfo = ctx->ws.seginfo + g0;
+    uint8_t* bdst = (uint8_t*)d_dst + g0 * sf::kChunk;
+    hipEvent_t* ev = prof ? &ctx->ev_inf[(size_t)bi * (SFH_INFLATE_NSTAGES + 1)] : nullptr;
+    if (ev) SF_HIP(hipEventRecord(ev[0], s), "event");
+    if (d_subindex)
+      SF_HIP(sf::launch_inflate_tokens_sub((const uint8_t*)d_src, src_n, bindex, d_subindex + g0 * SFH_SUBINDEX_WORDS, nb, bdst_n,
+                                           ctx->ws.tokens, binfo, sps, s), "launch k_inflate_tokens_sub");
+    else
+      SF_HIP(sf::launch_inflate_tokens((const uint8_t*)d_src, src_n, bindex, nb, bdst_n, ctx->ws.tokens,
+                                       binfo, sps, !ctx->inflate_serial, s), "launch k_inflate_tokens");
+    if (ev) SF_HIP(hipEventRecord(ev[1], s), "event");
+    SF_HIP(sf::launch_inflate_bytes((const uint8_t*)d_src, src_n, nb, ctx->ws.tokens, binfo, bdst, sps, s), "launch k_inflate_bytes");
+    if (ev) SF_HIP(hipEventRecord(ev[2], s), "event");
+  }
+  ctx->ev_inf_batches = nbatches;
   ctx->ev_inf_valid = prof;
   SF_HIP(sf::launch_inflate_status(ctx->ws.seginfo, (uint32_t)nseg, ctx->d_value, s), "launch k_inflate_status");
   uint32_t res[2] = {0, 0};
@@ -673,10 +706,18 @@ int sfh_decompress(sfh_ctx* ctx, const void* src, size_t src_n, const uint64_t* 
   return SFH_OK;
 }
 
+size_t sfh_last_decode_scratch_bytes(const sfh_ctx* ctx) { return ctx ? ctx->last_dtok_bytes : 0; }
+
 int sfh_last_inflate_ms(sfh_ctx* ctx, float ms[SFH_INFLATE_NSTAGES]) {
   if (!ctx || !ms || !ctx->ev_inf_valid) return SFH_E_INVALID_ARG;
-  for (int k = 0; k < SFH_INFLATE_NSTAGES; ++k)
-    SF_HIP(hipEventElapsedTime(&ms[k], ctx->ev_inf[k], ctx->ev_inf[k + 1]), "elapsed");
+  for (int k = 0; k < SFH_INFLATE_NSTAGES; ++k) ms[k] = 0.f;
+  for (uint32_t b = 0; b < ctx->ev_inf_batches; ++b)  // a stage's time over every batch of the call
+    for (int k = 0; k < SFH_INFLATE_NSTAGES; ++k) {
+      float t = 0.f;
+      const hipEvent_t* ev = &ctx->ev_inf[(size_t)b * (SFH_INFLATE_NSTAGES + 1)];
+      SF_HIP(hipEventElapsedTime(&t, ev[k], ev[k + 1]), "elapsed");
+      ms[k] += t;
+    }
   return SFH_OK;
 }
 

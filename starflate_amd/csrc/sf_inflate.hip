@@ -725,7 +725,9 @@ __device__ __forceinline__ void tokens_wave_spec(const uint8_t* __restrict__ src
       else if (b.kind == kBlkStored) {
         if (b.len > out_n - out_base) state = kSegRetry;
         else {
-          if (blk == 0 && b.len == out_n) {  // the whole segment is this block: the byte-copy kernel takes it from the stream
+          // the whole segment is this block (nothing emitted yet -- empty blocks may precede it, as in decode_segment,
+          // sf_inflate_core.h): the byte-copy kernel takes it from the stream
+          if (out_base == 0 && tok_base == 0 && b.len == out_n && b.len != 0) {
             raw = 1;
             raw_off = S.lo + b.data_byte;
           } else if (raw) {

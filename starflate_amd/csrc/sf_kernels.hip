@@ -2361,6 +2361,7 @@ hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const 
   return hipGetLastError();
 }
 hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, bool carry, uint64_t* d_total, hipStream_t s) {
+  if (nchunks > kBatchChunks) return hipErrorInvalidValue;  // k_scan covers one batch (K3_TILES tiles, 32-bit sums): more would get no offset
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(K3_THREADS), 0, s, nchunks, ws.plan, base, carry ? 1u : 0u, ws.offsets, d_total);
   return hipGetLastError();
 }

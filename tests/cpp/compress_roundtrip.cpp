@@ -183,9 +183,13 @@ auto main(int argc, char** argv) -> int {
     static_assert(static_cast<int>(Effort::Max) == SFH_EFFORT_MAX && static_cast<int>(Effort::Fastest) == SFH_EFFORT_FASTEST);
     static_assert(static_cast<int>(Effort::Best) == SFH_EFFORT_BEST && static_cast<int>(Effort::Ultra) == SFH_EFFORT_ULTRA);
     std::size_t size_of[10] = {};
+    // (Effort::Recent is deprecated -- Thorough's ratio at Thorough's speed -- but stays accepted: still exercised here)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wdeprecated-declarations"
     static_assert(static_cast<int>(Effort::Recent) == SFH_EFFORT_RECENT && static_cast<int>(Effort::RecentAll) == SFH_EFFORT_RECENT_ALL);
     for (const Effort e : {Effort::Default, Effort::Fast, Effort::Fastest, Effort::Thorough, Effort::Max, Effort::Best, Effort::Ultra, Effort::Extreme,
                            Effort::Recent, Effort::RecentAll}) {
+#pragma clang diagnostic pop
       compress_options eo;
       eo.effort = e;
       const auto ne = gpu.compress(html, comp, eo);

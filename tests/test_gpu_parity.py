@@ -764,21 +764,16 @@ def test_lds_atomics_execute_lanes_in_ascending_order(compressor):
         assert bad == 0 and n > 150_000_000, (op, bad, n)
 
 
-def test_order_guard_refuses_the_efforts_that_need_it():
-    """SFH_FORCE_ORDER_FAIL=1 makes the library's own check (run once per context, before the first call with a chain effort
-    or SFH_EFFORT_RECENT) report failure: those efforts then return SFH_E_UNSUPPORTED with a message that says why, every
+def test_order_guard_refuses_the_efforts_that_need_it(monkeypatch):
+    """SFH_FORCE_ORDER_FAIL=1 makes the library's own check (run once per context, in sfh_create) report failure: those efforts then return SFH_E_UNSUPPORTED with a message that says why, every
     other effort works as ever, and nothing is written."""
-    import os
-
     from starflate_amd import Compressor
     from starflate_amd.compressor import StarflateError
 
     text = synth.gen_text(3 * CHUNK, seed=3)
-    os.environ["SFH_FORCE_ORDER_FAIL"] = "1"
-    try:
+    with monkeypatch.context() as m:
+        m.setenv("SFH_FORCE_ORDER_FAIL", "1")
         c = Compressor(0)
-    finally:
-        del os.environ["SFH_FORCE_ORDER_FAIL"]
     try:
         for effort in ("best", "ultra", "extreme", "chain3", "recent", "recent_all"):
             with pytest.raises(StarflateError) as e:
