@@ -301,8 +301,8 @@ const char* sfh_stage_name(int stage);
 enum sfh_debug_what {
   SFH_DBG_NTOK = 0,   /* uint32 per chunk */
   SFH_DBG_TOKENS = 1, /* decoder: uint32[32768] per segment, first ntok valid */
-  SFH_DBG_ITEMS = 8,  /* compressor: uint16[32768] per chunk, first nitems valid (literal: byte; match: 0x8000 | len-3,
-                         then dist-1; 0x4000 + region index in bits 8..12 on a parse region's first item) */
+  SFH_DBG_ITEMS = 8,  /* compressor: uint16[32768] per chunk, first nitems valid (literal: 0x8000 | byte; match: 0x8100 | len-3,
+                         then dist-1 with bit 15 clear; 0x4000 + region index in bits 9..13 on a parse region's first item) */
   SFH_DBG_NITEMS = 9, /* uint32 per chunk */
   SFH_DBG_HIST = 2,   /* uint32[576] per chunk: ll[0..285], d at [288..317], raw len-3 counts at [320..575] */
   SFH_DBG_PLAN = 3,   /* uint32[4] per chunk: btype, out_bytes, header_bits, body_bits */

@@ -263,16 +263,14 @@ class Compressor:
             if nit[c] & 0x80000000:  # kItemsSkipped: stored fast path, the items behind the first 8 KiB were never written
                 raise StarflateError(-1, f"chunk {c} took the stored fast path: its items are not materialised (stored_fast_path=False shows them)")
             it = items[c, : nit[c]].astype(np.uint32)
-            head = (it & 0x8000) != 0
-            cont = np.zeros(it.size, dtype=bool)
-            cont[1:] = head[:-1]
-            head &= ~cont
-            start = ~cont
+            start = (it & 0x8000) != 0  # kItemTok: a literal or a match head; clear: the distance behind a head
+            head = start & ((it & 0x0100) != 0)  # kItemHead
+            assert not np.any(head[:-1] & start[1:]) and (it.size == 0 or not head[-1]), "a head without its distance"
             nxt = np.zeros(it.size, dtype=np.uint32)
             nxt[:-1] = it[1:]
             tok = np.where(head, np.uint32(0x80000000) | ((it & 0xFF) << 16) | (nxt & 0x7FFF), it & 0xFF)[start]
             fl = ((it & 0x4000) != 0)[start]
-            reg = ((it >> 8) & 31)[start]
+            reg = ((it >> 9) & 31)[start]  # kItemRegionShift
             toks.append(tok.astype(np.uint32))
             flags.append([(int(k), int(reg[k])) for k in np.flatnonzero(fl)])
         return toks, flags

@@ -46,11 +46,15 @@ constexpr uint32_t kItemsSkipped = 0x80000000u;  // nitems[chunk]: the items wer
 constexpr uint32_t kSubRegions = kChunk / kSubBytes;  // 32 sub-index entries per chunk
 constexpr uint32_t kTokMatch = 0x80000000u;  // decoder token (k_inflate_*): bit31 match, 16..23 len-3, 0..14 dist-1
 constexpr uint32_t kTokRegion = 0x40000000u; // decoder token: first token of a parse region, region index in 24..28
-// k_lz77 -> k_emit: 16-bit ITEMS, at most kChunk per chunk.  A literal is one item (the byte); a match is two:
-// head = kItemMatch | len-3, then dist-1 (bit 15 clear, so "the item before me has bit 15 set" identifies it).
-// The first item of a parse region's first token also carries kItemRegion and the region's index in bits 8..12.
-constexpr uint32_t kItemMatch = 0x8000u;
+// k_lz77 -> k_emit: 16-bit ITEMS, at most kChunk per chunk.  A literal is one item (kItemTok | byte); a match is two:
+// head = kItemTok | kItemHead | len-3, then dist-1 (15 bits, bit 15 clear).  Every item says what it is by itself (round 6;
+// before, a distance was "the item behind a head" and k_emit looked at every item's neighbour), and kItemHead sits right
+// above the byte: a token's low nine bits ARE its place in k_emit's table of literal and length codes.  The first item of a
+// parse region's first token also carries kItemRegion and the region's index in bits 9..13 (kItemRegionShift).
+constexpr uint32_t kItemTok = 0x8000u;     // a token's first item: a literal or a match head (clear: a distance)
 constexpr uint32_t kItemRegion = 0x4000u;
+constexpr uint32_t kItemRegionShift = 9;
+constexpr uint32_t kItemHead = 0x0100u;    // with kItemTok: a match head (len-3 in bits 0..7)
 
 constexpr uint32_t kChecksumAdler32 = 1;  // = SFH_ZLIB
 constexpr uint32_t kChecksumCrc32 = 2;    // = SFH_GZIP

@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         // across the match phase -- a spill in this kernel)
         uint32_t t_now = t;
         asm volatile("" : "+v"(t_now));
-        const uint32_t flag = (t_now & (kSubBytes / 8 - 1)) == 0 ? (kItemRegion | ((rc * kRSubs + (8 * t_now) / kSubBytes) << 8)) : 0u;
+        const uint32_t flag = (t_now & (kSubBytes / 8 - 1)) == 0 ? (kItemRegion | ((rc * kRSubs + (8 * t_now) / kSubBytes) << kItemRegionShift)) : 0u;
         // an item of the chunk: uniform base + a 32-bit byte offset (no 64-bit address arithmetic)
         auto put_item = [&](uint32_t byte_off, uint32_t v) {
           *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(gi) + (uint64_t)byte_off) = (uint16_t)v;
@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         for (uint32_t k = 0; k < 8; ++k) {
           if ((lits >> k) & 1) {
             const uint32_t b = ((k < 4 ? B.x : B.y) >> (8 * (k & 3))) & 0xFFu;
-            put_item(item_at((1u << k) - 1u), k == 0 ? (b | flag) : b);
+            put_item(item_at((1u << k) - 1u), k == 0 ? (kItemTok | b | flag) : (kItemTok | b));
             atomicAdd(&s_hist[b], 1u);
           }
         }
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
               l3 = cap_len - 3;
               d1 = cap_run ? 0u : d1;
             }
-            put_item(at, (kItemMatch | l3) | (k == 0 ? flag : 0u));
+            put_item(at, (kItemTok | kItemHead | l3) | (k == 0 ? flag : 0u));
             put_item(at + 2, d1);
             atomicAdd(&s_hist[kHistLen + l3], 1u);
             atomicAdd(&s_hist[kHistD + smem[LD + (d1 < 256 ? d1 : 256 + (d1 >> 7))]], 1u);
@@ -2043,15 +2043,20 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
                                                      const uint32_t* __restrict__ rtok,
                                                      uint32_t* __restrict__ subidx,
                                                      uint8_t* __restrict__ dst) {
+  // @phase k4.setup trips=0 note=per chunk: tables, header
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[K4_STAGE_WORDS];
   __shared__ uint32_t s_lcode[288];
   __shared__ uint32_t s_dcode[32];
-  __shared__ uint32_t s_lenlut[256];
+  // ONE table for every kind of item (round 6; before: three tables and four reads per item, every item priced as all
+  // three kinds): entry = value (bits 0..19: the code, a length's extra bits appended) | bits of the value << 20 | extra
+  // bits to take from the item's own low bits << 25 (a distance: 0..13).  [kTabLit + byte], [kTabLen + len-3], and for a
+  // distance - 1 = d: [min(d, 254 + (d >> 7))] -- d itself below 256, one entry per 128 from there on (the symbols from
+  // 16 on cover whole multiples of 128)
+  __shared__ uint32_t s_tab[1024];
   __shared__ uint32_t s_wtot[2][K4_WAVES];
   __shared__ uint32_t s_rtok[kSubRegions];
-  // distance - 1 -> symbol: [d] below 256, [256 + (d >> 7)] from there on (symbols 16.. cover whole multiples of 128)
-  __shared__ uint8_t s_dsym[512];
-  static_assert(K4_THREADS == 512, "one table entry per thread");
+  static_assert(K4_THREADS == 512, "one table entry per thread and kind");
+  constexpr uint32_t kTabLit = 512, kTabLen = 768, kTabDistN = 510;
 
   const uint32_t t = threadIdx.x, lane = t & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
@@ -2144,16 +2149,25 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
     uint4* z = reinterpret_cast<uint4*>(s_stage);
     for (uint32_t k = t; k < (nwords + 2 + 3) / 4 && k < K4_STAGE_WORDS / 4; k += K4_THREADS) z[k] = make_uint4(0, 0, 0, 0);
   }
-  // literals: code | bits << 24 like a length entry (one select in the loop); 256..287 stay code | bits << 16
-  if (t < 288) s_lcode[t] = t < 256 ? (pre_code & 0xFFFFu) | ((pre_code >> 16) << 24) : pre_code;
-  else if (t < 320) s_dcode[t - 288] = pre_code | (dist_extra_of_sym(t - 288) << 24);  // code | length << 16 | extra bits << 24
+  if (t < 288) s_lcode[t] = pre_code;  // code | bits << 16
+  else if (t < 320) s_dcode[t - 288] = pre_code;
   if (t < kSubRegions) {
     s_rtok[t] = pre_rtok;
     sub[2 * t + 1] = pre_rtok;
   }
   __syncthreads();
-  if (t < 256) s_lenlut[t] = lenlut_entry(t, s_lcode);
-  s_dsym[t] = (uint8_t)dist_symbol_of(t < 256 ? t : (t - 256) << 7);
+  if (t < 256) {
+    const uint32_t le = lenlut_entry(t, s_lcode);  // value | bits << 24
+    s_tab[kTabLen + t] = (le & 0xFFFFFu) | ((le >> 24) << 20);
+    s_tab[kTabLit + t] = (pre_code & 0xFFFFu) | ((pre_code >> 16) << 20);
+  }
+  if (t < kTabDistN) {
+    const uint32_t sym = dist_symbol_of(t < 256 ? t : (t - 254) << 7);
+    const uint32_t dc = s_dcode[sym];  // code | length << 16
+    s_tab[t] = (dc & 0xFFFFu) | ((dc >> 16) << 20) | (dist_extra_of_sym(sym) << 25);
+  } else {
+    s_tab[t] = 0;  // (510, 511: where the distance index of a non-distance item may land; never used)
+  }
   {
     uint8_t* sb = reinterpret_cast<uint8_t*>(s_stage) + sh;
     const uint8_t* hb = reinterpret_cast<const uint8_t*>(C.header);
@@ -2172,7 +2186,7 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
     uint16_t* const wr = items + (uint64_t)chunk * kChunk;
     for (uint32_t pos = t; pos < nit; pos += K4_THREADS) {
       const uint32_t b = src[cbase + pos];
-      wr[pos] = (uint16_t)((pos & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((pos / kSubBytes) << 8)) : b);
+      wr[pos] = (uint16_t)(kItemTok | ((pos & (kSubBytes - 1)) == 0 ? (b | kItemRegion | ((pos / kSubBytes) << kItemRegionShift)) : b));
     }
     __threadfence_block();
     __syncthreads();  // (the stores have completed: every thread reads its items from memory below)
@@ -2180,61 +2194,63 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
   uint32_t running = 8 * sh + P.header_bits;
   uint32_t buf = 0;
   // items in batches of K4_THREADS*8 (one 16-byte load per thread); the next batch is in flight while this
-  // one is packed.  A thread also needs the item before its eight (is my first one a match's distance?): its
-  // neighbour's last -- over the DPP network, only a wave's first lane goes to memory.
-  // (reads past nit stay inside the chunk's kChunk-slot item area; they are masked below)
-  auto load_batch = [&](uint32_t i0, uint4& q, uint32_t& before) {
-    q = *reinterpret_cast<const uint4*>(it + i0);
-    before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q.w >> 16), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-    if (lane == 0) before = i0 ? it[i0 - 1] : 0u;
-  };
+  // one is packed.  (reads past nit stay inside the chunk's kChunk-slot item area; they are masked below)
   uint4 q_next = make_uint4(0, 0, 0, 0);
-  uint32_t before_next = 0;
-  if (nit) load_batch(t * K4_IPT, q_next, before_next);
+  if (nit) q_next = *reinterpret_cast<const uint4*>(it + t * K4_IPT);
+  // @phase k4.load trips=1 note=per batch of 4096 items
   for (uint32_t b0 = 0; b0 < nit; b0 += K4_THREADS * K4_IPT, buf ^= 1) {
     const uint32_t i0 = b0 + t * K4_IPT;
     const uint4 q = q_next;
-    const uint32_t before = before_next;
-    if (b0 + K4_THREADS * K4_IPT < nit) load_batch(i0 + K4_THREADS * K4_IPT, q_next, before_next);
-    // e[0] = the item before mine, e[1..8] = mine
-    const uint32_t e[K4_IPT + 1] = {before,        q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16,
-                                    q.z & 0xFFFFu, q.z >> 16,     q.w & 0xFFFFu, q.w >> 16};
-    // Every item is ONE unit of at most 28 bits: a literal its code; a match head its length code + extra bits; the
-    // item behind a head the distance code + extra bits.  (A match is not priced as one 48-bit unit: that needs
-    // 64-bit shifts and a two-part flush, and the head's thread would have to look at the next thread's item.)
+    const bool full = b0 + K4_THREADS * K4_IPT <= nit;  // (uniform) every item of the batch exists
+    if (b0 + K4_THREADS * K4_IPT < nit) q_next = *reinterpret_cast<const uint4*>(it + i0 + K4_THREADS * K4_IPT);
+    const uint32_t e[K4_IPT] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16, q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
+    // Every item is ONE unit of at most 28 bits: a literal its code; a match head its length code + extra bits; a
+    // distance its code + extra bits.  (A match is not priced as one 48-bit unit: that needs 64-bit shifts and a
+    // two-part flush, and the head's thread would have to look at the next thread's item.)  An item says what it is
+    // (kItemTok, kItemHead), so its place in the one table is arithmetic on the item alone, and all eight reads of a
+    // thread's batch are in flight together.
     uint32_t val[K4_IPT], nb[K4_IPT], mine = 0;
-    uint32_t starts = 0;  // bit k: item k starts a token and carries the region flag
-    // all table reads of the batch up front, pinned: twenty-four LDS reads in flight instead of chains of dependent
-    // ones.  Each item is looked up as all three kinds (any 15-bit value has a distance symbol, any low byte a
-    // literal and a length entry); what it really is picks one below
-    uint32_t lcv[K4_IPT], lev[K4_IPT], dcv[K4_IPT];
+    // @phase k4.lookup trips=1
+    uint32_t ent[K4_IPT];
 #pragma unroll
     for (uint32_t k = 0; k < K4_IPT; ++k) {
-      lcv[k] = s_lcode[e[k + 1] & 0xFFu];
-      lev[k] = s_lenlut[e[k + 1] & 0xFFu];
-      const uint32_t dd = e[k + 1] & 0x7FFFu;
-      dcv[k] = s_dcode[s_dsym[dd < 256 ? dd : 256 + (dd >> 7)]];
+      const uint32_t cur = e[k];
+      // a token's first item: byte or len-3 with kItemHead right above it -- its place among the literal and length entries;
+      // a distance - 1 (the item itself: bit 15 clear): itself below 256, 254 + (d >> 7) from there on
+      static_assert(kItemHead == 0x100 && kTabLen == kTabLit + 0x100 && kTabLit == 0x200, "a token's low nine bits are its table index");
+      uint32_t itok = (cur & 0x1FFu) | kTabLit, idist = min(cur, 254u + (cur >> 7));
+      asm volatile("" : "+v"(itok), "+v"(idist));  // (both are there: the choice is ONE select -- left alone, the compiler branches around each)
+      ent[k] = s_tab[cur >= kItemTok ? itok : idist];
     }
-    asm volatile("" : "+v"(lcv[0]), "+v"(lcv[1]), "+v"(lcv[2]), "+v"(lcv[3]), "+v"(lcv[4]), "+v"(lcv[5]), "+v"(lcv[6]), "+v"(lcv[7]),
-                      "+v"(lev[0]), "+v"(lev[1]), "+v"(lev[2]), "+v"(lev[3]), "+v"(lev[4]), "+v"(lev[5]), "+v"(lev[6]), "+v"(lev[7]),
-                      "+v"(dcv[0]), "+v"(dcv[1]), "+v"(dcv[2]), "+v"(dcv[3]), "+v"(dcv[4]), "+v"(dcv[5]), "+v"(dcv[6]), "+v"(dcv[7]));
+    asm volatile("" : "+v"(ent[0]), "+v"(ent[1]), "+v"(ent[2]), "+v"(ent[3]), "+v"(ent[4]), "+v"(ent[5]), "+v"(ent[6]), "+v"(ent[7]));
+    // items that start a token AND carry the region flag (bits 15 and 14), two to a dword: rare (one in ~500)
+    auto both = [](uint32_t w) { return w & (w << 1) & 0x80008000u; };
+    uint32_t flagged = both(q.x) | both(q.y) | both(q.z) | both(q.w);
+    if (!full) {  // (uniform) a chunk's last batch: what lies behind the last item is no item -- an empty entry is no bits
+      uint32_t left = nit - i0;  // (wraps to something huge for a thread wholly inside: every k is below it)
+      left = i0 < nit ? left : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < K4_IPT; ++k) ent[k] = k < left ? ent[k] : 0u;
+      flagged = 1;  // ... and the flags are looked at item by item
+    }
 #pragma unroll
     for (uint32_t k = 0; k < K4_IPT; ++k) {
-      const uint32_t cur = e[k + 1];
-      const bool dist = (e[k] & kItemMatch) != 0;      // the item behind a match head: dist - 1
-      const bool head = (cur & kItemMatch) != 0;
-      const bool live = i0 + k < nit;
-      const uint32_t dc = dcv[k];                       // code | length << 16 | extra bits << 24
-      const uint32_t dl = (dc >> 16) & 0xFFu, de = dc >> 24;
-      const uint32_t vd = (dc & 0xFFFFu) | (__builtin_amdgcn_ubfe(cur, 0, de) << dl);
-      const uint32_t w = head ? lev[k] : lcv[k];        // value | bits << 24
-      const uint32_t v = dist ? vd : (w & 0xFFFFFFu);
-      const uint32_t n = dist ? dl + de : w >> 24;
-      val[k] = live ? v : 0u;
-      nb[k] = live ? n : 0u;
-      starts |= (live && !dist && (cur & kItemRegion)) ? 1u << k : 0u;
+      // @phase k4.price trips=1
+      const uint32_t en = ent[k];
+      const uint32_t dl = __builtin_amdgcn_ubfe(en, 20, 5), de = en >> 25;  // bits of the code, extra bits from the item (a distance's)
+      val[k] = (__builtin_amdgcn_ubfe(e[k], 0, de) << dl) | (en & 0xFFFFFu);
+      nb[k] = dl + de;
       mine += nb[k];
     }
+    uint32_t starts = 0;  // bit k: item k starts a token and carries the region flag
+    if (flagged) {
+      uint32_t i_now = i0;
+      asm volatile("" : "+v"(i_now));  // (opaque: the eight compares belong to this rare path, not in front of the loop)
+#pragma unroll
+      for (uint32_t k = 0; k < K4_IPT; ++k)
+        starts |= ((e[k] & (kItemTok | kItemRegion)) == (kItemTok | kItemRegion) && i_now + k < nit) ? 1u << k : 0u;
+    }
+    // @phase k4.scan trips=1
     const uint32_t incl = wave_incl_scan(mine, lane);
     if (lane == 63) s_wtot[buf][wave] = incl;
     __syncthreads();
@@ -2248,16 +2264,18 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
     // the thread's codes are contiguous in the stream: gather them in a 64-bit window
     // and OR whole words, instead of one to three atomics per token
     const uint32_t pos = running + pre + incl - mine;
+    // @phase k4.subindex trips=1
     if (starts) {
       // k_lz77 flags the first token of every 1024-byte parse region (32 per chunk): its bit offset is the
       // sub-index entry
       uint32_t pk = pos;
 #pragma unroll
       for (uint32_t k = 0; k < K4_IPT; ++k) {
-        if ((starts >> k) & 1) sub[2 * ((e[k + 1] >> 8) & 31u)] = pk - 8 * sh;
+        if ((starts >> k) & 1) sub[2 * ((e[k] >> kItemRegionShift) & 31u)] = pk - 8 * sh;
         pk += nb[k];
       }
     }
+    // @phase k4.pack trips=1
     uint32_t wi = pos >> 5, ab = pos & 31;
     uint64_t acc = 0;
     auto put = [&](uint32_t v32, uint32_t n) {
@@ -2275,6 +2293,7 @@ __global__ __launch_bounds__(K4_THREADS, 4) void k_emit(const uint8_t* __restric
     running += all;
   }
   __syncthreads();
+  // @phase k4.flush trips=0 note=per chunk
   if (t < kSubRegions && s_rtok[t] >= ntok) sub[2 * t] = running - 8 * sh;  // regions past the data: the end-of-block code
   if (t == 0) {
     // end of block, then (unless this is the stream's final block) an empty stored

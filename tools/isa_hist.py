@@ -93,7 +93,7 @@ def compile_asm(src, extra, out):
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 
 
-def kernel_body(asm_path, pattern):
+def kernel_body(asm_path, pattern, src_name):
     """lines of the first kernel whose mangled name matches `pattern`: [(kind, text)] with kind in loc / label / inst"""
     rx = re.compile(pattern)
     lines, name, on = [], None, False
@@ -106,7 +106,8 @@ def kernel_body(asm_path, pattern):
         s = ln.strip()
         if s.startswith(".loc"):
             p = s.split()
-            lines.append(("loc", int(p[2])))
+            # a line of another file (a HIP header's min(), a builtin wrapper) says nothing about the phase: 0 = "inherit"
+            lines.append(("loc", int(p[2]) if os.path.basename(src_name) in s else 0))
         elif re.match(r"^\.LBB\d+_\d+:", ln):
             d = re.search(r"Depth=(\d+)", ln)
             lines.append(("label", (s.split(":")[0], int(d.group(1)) if d else 0)))
@@ -156,8 +157,8 @@ def main():
         g, p = os.path.join(td, "g.s"), os.path.join(td, "p.s")
         compile_asm(args.src, ["-gline-tables-only"], g)
         compile_asm(args.src, [], p)
-        name, body = kernel_body(g, args.kernel)
-        _, plain = kernel_body(p, args.kernel)
+        name, body = kernel_body(g, args.kernel, args.src)
+        _, plain = kernel_body(p, args.kernel, args.src)
     n_g = sum(1 for k, _ in body if k == "inst")
     n_p = sum(1 for k, _ in plain if k == "inst")
 
