@@ -349,6 +349,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
   bool skip = false;                     // stored fast path (uniform): the chunk in hand took it (decided behind its first round's parse)
   bool short_probe = false;              // (uniform) the strip's previous chunk took it: only kSkipProbe positions of this one's span are searched
   bool lds_stale = false;                // (uniform) the rounds behind a chunk's probe round were taken in one go: the window in LDS is not the strip's
+  uint32_t stale_span = 0;               // ... and the positions of that chunk that were searched and inserted (its probe span)
 
   // @phase round.head trips=1 note=round bookkeeping
   for (uint32_t r = 0; r < nrounds; ++r) {
@@ -375,19 +376,23 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       static_assert(kUnits > 2 * K1_THREADS && kUnits <= 3 * K1_THREADS, "shift: three units per thread");
       const bool reload = lds_stale;  // (uniform)
       if (reload) {
-        // behind a chunk that took the stored fast path (its later rounds never came through here): the window, this
-        // round and the look-ahead come from the input again -- the strip's last 32 KiB, read a few microseconds ago --
-        // instead of from three shifts per skipped chunk.  (rb >= kChunk: the skipped chunk lies in this strip.  Every
+        // behind a chunk that took the stored fast path (its later rounds never came through here): what the window must hold
+        // and this round come from the input again instead of from three shifts per skipped chunk.  Of the window only the
+        // skipped chunk's PROBE SPAN was ever inserted into the table (stale_span positions at the window's start, and
+        // anything older is farther back than 32 KiB: rejected by distance, its bytes read and dropped like any outdated
+        // entry's), so only that span and what a match starting in it can reach (258 bytes + the compares' slack) are
+        // loaded; the rest of the window stays whatever it is.  (rb >= kChunk: the skipped chunk lies in this strip.  Every
         // reader of the old LDS bytes is behind the barrier at the skipped chunk's end.)
-        constexpr uint32_t kAll = (kWindow + kRound + kLook) / 16;
-        static_assert(kAll <= 3 * K1_THREADS, "reload: three units per thread");
+        constexpr uint32_t kReach = 320, kRoundUnits = (kRound + kLook) / 16;
+        static_assert(kReach >= 258 + kCap + 32 && (kSkipSpan + kReach) / 16 <= K1_THREADS && kRoundUnits <= K1_THREADS, "reload: two units per thread");
+        const uint32_t wunits = (stale_span + kReach) / 16;
         const uint8_t* const wp = sp + (rb - kWindow);
         if (rb + kRound + kLook <= n) {
-#pragma unroll
-          for (uint32_t k = 0; k < 3; ++k)
-            if (k * K1_THREADS + t < kAll) s4[k * K1_THREADS + t] = reinterpret_cast<const uint4*>(wp)[k * K1_THREADS + t];
+          if (t < wunits) s4[t] = reinterpret_cast<const uint4*>(wp)[t];
+          if (t < kRoundUnits) s4[kWindow / 16 + t] = reinterpret_cast<const uint4*>(wp)[kWindow / 16 + t];
         } else {  // the strip ends inside: word by word, zeros beyond the end
-          for (uint32_t i = t; i < 4 * kAll; i += K1_THREADS) s_data[i] = load4(rb - kWindow + 4 * i);
+          for (uint32_t i = t; i < 4 * wunits; i += K1_THREADS) s_data[i] = load4(rb - kWindow + 4 * i);
+          for (uint32_t i = t; i < 4 * kRoundUnits; i += K1_THREADS) s_data[kWindow / 4 + i] = load4(rb + 4 * i);
         }
         lds_stale = false;
       } else {
@@ -1294,9 +1299,17 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         const uint32_t clen = (n - cstart) < kChunk ? (n - cstart) : kChunk;  // the chunk's bytes
         const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + 8 * t]);
         if (clen == kChunk) {
+          // the chunk's bytes behind this round: [kRound, kRound + kLook) lie in the look-ahead, the kRound bytes from there on
+          // are the thread's prefetched eight (pre_lo, pre_hi: asked for in the stage, or behind the match phase), the rest
+          // comes in two loads -- every byte of the input is fetched by this kernel once
+          static_assert(kRoundsPerChunk == 4, "the fast path's loads");
           uint2 w[kRoundsPerChunk - 1];
-#pragma unroll
-          for (uint32_t k = 1; k < kRoundsPerChunk; ++k) w[k - 1] = *reinterpret_cast<const uint2*>(sp + cstart + k * kRound + 8 * t);
+          w[0] = make_uint2(pre_lo, pre_hi);
+          w[1] = *reinterpret_cast<const uint2*>(sp + cstart + 2 * kRound + kLook + 8 * t);
+          w[2] = make_uint2(0, 0);
+          const bool tail = 8 * t + kLook < kRound;  // (the last kLook bytes of that span belong to the next chunk -- or to nobody)
+          if (tail) w[2] = *reinterpret_cast<const uint2*>(sp + cstart + 3 * kRound + kLook + 8 * t);
+          const uint32_t look = t < kLook / 4 ? s_data[(kWindow + kRound) / 4 + t] : 0u;
           // The chunk's 32,768 byte counts.  On the histogram itself a wave's 64 random bytes pile up on the LDS banks (one
           // atomic instruction: six to eight cycles; 0.060 of the fast path's 0.186 ms per 256 MiB, 0.043 now).  The window is dead from
           // here on (lds_stale), so its 32 KiB hold 32 COPIES of the 256 counters, copy = lane mod 32 at dword
@@ -1313,8 +1326,13 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             for (uint32_t j = 0; j < 8; ++j) atomicAdd(&rep[(((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xFFu) * 32u], 1u);
           };
           count8(B.x, B.y);
+          count8(w[0].x, w[0].y);
+          count8(w[1].x, w[1].y);
+          if (tail) count8(w[2].x, w[2].y);
+          if (t < kLook / 4) {
 #pragma unroll
-          for (uint32_t k = 1; k < kRoundsPerChunk; ++k) count8(w[k - 1].x, w[k - 1].y);
+            for (uint32_t j = 0; j < 4; ++j) atomicAdd(&rep[((look >> (8 * j)) & 0xFFu) * 32u], 1u);
+          }
           __syncthreads();
           {
             const uint4 p = z4[2 * t], q = z4[2 * t + 1];  // thread t: copies 8 (t mod 4) .. + 8 of byte value t / 4
@@ -1332,6 +1350,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         if (t < kSubRegions) rtok_out[chunk * kSubRegions + t] = t * kSubBytes < clen ? t * kSubBytes : clen;
         skip = true;
         lds_stale = true;
+        stale_span = short_probe ? kSkipProbe : kSkipSpan;  // (the positions of this chunk the match phase went over)
         chunk_done = true;
         tot_tok = clen;  // tokens = items = positions
         tot_items = clen;
