@@ -315,12 +315,15 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
   const uint32_t n = (uint32_t)((n_total - sbase) < (uint64_t)strip_bytes ? (n_total - sbase) : strip_bytes);
   const uint32_t chunk0 = strip * (strip_bytes / kChunk);
   const uint8_t* const sp = src + sbase;
+  // @phase inherit
   // four bytes of the strip at `pos` (multiple of 4), zero beyond n
   auto load4 = [&](uint32_t pos) -> uint32_t {
     if (pos + 4 <= n) return *reinterpret_cast<const uint32_t*>(sp + pos);
+    // @phase +tail trips=0 note=the strip's last bytes, byte by byte
     uint32_t w = 0;
     for (uint32_t b = 0; pos + b < n; ++b) w |= (uint32_t)sp[pos + b] << (8 * b);
     return w;
+    // @phase inherit
   };
 
   // ---- prologue: empty table and histogram; the strip's first kLook bytes where the first shift finds them ----
