@@ -40,3 +40,27 @@ def test_source_stamp():
 
     a, b = source_stamp(), source_stamp()
     assert a == b and len(a["csrc_sha256"]) == 16 and a["commit"]
+
+
+def test_isa_table_of_the_match_kernel(tmp_path):
+    """tools/isa_hist.py (round 6): the per-phase instruction table of the default k_lz77 -- the line tables it compiles with
+    leave the code as it is, every phase of the source's `@phase` markers gets instructions, and the dynamic total per wave-round
+    reproduces the counter pass it is quoted beside (SQ_INSTS_VALU = 1,078 per wave-round, profiles/r06_pmc_summary.json) to 15 %."""
+    import json
+    import sys
+
+    out = tmp_path / "isa.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hist.py"), "--pmc-valu-per-wave-round", "1078", "--json", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "** DIFFER **" not in r.stdout
+    d = json.load(open(out))
+    rows = {x["phase"]: x for x in d["rows"]}
+    for ph in ("stage", "match.first", "match.second", "match.insert", "parse.take", "parse.transfer", "parse.reconcile", "parse.counts",
+               "emit.literals", "emit.matches"):
+        assert rows[ph]["static_valu"] > 0 and rows[ph]["dyn_valu"] > 0, ph
+    tot = d["total"]
+    assert 0.9 < tot["dyn_valu"] / 1078 < 1.15, tot
+    assert 2.8 < tot["dyn_valu_cycles"] / tot["dyn_valu"] < 3.8  # the mix: half the instructions in the 2.3-cycle class
+    match = sum(v["dyn_valu_cycles"] for k, v in rows.items() if k.startswith("match"))
+    assert 0.4 < match / tot["dyn_valu_cycles"] < 0.6  # the match phase is about half of the kernel's vector issue

@@ -50,7 +50,9 @@ def extra_weights(path):
     try:
         for ln in open(path):
             m = re.match(r"(v_\w+)\s.*=\s*([0-9.]+) cycles", ln)
-            if m and "PAIR" not in ln:
+            # (the lone `v_cndmask_b32 ... vcc` line is a chain on VCC without a writer, 23 cycles: not an issue cost --
+            # the PAIR line is: compare 4.15 + select 2.25; encodings with a suffix are classed by their suffix anyway)
+            if m and "PAIR" not in ln and float(m.group(2)) < 8 and not re.search(r"_(e64|dpp|sdwa)$", m.group(1)):
                 out[m.group(1)] = float(m.group(2))
     except OSError:
         pass

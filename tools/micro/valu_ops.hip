@@ -53,11 +53,25 @@ __global__ __launch_bounds__(1024, 8) void k(uint32_t* out, uint32_t seed, int i
   if (OP == 33) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(r) : "v"(x), "v"(y));                                    \
   if (OP == 34) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(r) : "v"(x));                                       \
   if (OP == 35) asm volatile("v_add_u32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(x));      \
-  if (OP == 36) asm volatile("v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(r) : "v"(x));
-    uint64_t aa = a, bb = b, cc = c, dd = d, ee = e, ff = f, gg = g, hh = h;
+  if (OP == 36) asm volatile("v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(r) : "v"(x)); \
+  if (OP == 37) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(r) : "v"(x), "v"(y));                                    \
+  if (OP == 38) asm volatile("v_max_u32 %0, %0, %1" : "+v"(r) : "v"(x));                                               \
+  if (OP == 39) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(r) : "v"(x), "v"(y));                                    \
+  if (OP == 40) asm volatile("v_and_b32_e64 %0, %0, %1" : "+v"(r) : "s"((uint32_t)mask));                                         \
+  if (OP == 41) asm volatile("v_cmp_lt_u32_e64 %1, %0, %2" : "+v"(r), "=s"(sm) : "v"(x));                               \
+  if (OP == 42) asm volatile("v_add_lshl_u32 %0, %0, %1, 1" : "+v"(r) : "v"(x));                                        \
+  if (OP == 43) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(*(uint64_t*)&r##r) : "v"(*(uint64_t*)&r##r));         \
+  if (OP == 44) asm volatile("v_readlane_b32 %1, %0, 3\n\ts_nop 3" : "+v"(r), "=s"(sl));                                \
+  if (OP == 45) asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(r) : "s"((uint32_t)mask));                                           \
+  if (OP == 46) asm volatile("v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r));               \
+  if (OP == 47) asm volatile("v_mov_b32 %0, 0x12345678" : "=v"(r));                                                     \
+  if (OP == 48) asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(*(uint64_t*)&r##r) : "v"(x));
+    uint64_t aa = a, bb = b, cc = c, dd = d, ee = e, ff = f, gg = g, hh = h, sm = 0;
+    uint32_t sl = 0;
+    (void)sm; (void)sl;
     (void)aa; (void)bb; (void)cc; (void)dd; (void)ee; (void)ff; (void)gg; (void)hh;
     REP8(ONE(a, b, s) ONE(b, c, s) ONE(c, d, s) ONE(d, e, s) ONE(e, f, s) ONE(f, g, s) ONE(g, h, s) ONE(h, a, s))
-    if (OP == 14) { a ^= (uint32_t)aa; b ^= (uint32_t)bb; c ^= (uint32_t)cc; d ^= (uint32_t)dd; e ^= (uint32_t)ee; f ^= (uint32_t)ff; g ^= (uint32_t)gg; h ^= (uint32_t)hh; }
+    if (OP == 14 || OP == 43 || OP == 48) { a ^= (uint32_t)aa; b ^= (uint32_t)bb; c ^= (uint32_t)cc; d ^= (uint32_t)dd; e ^= (uint32_t)ee; f ^= (uint32_t)ff; g ^= (uint32_t)gg; h ^= (uint32_t)hh; }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h;
 }
@@ -113,5 +127,9 @@ int main() {
   run<29>("v_cndmask_b32_e64 (sgpr mask)", out, ghz); run<30>("v_bitop3_b32", out, ghz); run<31>("v_alignbit_b32", out, ghz);
   run<32>("v_xad_u32", out, ghz); run<33>("v_sad_u8", out, ghz); run<34>("v_lshl_add_u32", out, ghz);
   run<35>("v_add_u32_dpp wave_shr:1", out, ghz); run<36>("v_and_b32_sdwa", out, ghz);
+  run<37>("v_bfi_b32", out, ghz); run<38>("v_max_u32 (VOP2)", out, ghz); run<39>("v_or3_b32", out, ghz);
+  run<40>("v_and_b32_e64 (sgpr operand)", out, ghz); run<41>("v_cmp_lt_u32_e64 (to sgpr)", out, ghz); run<42>("v_add_lshl_u32", out, ghz);
+  run<43>("v_lshl_add_u64", out, ghz); run<44>("v_readlane_b32 (+ s_nop 3)", out, ghz); run<45>("v_writelane_b32", out, ghz);
+  run<46>("v_max_u32_dpp row_shr:1", out, ghz); run<47>("v_mov_b32 literal", out, ghz); run<48>("v_lshrrev_b64", out, ghz);
   return 0;
 }
