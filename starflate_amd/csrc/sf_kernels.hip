@@ -387,15 +387,19 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         // loaded; the rest of the window stays whatever it is.  (rb >= kChunk: the skipped chunk lies in this strip.  Every
         // reader of the old LDS bytes is behind the barrier at the skipped chunk's end.)
         constexpr uint32_t kReach = 320, kRoundUnits = (kRound + kLook) / 16;
-        static_assert(kReach >= 258 + kCap + 32 && (kSkipSpan + kReach) / 16 <= K1_THREADS && kRoundUnits <= K1_THREADS, "reload: two units per thread");
+        static_assert(kReach >= 258 + kCap + 32 && (kSkipSpan + kReach) / 16 < K1_THREADS - 1 && kRoundUnits < K1_THREADS - 1, "reload: two units per thread, the last thread a third");
         const uint32_t wunits = (stale_span + kReach) / 16;
         const uint8_t* const wp = sp + (rb - kWindow);
+        // (... and the window's LAST bytes: the byte in front of the round's first position is looked at whenever a match
+        // starts there -- the odd neighbour's byte check of a near candidate, the run test of the wave-wide extension)
         if (rb + kRound + kLook <= n) {
           if (t < wunits) s4[t] = reinterpret_cast<const uint4*>(wp)[t];
           if (t < kRoundUnits) s4[kWindow / 16 + t] = reinterpret_cast<const uint4*>(wp)[kWindow / 16 + t];
+          if (t == K1_THREADS - 1) s4[kWindow / 16 - 1] = reinterpret_cast<const uint4*>(wp)[kWindow / 16 - 1];
         } else {  // the strip ends inside: word by word, zeros beyond the end
           for (uint32_t i = t; i < 4 * wunits; i += K1_THREADS) s_data[i] = load4(rb - kWindow + 4 * i);
           for (uint32_t i = t; i < 4 * kRoundUnits; i += K1_THREADS) s_data[kWindow / 4 + i] = load4(rb + 4 * i);
+          if (t == K1_THREADS - 1) s_data[kWindow / 4 - 1] = load4(rb - 4);
         }
         lds_stale = false;
       } else {

@@ -642,6 +642,59 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
             assert st == 0 and back == data.tobytes(), it
 
 
+def test_fuzz_stored_fast_path_switching(compressor):
+    """Seeded fuzz of the stored fast path's switching (round 6: a skipped chunk's later rounds in one go, the window reloaded
+    from the input behind it, bank-private byte counts): inputs stitched from CHUNK-SCALE pieces -- noise (stored), six-bit
+    noise (the fast path taken, the chunk NOT stored: k_emit takes the items from the input), text, zeros, text right behind
+    noise with matches into the noise's probe span -- so that the path switches on and off at every offset of a strip, with
+    ragged tails; every effort family, the switch on and off, strips of 1..8 chunks.  Bit-exact against the specification,
+    round trips through the oracle decoder and the GPU decoder.  SF_FUZZ_N scales it (default 60)."""
+    import os
+
+    rng = np.random.default_rng(20261005)
+    text = synth.gen_text(600_000, seed=91)
+
+    def piece(n):
+        kind = int(rng.integers(0, 7))
+        if kind in (0, 1):
+            return rng.integers(0, 256, n, dtype=np.uint8)
+        if kind == 2:
+            return rng.integers(0, 64, n, dtype=np.uint8)  # high entropy for the probe, compressible for the plan
+        if kind == 3:
+            return np.zeros(n, np.uint8)
+        if kind == 4:  # noise whose head repeats a little later: matches that reach back into a skipped chunk's probe span
+            a = rng.integers(0, 256, n, dtype=np.uint8)
+            k = int(min(n // 3, rng.integers(100, 3000)))
+            if k:
+                a[n - k:] = a[:k]
+            return a
+        o = int(rng.integers(0, text.size - n)) if n < text.size else 0
+        return text[o:o + n]
+
+    efforts = [("default", {}), ("thorough", dict(stride2=0, step=512)), ("recent_all", dict(recent=1, near_depth=1, link_steps=1, stride2=0, step=512)),
+               ("best", dict(chain_depth=8)), ("fastest", dict(depth=1, use_near=0)), ("max", dict(stride2=0, step=512, hash_bits=12, long_hash_bytes=7))]
+    for it in range(int(os.environ.get("SF_FUZZ_N", "60"))):
+        parts = []
+        for _ in range(int(rng.integers(1, 9))):
+            n = int(rng.choice([CHUNK // 4, CHUNK // 2, CHUNK, CHUNK, 2 * CHUNK, 3 * CHUNK, int(rng.integers(1, 3 * CHUNK))]))
+            parts.append(np.ascontiguousarray(piece(n)[:n]))
+        data = np.concatenate(parts)
+        if it % 3 == 0:
+            data = data[: data.size - int(rng.integers(0, min(data.size, CHUNK)))]  # a ragged tail inside the last chunk
+        fast = it % 5 != 4
+        bb = [0, CHUNK, 2 * CHUNK, 4 * CHUNK, 8 * CHUNK][it % 5]
+        lazy = [3, 3, 0, 2][it % 4]
+        effort, ekw = efforts[it % len(efforts)]
+        got = np.frombuffer(compressor.compress(data, lazy=lazy, stored_fast_path=fast, block_bytes=bb, effort=effort), np.uint8)
+        want = O.compress(data, O.default_params(lazy=lazy, fast_skip=int(fast), strip_bytes=bb, **ekw))
+        assert np.array_equal(got, want), (it, data.size, lazy, fast, bb, effort, np.flatnonzero(got[:min(got.size, want.size)] != want[:min(got.size, want.size)])[:3])
+        if it % 4 == 0:
+            _roundtrip(got, data)
+            idx, sub = compressor.last_index(), compressor.last_subindex()
+            back, st = compressor.decompress(got, idx, data.size, subindex=sub, block_bytes=compressor.last_block_bytes())
+            assert st == 0 and back == data.tobytes(), it
+
+
 def test_repeated_calls_do_not_leak_or_drift():
     """200 calls of varying size on one context (growing and shrinking inputs, all entry points): device memory in
     use by the library stays bounded by its largest call, results stay identical."""
