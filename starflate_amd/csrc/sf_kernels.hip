@@ -810,6 +810,12 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
         // extra HBM reads per GiB of input: FETCH_SIZE 274 against 145 MiB per 256 MiB, tools/exp/pmc_fetch_variants.sh)
         uint8_t* const gst = reinterpret_cast<uint8_t*>(gi) + stage_off;
         // first part -> second part.  (LONG: f_m0.. f_q1 carry the four far candidates as KEYS rank << 16 | 0xFFFF - distance)
+        // A bucket is named by its BYTE OFFSET in its table (hash << 2), made by one shift and one mask of the product: the
+        // index would be shifted left again for every read and every atomic (`v_lshlrev_b32`: 4.1 cycles against 2.3 for
+        // the mask; five of them per search in the phase where an instruction costs most, section 3 K1 "Round 6")
+        auto bucket_of = [](uint32_t product) { return (product >> (30 - HB)) & (((1u << HB) - 1u) << 2); };
+        static_assert(HB <= kHashBits && 30 - HB > 0, "bucket offsets");
+        auto tab_at = [&](uint32_t* table, uint32_t off) -> uint32_t& { return *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(table) + off); };
         uint32_t f_a0 = 0, f_a1 = 0, f_h = 0, f_m0 = 0, f_m1 = 0, f_q0 = 0, f_q1 = 0, f_maxlen = 0;
         // @phase match.loop trips=9 depth=2 note=nine intervals for eight steps
         for (uint32_t it = 0; it <= nsteps; ++it) {
@@ -832,19 +838,20 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
               const uint32_t d0 = lds32(wb, 0), d1 = lds32(wb, 4), d2 = lds32(wb, 8);
               const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh0), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh0);
               const uint32_t hmul = a0 * 2654435761u;
-              const uint32_t h = hmul >> (32 - HB);
-              const uint32_t farv = s_table[h];
+              const uint32_t h = bucket_of(hmul);       // (byte offset of the bucket: see bucket_of)
+              const uint32_t farv = tab_at(s_table, h);
               if constexpr (STRIDE2) {
                 // the odd position behind this one is only inserted: its four bytes are in the registers already, its
                 // bucket is read beside this one's
-                ins2_h = (__builtin_amdgcn_alignbyte(a1, a0, 1) * 2654435761u) >> (32 - kHashBits);
-                ins2_v = s_table[ins2_h];
+                static_assert(!STRIDE2 || HB == kHashBits, "the odd position's bucket is in the one table");
+                ins2_h = bucket_of(__builtin_amdgcn_alignbyte(a1, a0, 1) * 2654435761u);
+                ins2_v = tab_at(s_table, ins2_h);
               }
               [[maybe_unused]] uint32_t h2 = 0, farv2 = 0;
               if constexpr (LONG) {
                 // bytes 4..6 join the hash (the specification's long hash: two multiplicative hashes xored)
-                h2 = (hmul ^ ((a1 & 0xFFFFFFu) * 0x85EBCA6Bu)) >> (32 - HB);
-                farv2 = s_table2[h2];
+                h2 = bucket_of(hmul ^ ((a1 & 0xFFFFFFu) * 0x85EBCA6Bu));
+                farv2 = tab_at(s_table2, h2);
               }
               const uint32_t f0 = farv >> 16, f1 = farv & 0xFFFFu;
               const uint32_t m0 = entry_rel<SH>(f0), m1 = entry_rel<SH>(f1);  // coded positions + 1, from the epoch's start
@@ -896,7 +903,7 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
               const uint32_t ad1 = sb + psK1;           // LDS address of the byte before the position
               const uint32_t wb = sb + pswK;
               const uint32_t a0 = f_a0, a1 = f_a1, maxlen = f_maxlen;
-              uint32_t neare = NEAR ? s_table[f_h] : 0u;
+              uint32_t neare = NEAR ? tab_at(s_table, f_h) : 0u;
               uint32_t pbyte = STRIDE2 ? smem[ad1] : 0u;  // the odd position's byte (used if a match is found)
               // this position's bytes 8..15 (for the winner's extension, if it comes to that)
               uint32_t d2 = lds32(wb, 8), d3 = lds32(wb, 12), d4 = lds32(wb, 16);
@@ -973,16 +980,16 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
             // need not insert: that one's position is lower, its code larger (a run would otherwise serialise the wave's
             // atomics)
             const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)~ins_h, (int)ins_h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-            if (hp != ins_h) atomicMax(&s_table[ins_h], ins_v);
+            if (hp != ins_h) atomicMax(&tab_at(s_table, ins_h), ins_v);
             if constexpr (LONG) {
               const uint32_t hp2 = (uint32_t)__builtin_amdgcn_update_dpp((int)~ins2_h, (int)ins2_h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-              if (hp2 != ins2_h) atomicMax(&s_table2[ins2_h], ins2_v);
+              if (hp2 != ins2_h) atomicMax(&tab_at(s_table2, ins2_h), ins2_v);
             }
             if constexpr (STRIDE2) {
               // the odd position behind: the same, among the wave's odd positions (and its own even position's bucket has
               // the larger code already)
               const uint32_t hp2 = (uint32_t)__builtin_amdgcn_update_dpp((int)~ins2_h, (int)ins2_h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-              if (hp2 != ins2_h && ins2_h != ins_h) atomicMax(&s_table[ins2_h], ins2_v);
+              if (hp2 != ins2_h && ins2_h != ins_h) atomicMax(&tab_at(s_table, ins2_h), ins2_v);
             }
           }
           // @phase match.barrier2 trips=8 depth=2
