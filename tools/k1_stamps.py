@@ -11,7 +11,7 @@ import torch
 from starflate_amd import Compressor, _capi, synth
 
 def _input(n):
-    """SF_WORKLOAD = text (default) | mixed | source | binary: the bench generators or the real bytes of
+    """SF_WORKLOAD = text (default) | mixed | random | source | binary: the bench generators or the real bytes of
     starflate_amd/realbytes.py (tiled to n: the window is 32 KiB and strips are independent, so tiling a corpus far longer
     than that changes neither the parse nor the ratio)."""
     import numpy as np
@@ -21,6 +21,10 @@ def _input(n):
         return synth.gen_text_torch(n, seed=3, device="cuda")
     if w == "mixed":
         return torch.from_numpy(synth.gen_mixed(n, seed=4)).cuda()
+    if w == "random":
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        return torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
     buf = realbytes.source(96 << 20) if w == "source" else realbytes.binary(min(n, 256 << 20))
     return torch.from_numpy(np.resize(buf, n)).cuda()
 
