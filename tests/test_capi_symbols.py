@@ -97,3 +97,23 @@ def test_product_never_imports_the_oracle():
                 with open(os.path.join(dirpath, fn), errors="ignore") as f:
                     txt = f.read()
                 assert "oracle_lib" not in txt and "sf_oracle" not in txt and "sfo_" not in txt, fn
+
+
+def test_item_format_constants_match_the_python_decoder():
+    """k_lz77 -> k_emit items (sf_device.h: kItemTok, kItemHead, kItemRegion, kItemRegionShift; round 6: every item says what it is)
+    are decoded by Compressor.debug_tokens for the stage-parity tests: the two spellings of the format must not drift apart."""
+    import inspect
+
+    from starflate_amd import compressor
+
+    with open(os.path.join(ROOT, "starflate_amd", "csrc", "sf_device.h")) as f:
+        h = f.read()
+    c = {k: int(v, 0) for k, v in re.findall(r"constexpr uint32_t (kItem\w+) = (0x[0-9A-Fa-f]+|\d+)u?;", h)}
+    assert c == {"kItemTok": 0x8000, "kItemRegion": 0x4000, "kItemRegionShift": 9, "kItemHead": 0x0100}, c
+    assert c["kItemHead"] == 1 << 8 and c["kItemRegionShift"] == 9  # a token's low nine bits index k_emit's table; the region index sits above them
+    src = inspect.getsource(compressor.Compressor.debug_tokens)
+    for needle in ("(it & 0x8000) != 0", "(it & 0x0100) != 0", "(it & 0x4000) != 0", "(it >> 9) & 31"):
+        assert needle in src, needle
+    with open(os.path.join(ROOT, "include", "starflate_hip.h")) as f:
+        doc = f.read()
+    assert "0x8000 | byte" in doc and "0x8100 | len-3" in doc and "bits 9..13" in doc
