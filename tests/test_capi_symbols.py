@@ -109,7 +109,7 @@ def test_item_format_constants_match_the_python_decoder():
     with open(os.path.join(ROOT, "starflate_amd", "csrc", "sf_device.h")) as f:
         h = f.read()
     c = {k: int(v, 0) for k, v in re.findall(r"constexpr uint32_t (kItem\w+) = (0x[0-9A-Fa-f]+|\d+)u?;", h)}
-    assert c == {"kItemTok": 0x8000, "kItemRegion": 0x4000, "kItemRegionShift": 9, "kItemHead": 0x0100}, c
+    assert c == {"kItemTok": 0x8000, "kItemRegion": 0x4000, "kItemRegionShift": 9, "kItemHead": 0x0100, "kItemsSkipped": 0x80000000}, c
     assert c["kItemHead"] == 1 << 8 and c["kItemRegionShift"] == 9  # a token's low nine bits index k_emit's table; the region index sits above them
     src = inspect.getsource(compressor.Compressor.debug_tokens)
     for needle in ("(it & 0x8000) != 0", "(it & 0x0100) != 0", "(it & 0x4000) != 0", "(it >> 9) & 31"):
