@@ -60,6 +60,7 @@ struct sfh_ctx {
   int sizes_cap = 0;
   int order_ok[2] = {0, 0};      // sfh_lds_order_check per op (0 exchange: chains, 1 masked-or: recent): 0 not run, 1 holds, -1 does not
   int force_order_fail = 0;      // SFH_FORCE_ORDER_FAIL=1: the library's own check reports failure (tests)
+  int plan_fused = 0;            // SFH_PLAN_FUSED=1: k_plan as one launch (the rounds 1-5 kernel; A/B)
   int inflate_serial = 0;        // SFH_INFLATE_SERIAL=1: index-only streams through the lane-serial kernel alone (tests, A/B)
   char err[256] = {0};
 };
@@ -98,6 +99,7 @@ void free_ws(sfh_ctx* c) {
   (void)hipFree(c->ws.hist);
   (void)hipFree(c->ws.plan);
   (void)hipFree(c->ws.codes);
+  (void)hipFree(c->ws.ptree);
   (void)hipFree(c->ws.offsets);
   (void)hipFree(c->ws.stamps);
   (void)hipFree(c->ws.seginfo);
@@ -129,6 +131,7 @@ int ensure_ws(sfh_ctx* ctx, uint32_t nchunks) {
       (e = hipMalloc(&ctx->ws.hist, nb * sf::kHistStride * sizeof(uint32_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.plan, nb * sizeof(sf::ChunkPlan))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.codes, nb * sizeof(sf::ChunkCodes))) != hipSuccess ||
+      (e = hipMalloc(&ctx->ws.ptree, nb * sizeof(sf::PlanTree))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.rtok, nb * sf::kSubRegions * sizeof(uint32_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.offsets, (nc + 1) * sizeof(uint64_t))) != hipSuccess ||
       (e = hipMalloc(&ctx->ws.seginfo, nc * sizeof(sf::SegInfo))) != hipSuccess ||
@@ -261,7 +264,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
                        ef == SFH_EFFORT_MAX ? 1u : 0u,
                        !ef_chain ? 0u : o.chain_depth ? o.chain_depth
                        : ef == SFH_EFFORT_BEST ? 8u : ef == SFH_EFFORT_ULTRA ? 16u : 32u,
-                       ef_recent ? 1u : 0u};
+                       ef_recent ? 1u : 0u, ctx->plan_fused ? 1u : 0u};
   if ((ko.chain_depth || ko.recent) && (rc = ensure_order(ctx, ko.recent ? 1 : 0)) != SFH_OK) return rc;
   ctx->last_block_bytes = ko.strip_bytes;
   const bool prof = ctx->profiling != 0;
@@ -447,6 +450,8 @@ int sfh_create(sfh_ctx** out, int device) {
     if (b && atoi(b) > 0) ctx->batch_chunks = std::min<uint32_t>((uint32_t)atoi(b), sf::kBatchChunks);
     const char* f = getenv("SFH_FORCE_ORDER_FAIL");
     ctx->force_order_fail = (f && f[0] == '1');
+    const char* pf = getenv("SFH_PLAN_FUSED");
+    ctx->plan_fused = (pf && pf[0] == '1');
     const char* q = getenv("SFH_INFLATE_SERIAL");
     ctx->inflate_serial = (q && q[0] == '1');
   }

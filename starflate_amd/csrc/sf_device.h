@@ -79,6 +79,20 @@ struct ChunkCodes {
   uint8_t lens[320];     // ll lens [0..287], d lens [288..319] (debug / parity)
 };
 
+// k_plan in three launches (round 6): what the sorting pass hands the merge pass and the merge pass the finishing one, per chunk
+struct PlanTree {
+  uint32_t done;           // 1: the sorting pass settled the chunk (stored without a code)
+  uint32_t m_ll, m_d;      // used literal/length and distance symbols
+  uint32_t pad;
+  uint32_t key_ll[288];    // (freq << 9 | symbol) ascending, [0 .. m_ll)
+  uint32_t key_d[32];
+  uint16_t wt_ll[288];     // the same symbols' weights (what the merge reads)
+  uint16_t wt_d[32];
+  uint16_t parent_ll[576]; // the merge's result: node -> parent, root = node 2m - 2
+  uint16_t parent_d[64];
+};
+static_assert(sizeof(PlanTree) % 16 == 0, "PlanTree rows");
+
 // per-segment record of the decoder (sf_inflate.hip): written by k_inflate_tokens, read by k_inflate_bytes
 constexpr uint32_t kSegRaw = 1u, kSegSerial = 2u;
 struct SegInfo {
@@ -102,6 +116,7 @@ struct Workspace {
   uint32_t* hist;     // [nchunks][kHistStride]
   ChunkPlan* plan;    // [nchunks]
   ChunkCodes* codes;  // [nchunks]
+  PlanTree* ptree;    // (batch) [nchunks] k_plan's three launches hand their chunk's tree along here
   uint64_t* offsets;  // [nchunks + 1]: first stream byte of every chunk, then the end of the last one (= the index)
   uint64_t* stamps;   // [nchunks][8], diagnostic build only (SFH_K1_STAMPS=1), else null
   uint32_t* sums;     // [nchunks] checksum partials (container modes / sfh_checksum_device)
@@ -122,6 +137,7 @@ struct Options {
   uint32_t long_table;   // 1: two tables of 4096 buckets, keyed by four and by seven bytes (with stride2 = 0: SFH_EFFORT_MAX)
   uint32_t chain_depth;  // > 0: exact hash chains of this depth instead of the step tables (SFH_EFFORT_BEST 8, _ULTRA 16, _EXTREME 32)
   uint32_t recent;       // 1: exact recency (SFH_EFFORT_RECENT): buckets {latest, the one before the latest inserting step} + the exact predecessor
+  uint32_t plan_fused;   // 1: k_plan as ONE launch, its merges on lane 0 of every chunk's wave (the rounds 1-5 kernel; SFH_PLAN_FUSED=1, for A/B)
 };
 
 hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const Workspace& ws,

@@ -1504,10 +1504,12 @@ static_assert(kChunk + 1 <= 65535, "node weights are 16 bits");
 
 // Length-limited Huffman code lengths; all 64 lanes call it.  Specification (DESIGN.md,
 // "code lengths"): two-queue Huffman, clamp, Kraft repair, lengths dealt longest-first
-// to the rarest symbols.
+// to the rarest symbols.  Three parts, so that the serial one can run elsewhere (k_plan_merge):
+//   sort_symbols   -> m used symbols, their keys (freq << 9 | symbol) ascending in S.key[0..m)
+//   merge_two_queue: the tree over weights w[0..m) -> parent[0..2m-2), serial in the merges
+//   finish_lengths : leaf depths from the parents, clamp + Kraft repair, lengths dealt by rank
 template <uint32_t NG>  // 64-symbol groups the alphabet spans: 5 for literal/length, 1 for distance and code-length codes
-__device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uint32_t maxbits,
-                              uint8_t* lens, uint32_t lane) {
+__device__ uint32_t sort_symbols(PlanSmem& S, const uint32_t* freq, uint32_t n, uint8_t* lens, uint32_t lane) {
   // keys (freq << 9 | symbol) stay in registers: symbol g*64+lane in key[g]
   uint32_t key[NG], rank[NG];
   uint32_t mloc = 0;
@@ -1523,13 +1525,13 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
   if (lane < 16) S.cnt[lane] = 0;
   const uint32_t m = wave_sum(mloc);
   __syncthreads();
-  if (m == 0) return;
+  if (m == 0) return 0;
   if (m == 1) {
 #pragma unroll
     for (uint32_t g = 0; g < NG; ++g)
       if (key[g] != 0xFFFFFFFFu) lens[g * 64 + lane] = 1;
     __syncthreads();
-    return;
+    return 1;
   }
   // rank sort ascending by (freq, symbol): every used key is broadcast once (v_readlane)
   // and counted by the lanes holding larger keys -- no LDS round trips
@@ -1549,32 +1551,74 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
   for (uint32_t g = 0; g < NG; ++g)
     if (key[g] != 0xFFFFFFFFu) S.key[rank[g]] = key[g];
   __syncthreads();
-  for (uint32_t k = lane; k < m; k += 64) S.w[k] = (uint16_t)(S.key[k] >> 9);
-  __syncthreads();
-  // two-queue merge (serial; leaves first on ties).  Both queues are consumed in index order,
-  // so their next heads are fetched from LDS two picks ahead of use.
-  if (lane == 0) {
-    const uint32_t INF = 0xFFFFFFFFu;
-    uint32_t i = 0, j = m, k = m;
-    uint32_t a0 = S.w[0], a1 = S.w[1], a2 = 2 < m ? S.w[2] : INF;  // leaves i, i+1, i+2 (m >= 2)
-    uint32_t b0 = INF, b1 = INF;                                    // internal nodes j, j+1
-    while (k < 2 * m - 1) {
-      uint32_t x, y, wx, wy;
-      if (a0 <= b0) { x = i++; wx = a0; a0 = a1; a1 = a2; a2 = i + 2 < m ? S.w[i + 2] : INF; }
-      else          { x = j++; wx = b0; b0 = b1; b1 = j + 1 < k ? S.w[j + 1] : INF; }
-      if (a0 <= b0) { y = i++; wy = a0; a0 = a1; a1 = a2; a2 = i + 2 < m ? S.w[i + 2] : INF; }
-      else          { y = j++; wy = b0; b0 = b1; b1 = j + 1 < k ? S.w[j + 1] : INF; }
-      const uint32_t sum = wx + wy;
-      S.w[k] = (uint16_t)sum;
-      S.parent[x] = (uint16_t)k;
-      S.parent[y] = (uint16_t)k;
-      if (j == k) b0 = sum;          // the new node is the internal queue's head ...
-      else if (j + 1 == k) b1 = sum; // ... or its second entry
-      ++k;
-    }
+  return m;
+}
+
+// two-queue merge (serial; leaves first on ties) by ONE thread: W(k) reads a node's weight, SETW(k, w) writes one,
+// PARENT(x, k) records x's parent.  Both queues are consumed in index order, so their next heads are fetched two
+// picks ahead of use.  m >= 2.
+template <class RdW, class WrW, class WrP>
+__device__ __forceinline__ void merge_two_queue(uint32_t m, RdW W, WrW SETW, WrP PARENT) {
+  const uint32_t INF = 0xFFFFFFFFu;
+  uint32_t i = 0, j = m, k = m;
+  uint32_t a0 = W(0), a1 = W(1), a2 = 2 < m ? W(2) : INF;  // leaves i, i+1, i+2
+  uint32_t b0 = INF, b1 = INF;                              // internal nodes j, j+1
+  while (k < 2 * m - 1) {
+    uint32_t x, y, wx, wy;
+    if (a0 <= b0) { x = i++; wx = a0; a0 = a1; a1 = a2; a2 = i + 2 < m ? W(i + 2) : INF; }
+    else          { x = j++; wx = b0; b0 = b1; b1 = j + 1 < k ? W(j + 1) : INF; }
+    if (a0 <= b0) { y = i++; wy = a0; a0 = a1; a1 = a2; a2 = i + 2 < m ? W(i + 2) : INF; }
+    else          { y = j++; wy = b0; b0 = b1; b1 = j + 1 < k ? W(j + 1) : INF; }
+    const uint32_t sum = wx + wy;
+    SETW(k, sum);
+    PARENT(x, k);
+    PARENT(y, k);
+    if (j == k) b0 = sum;          // the new node is the internal queue's head ...
+    else if (j + 1 == k) b1 = sum; // ... or its second entry
+    ++k;
   }
-  __syncthreads();
-  // leaf depths, clamped histogram
+}
+
+// The same merge for a LANE of its own among 64 (k_plan_merge): no branch on which queue gives the next node -- under
+// divergence a wave executes both sides of every such branch anyway, with the exec-mask bookkeeping on top -- but both
+// refills asked for and the five queue registers moved by selects.  Same picks, same ties (leaves first), same parents.
+template <class RdW, class WrW, class WrP>
+__device__ __forceinline__ void merge_two_queue_lane(uint32_t m, RdW W, WrW SETW, WrP PARENT) {
+  const uint32_t INF = 0xFFFFFFFFu;
+  uint32_t i = 0, j = m, k = m;
+  uint32_t a0 = W(0), a1 = W(1), a2 = 2 < m ? W(2) : INF;
+  uint32_t b0 = INF, b1 = INF;
+  auto pick = [&](uint32_t& x, uint32_t& wx) {
+    const bool leaf = a0 <= b0;
+    const uint32_t nli = i + 3, nii = j + 2;             // what the queue that is taken from reads next
+    const uint32_t nl = W(nli < m ? nli : 0u), ni = W(nii < k ? nii : 0u);
+    x = leaf ? i : j;
+    wx = leaf ? a0 : b0;
+    a0 = leaf ? a1 : a0;
+    a1 = leaf ? a2 : a1;
+    a2 = leaf ? (nli < m ? nl : INF) : a2;
+    b0 = leaf ? b0 : b1;
+    b1 = leaf ? b1 : (nii < k ? ni : INF);
+    i += leaf ? 1u : 0u;
+    j += leaf ? 0u : 1u;
+  };
+  while (k < 2 * m - 1) {
+    uint32_t x, y, wx, wy;
+    pick(x, wx);
+    pick(y, wy);
+    const uint32_t sum = wx + wy;
+    SETW(k, sum);
+    PARENT(x, k);
+    PARENT(y, k);
+    b0 = j == k ? sum : b0;                       // the new node is the internal queue's head ...
+    b1 = (j != k && j + 1 == k) ? sum : b1;      // ... or its second entry
+    ++k;
+  }
+}
+
+// leaf depths from S.parent (root = node 2m-2), clamped histogram, Kraft repair, lengths dealt longest-first to the
+// rarest symbols (S.key[0..m) ascending).  m >= 2; S.cnt zeroed by sort_symbols.
+__device__ void finish_lengths(PlanSmem& S, uint32_t m, uint32_t maxbits, uint8_t* lens, uint32_t lane) {
   const uint32_t root = 2 * m - 2;
   for (uint32_t k = lane; k < m; k += 64) {
     uint32_t d = 0, v = k;
@@ -1617,6 +1661,20 @@ __device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uin
     }
   }
   __syncthreads();
+}
+
+template <uint32_t NG>
+__device__ void build_lengths(PlanSmem& S, const uint32_t* freq, uint32_t n, uint32_t maxbits,
+                              uint8_t* lens, uint32_t lane) {
+  const uint32_t m = sort_symbols<NG>(S, freq, n, lens, lane);
+  if (m < 2) return;
+  for (uint32_t k = lane; k < m; k += 64) S.w[k] = (uint16_t)(S.key[k] >> 9);
+  __syncthreads();
+  if (lane == 0)
+    merge_two_queue(m, [&](uint32_t k) -> uint32_t { return S.w[k]; }, [&](uint32_t k, uint32_t w) { S.w[k] = (uint16_t)w; },
+                    [&](uint32_t x, uint32_t k) { S.parent[x] = (uint16_t)k; });
+  __syncthreads();
+  finish_lengths(S, m, maxbits, lens, lane);
 }
 
 // canonical codes (RFC 1951 3.2.2 == huffman::table::canonicalize,
@@ -1756,11 +1814,17 @@ constexpr uint32_t kStoreMargin = 64;            // bytes: an estimate this clos
 
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-__global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
-                                             uint32_t* __restrict__ hist,
-                                             ChunkPlan* __restrict__ plan, ChunkCodes* __restrict__ codes,
-                                             uint32_t strategy, uint32_t final_stream,
-                                             uint64_t* __restrict__ stamps) {
+// MODE 0 (k_plan): the whole plan in one launch (rounds 1-5; SFH_PLAN_FUSED=1).  Round 6 -- three launches: MODE 1 (k_plan_sort)
+// loads, folds, decides "stored without a code", SORTS both alphabets and leaves keys and weights in PlanTree; k_plan_merge
+// builds the trees, one chunk per LANE; MODE 2 (k_plan_finish) picks the parents up, finishes the lengths and does the rest.  The two-queue merge is serial in the
+// merges: on lane 0 of a chunk's wave it was 46 % of k_plan's cycles at 1/64 of the lanes -- 58 merges per chunk on text,
+// 280 on machine code (1.0 ms per GiB there) -- and with a chunk per lane 64 of them share every instruction.
+template <int MODE>
+__device__ __forceinline__ void plan_chunk(uint64_t n_total, uint32_t nchunks,
+                                           uint32_t* __restrict__ hist,
+                                           ChunkPlan* __restrict__ plan, ChunkCodes* __restrict__ codes,
+                                           uint32_t strategy, uint32_t final_stream,
+                                           uint64_t* __restrict__ stamps, PlanTree* __restrict__ ptree) {
   __shared__ PlanSmem S;
   uint32_t* const s_header = S.key + kHeaderAt;
   // diagnostic (stamps != nullptr, SFH_K1_STAMPS=1): cycles per phase at stamps[chunk*8 + 8*nchunks..]
@@ -1780,24 +1844,32 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
   const uint32_t n_raw = (uint32_t)((n_total - cbase) < (uint64_t)kChunk ? (n_total - cbase) : kChunk);
   const bool fin = (chunk + 1 == nchunks) && final_stream;
 
+  [[maybe_unused]] PlanTree* const T = MODE ? ptree + chunk : nullptr;
+  if constexpr (MODE == 2) {
+    if (T->done) return;  // (uniform: stored without a code by the sorting pass)
+  }
   // both halves of the chunk's histogram are requested at once (one memory round trip, not two in a row)
-  uint32_t rawf[4];
+  uint32_t rawf[4] = {0, 0, 0, 0};
+  if constexpr (MODE != 2) {
 #pragma unroll
-  for (uint32_t q = 0; q < 4; ++q) rawf[q] = hist[(uint64_t)chunk * kHistStride + kHistLen + lane + 64 * q];
+    for (uint32_t q = 0; q < 4; ++q) rawf[q] = hist[(uint64_t)chunk * kHistStride + kHistLen + lane + 64 * q];
+  }
   for (uint32_t s = lane; s < 320; s += 64) S.freq[s] = hist[(uint64_t)chunk * kHistStride + s];
   for (uint32_t s = lane; s < 320; s += 64) S.lens[s] = 0;
   __syncthreads();
-  // k_lz77 counted match lengths raw (len-3 at kHistLen + 0..255): fold them into the length symbols 257..285
+  if constexpr (MODE != 2) {  // (the finishing pass finds the counts folded: the sorting pass wrote them back)
+    // k_lz77 counted match lengths raw (len-3 at kHistLen + 0..255): fold them into the length symbols 257..285
 #pragma unroll
-  for (uint32_t q = 0; q < 4; ++q) {
-    uint32_t eb, ev;
-    if (rawf[q]) atomicAdd(&S.freq[len_symbol(lane + 64 * q, eb, ev)], rawf[q]);
+    for (uint32_t q = 0; q < 4; ++q) {
+      uint32_t eb, ev;
+      if (rawf[q]) atomicAdd(&S.freq[len_symbol(lane + 64 * q, eb, ev)], rawf[q]);
+    }
+    __syncthreads();
+    if (lane < 29) hist[(uint64_t)chunk * kHistStride + 257 + lane] = S.freq[257 + lane];  // the folded counts: for parity tests, and for the finishing pass
   }
-  __syncthreads();
-  if (lane < 29) hist[(uint64_t)chunk * kHistStride + 257 + lane] = S.freq[257 + lane];  // the folded counts, for parity tests
 
   stamp();  // 0 load
-  if (strategy == 0) {
+  if (MODE != 2 && strategy == 0) {
     // A chunk that is (all but) incompressible is STORED without building a code: when the fixed block is no shorter than
     // the stored one and the ESTIMATE of the dynamic block -- the symbols' entropy in fixed point (est_log2: a 64-entry
     // table, the same integers in the specification) + extra bits + the shortest header -- comes within kStoreMargin
@@ -1836,14 +1908,59 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
         P.header_bits = 3;
         P.body_bits = 0;
         plan[chunk] = P;
+        if constexpr (MODE == 1) T->done = 1;
       }
       return;
     }
   }
-  build_lengths<5>(S, S.freq, 286, 15, S.lens, lane);
-  stamp();  // 1 lit/len lengths
-  build_lengths<1>(S, S.freq + kHistD, 30, 15, S.lens + 288, lane);
-  stamp();  // 2 distance lengths
+  if constexpr (MODE == 0) {
+    build_lengths<5>(S, S.freq, 286, 15, S.lens, lane);
+    stamp();  // 1 lit/len lengths
+    build_lengths<1>(S, S.freq + kHistD, 30, 15, S.lens + 288, lane);
+    stamp();  // 2 distance lengths
+  } else if constexpr (MODE == 1) {
+    // the sorting pass: both alphabets' used symbols ascending by (count, symbol), keys and weights for the merge pass
+    const uint32_t m_ll = sort_symbols<5>(S, S.freq, 286, S.lens, lane);
+    if (m_ll >= 2)
+      for (uint32_t k = lane; k < m_ll; k += 64) {
+        const uint32_t key = S.key[k];
+        T->key_ll[k] = key;
+        T->wt_ll[k] = (uint16_t)(key >> 9);
+      }
+    __syncthreads();  // (S.key is sorted into again below)
+    const uint32_t m_d = sort_symbols<1>(S, S.freq + kHistD, 30, S.lens + 288, lane);
+    if (m_d >= 2 && lane < m_d) {
+      const uint32_t key = S.key[lane];
+      T->key_d[lane] = key;
+      T->wt_d[lane] = (uint16_t)(key >> 9);
+    }
+    if (lane == 0) { T->done = 0; T->m_ll = m_ll; T->m_d = m_d; }
+    return;
+  } else {
+    // the finishing pass: the sorted keys and the merge pass's parents -> lengths (an alphabet of fewer than two used symbols
+    // needs no tree: sort_symbols settles it, as in the one-launch kernel)
+    const uint32_t m_ll = T->m_ll, m_d = T->m_d;
+    if (m_ll < 2) {
+      sort_symbols<5>(S, S.freq, 286, S.lens, lane);
+    } else {
+      if (lane < 16) S.cnt[lane] = 0;
+      for (uint32_t k = lane; k < m_ll; k += 64) S.key[k] = T->key_ll[k];
+      for (uint32_t v = lane; v < 2 * m_ll - 2; v += 64) S.parent[v] = T->parent_ll[v];
+      __syncthreads();
+      finish_lengths(S, m_ll, 15, S.lens, lane);
+    }
+    stamp();  // 1 lit/len lengths
+    if (m_d < 2) {
+      sort_symbols<1>(S, S.freq + kHistD, 30, S.lens + 288, lane);
+    } else {
+      if (lane < 16) S.cnt[lane] = 0;
+      if (lane < m_d) S.key[lane] = T->key_d[lane];
+      if (lane < 2 * m_d - 2) S.parent[lane] = T->parent_d[lane];
+      __syncthreads();
+      finish_lengths(S, m_d, 15, S.lens + 288, lane);
+    }
+    stamp();  // 2 distance lengths
+  }
 
   // body costs
   uint32_t dyn = 0, fix = 0, extra = 0, nmatch = 0;
@@ -1960,6 +2077,44 @@ __global__ __launch_bounds__(64) void k_plan(uint64_t n_total, uint32_t nchunks,
     plan[chunk] = P;
   }
   stamp();  // 6 canonical codes + stores
+}
+
+#define SF_PLAN_KERNEL(NAME, MODE)                                                                                          \
+  __global__ __launch_bounds__(64) void NAME(uint64_t n_total, uint32_t nchunks, uint32_t* __restrict__ hist,                 \
+                                             ChunkPlan* __restrict__ plan, ChunkCodes* __restrict__ codes, uint32_t strategy, \
+                                             uint32_t final_stream, uint64_t* __restrict__ stamps, PlanTree* __restrict__ ptree) { \
+    plan_chunk<MODE>(n_total, nchunks, hist, plan, codes, strategy, final_stream, stamps, ptree);                             \
+  }
+SF_PLAN_KERNEL(k_plan, 0)         // one launch (rounds 1-5; SFH_PLAN_FUSED=1)
+SF_PLAN_KERNEL(k_plan_sort, 1)    // K2a
+SF_PLAN_KERNEL(k_plan_finish, 2)  // K2c
+#undef SF_PLAN_KERNEL
+
+// K2b: the two-queue merges of k_plan's three launches, ONE CHUNK PER LANE.  A lane's node weights (u16, leaves then
+// internal nodes: 571 at most) live in its own row of LDS -- 289 dwords, an odd stride, so the 64 lanes' accesses at the
+// same node index fall on different banks -- and the parents go straight to the chunk's PlanTree (written, never read
+// here).  The wave runs as long as its longest merge; on one workload the chunks' alphabets are alike.
+constexpr uint32_t KM_ROW = 289;
+static_assert(2 * KM_ROW >= 576 && (KM_ROW & 1) == 1 && 64 * KM_ROW * 4 <= 80 * 1024, "k_plan_merge: two waves per CU");
+__global__ __launch_bounds__(64) void k_plan_merge(uint32_t nchunks, PlanTree* __restrict__ ptree) {
+  __shared__ uint32_t s_rows[64 * KM_ROW];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t chunk = blockIdx.x * 64 + lane;
+  if (chunk >= nchunks) return;  // (no barrier in this kernel: every lane is on its own)
+  PlanTree* const T = ptree + chunk;
+  if (T->done) return;
+  uint16_t* const w = reinterpret_cast<uint16_t*>(s_rows + lane * KM_ROW);
+  uint32_t* const w32 = s_rows + lane * KM_ROW;
+#pragma unroll 1
+  for (uint32_t tree = 0; tree < 2; ++tree) {
+    const uint32_t m = tree ? T->m_d : T->m_ll;
+    if (m < 2) continue;
+    const uint32_t* const wt32 = reinterpret_cast<const uint32_t*>(tree ? T->wt_d : T->wt_ll);  // (4-byte aligned: PlanTree's layout)
+    uint16_t* const parent = tree ? T->parent_d : T->parent_ll;
+    for (uint32_t k = 0; k < (m + 1) / 2; ++k) w32[k] = wt32[k];  // (the odd last half-word is a weight nobody reads)
+    merge_two_queue_lane(m, [&](uint32_t k) -> uint32_t { return w[k]; }, [&](uint32_t k, uint32_t v) { w[k] = (uint16_t)v; },
+                         [&](uint32_t x, uint32_t k) { parent[x] = (uint16_t)k; });
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2408,8 +2563,17 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
 }
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,
                        hipStream_t s) {
-  hipLaunchKernelGGL(k_plan, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.plan, ws.codes,
-                     opt.strategy, opt.final_stream, ws.stamps);
+  if (opt.plan_fused || !ws.ptree) {
+    hipLaunchKernelGGL(k_plan, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.plan, ws.codes,
+                       opt.strategy, opt.final_stream, ws.stamps, (PlanTree*)nullptr);
+    return hipGetLastError();
+  }
+  // sort (a wave per chunk) -> merge (a lane per chunk) -> finish (a wave per chunk)
+  hipLaunchKernelGGL(k_plan_sort, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.plan, ws.codes,
+                     opt.strategy, opt.final_stream, (uint64_t*)nullptr, ws.ptree);
+  hipLaunchKernelGGL(k_plan_merge, dim3((nchunks + 63) / 64), dim3(64), 0, s, nchunks, ws.ptree);
+  hipLaunchKernelGGL(k_plan_finish, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.plan, ws.codes,
+                     opt.strategy, opt.final_stream, ws.stamps, ws.ptree);
   return hipGetLastError();
 }
 hipError_t launch_scan(uint32_t nchunks, const Workspace& ws, uint64_t base, bool carry, uint64_t* d_total, hipStream_t s) {

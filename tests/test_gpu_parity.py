@@ -178,6 +178,31 @@ def test_batches_give_the_stream_of_one_launch(monkeypatch):
         c.close()
 
 
+def test_plan_in_three_launches_and_in_one(monkeypatch):
+    """k_plan runs as sort / merge (a chunk per LANE) / finish since round 6; SFH_PLAN_FUSED=1 (read at sfh_create) is the one
+    launch of rounds 1-5.  Both give the specification's code lengths: alphabets of every width (one symbol, two, all 256
+    literals + every length + every distance), chunk counts that do not fill the merge kernel's waves (1, 63, 64, 65, 130),
+    stored and fixed chunks in between (their lanes leave early), and more than one batch."""
+    from starflate_amd import Compressor
+
+    rng = np.random.default_rng(66)
+    pieces = [synth.gen_text(3 * CHUNK + 17, seed=61), rng.integers(0, 256, CHUNK + 5, dtype=np.uint8), np.zeros(CHUNK, np.uint8),
+              np.full(40, 7, np.uint8), rng.integers(0, 2, 2 * CHUNK, dtype=np.uint8), synth.gen_mixed(4 * CHUNK, seed=62, stripe=1 << 14),
+              np.frombuffer(rng.bytes(9000) * 11, np.uint8), rng.integers(0, 64, CHUNK - 1, dtype=np.uint8)]
+    wide = np.concatenate(pieces)
+    cases = [wide[:1], wide[:CHUNK], wide[: 63 * CHUNK // 4], np.concatenate([wide] * 5)[: 130 * CHUNK - 3], synth.gen_text(65 * CHUNK, seed=63)]
+    for fused, bc in (("0", None), ("1", None), ("0", "3")):
+        monkeypatch.setenv("SFH_PLAN_FUSED", fused)
+        if bc:
+            monkeypatch.setenv("SFH_BATCH_CHUNKS", bc)
+        c = Compressor(0)
+        for k, data in enumerate(cases):
+            for effort, ekw in (("default", {}), ("best", dict(chain_depth=8))):
+                got = np.frombuffer(c.compress(data, effort=effort), np.uint8)
+                assert np.array_equal(got, O.compress(data, O.default_params(**ekw))), (fused, bc, k, effort)
+        c.close()
+
+
 def test_largest_and_odd_strips(compressor):
     """block_bytes at its maximum (16 MiB: the table's step codes are aged a thousand times, the decoder walks 512
     segments per strip) and at a non-power-of-two multiple of 32 KiB: bit-exact, and decodable on the GPU."""
