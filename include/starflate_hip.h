@@ -65,7 +65,10 @@ typedef struct sfh_options {
   uint32_t no_stored_fast_path; /* 0 (default): a 32 KiB chunk whose first 8 KiB parse to (almost) only
                             literals is not searched further and is coded as literals throughout (high-entropy
                             data -> stored blocks); the chunk behind it in its strip is probed on its first
-                            2 KiB only (a sixteenth of the match work while the data stays like that);
+                            2 KiB only (a sixteenth of the match work while the data stays like that); with
+                            SFH_STRATEGY_AUTO a full chunk whose first 8 KiB of BYTES are as good as uniform (their
+                            entropy within 64 bytes of 8 KiB) is stored outright, its other 24 KiB never fetched by the
+                            match kernel (round 6);
                             1: always search the whole chunk */
   uint32_t container;    /* enum sfh_container; SFH_ZLIB / SFH_GZIP need final_stream = 1.  The checksum is
                             computed on the GPU from the same device buffer (two more launches) */

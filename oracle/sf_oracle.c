@@ -725,6 +725,22 @@ static uint32_t parse_regions(const uint8_t* data, uint32_t n, const sfo_params*
   return total;
 }
 
+static uint32_t est_log2(uint32_t x);
+
+/* Stored BY THE PROBE (round 6).  A full block that takes the stored fast path (below) and whose first SFO_SKIP_SPAN BYTES are
+ * as good as uniform -- their entropy in the plan's fixed point (est_log2) within SFO_STORE_MARGIN bytes of SFO_SKIP_SPAN --
+ * is stored outright when the block type is the encoder's to choose (strategy 0): it has NO tokens at all, and
+ * sfo_plan_chunk stores a block without tokens.  What the rest of the block holds is then never looked at (on the GPU:
+ * never fetched by the match kernel): a block whose probe span is noise and whose rest is not loses what a Huffman code
+ * over its literals would have saved -- matches it had given up already. */
+static int probe_span_is_noise(const uint8_t* d) {
+  uint32_t f[256] = {0}, ent = 0;
+  for (uint32_t i = 0; i < SFO_SKIP_SPAN; i++) f[d[i]]++;
+  for (uint32_t s = 0; s < 256; s++)
+    if (f[s]) ent += f[s] * (est_log2(SFO_SKIP_SPAN) - est_log2(f[s]));
+  return ((ent >> 8) + 7) / 8 + SFO_STORE_MARGIN >= SFO_SKIP_SPAN;
+}
+
 /*
  * Stages n1 + parse for one strip, DEFLATE block by block (chunk_bytes each): the hash tables and the
  * window carry over from block to block.
@@ -762,6 +778,11 @@ int sfo_strip_tokens(const uint8_t* src, uint32_t n, const sfo_params* p, uint32
     match_steps(&m, s0, s0 + probe / W);
     const uint32_t head = parse_regions(m.d, n, p, m.len16, m.dist16, r0, rh, 0, tokens, ntok);
     const int skip = head >= SFO_SKIP_SPAN - SFO_SKIP_SLACK;
+    if (skip && p->strategy == 0 && cn == cb && probe_span_is_noise(src + c0)) {  /* stored by the probe: no tokens */
+      for (uint32_t r = r0; r < r1; r++) ntok[r] = 0;
+      prev_skipped = 1;
+      continue;
+    }
     /* (round 5) the WHOLE block is literals then, the probe span included: its few matches are dropped */
     if (skip) parse_regions(m.d, n, p, m.len16, m.dist16, r0, rh, 1, tokens, ntok);
     if (!skip) match_steps(&m, sh, s1);
@@ -799,6 +820,10 @@ void sfo_parse_chunk(const uint8_t* data, uint32_t n, const sfo_params* p,
   const uint32_t rh = SFO_SKIP_SPAN / R;
   const uint32_t head = parse_regions(data, n, p, len16, dist16, 0, rh, 0, tokens, ntok);
   const int skip = head >= SFO_SKIP_SPAN - SFO_SKIP_SLACK;
+  if (skip && p->strategy == 0 && n == p->chunk_bytes && probe_span_is_noise(data)) {
+    for (uint32_t r = 0; r < nreg; r++) ntok[r] = 0;
+    return;
+  }
   if (skip) parse_regions(data, n, p, len16, dist16, 0, rh, 1, tokens, ntok);
   parse_regions(data, n, p, len16, dist16, rh, nreg, skip, tokens, ntok);
 }
@@ -953,6 +978,11 @@ void sfo_plan_chunk(const uint32_t* ll, const uint32_t* d, uint32_t n_raw, int i
      * planner a histogram pass. */
     uint32_t tot = 0, nmat = 0, ent = 0, extra = 0, fixb = 0;
     for (uint32_t s = 0; s < 286; s++) tot += ll[s];
+    if (n_raw && tot == 1) { /* bytes but no tokens: stored by the probe (sfo_strip_tokens) */
+      plan->btype = 0;
+      plan->out_bytes = n_raw + 5;
+      return;
+    }
     for (uint32_t s = 0; s < 30; s++) nmat += d[s];
     for (uint32_t s = 0; s < 286; s++) {
       if (ll[s]) ent += ll[s] * (est_log2(tot) - est_log2(ll[s]));

@@ -94,7 +94,8 @@ typedef struct sfo_params {
   uint32_t cap;          /* >0: match-time compare is capped at `cap` bytes; the parse extends
                             a capped match to its full length at chain positions only */
   uint32_t fast_skip;    /* 1: stored fast path -- a chunk whose first SFO_SKIP_SPAN positions are (almost)
-                            all literals is not searched any further */
+                            all literals is not searched any further; with strategy 0 a full chunk whose first
+                            SFO_SKIP_SPAN BYTES are as good as uniform gets no tokens and is stored (round 6) */
   uint32_t far4_dist;    /* >0: a match of exactly 4 bytes at a distance beyond this is not used */
   uint32_t container;    /* 0 raw RFC 1951; 1 zlib (RFC 1950: 78 9C .. Adler-32 BE); 2 gzip (RFC 1952:
                             1F 8B 08 00, MTIME 0, XFL 0, OS 255 .. CRC-32 LE, ISIZE LE); needs final_stream */

@@ -257,7 +257,7 @@ int enqueue(sfh_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t cap, 
   const uint32_t ef = o.effort;
   const bool ef_chain = ef >= SFH_EFFORT_BEST && ef <= SFH_EFFORT_EXTREME, ef_recent = ef == SFH_EFFORT_RECENT || ef == SFH_EFFORT_RECENT_ALL;
   const bool ef_all = ef == SFH_EFFORT_THOROUGH || ef == SFH_EFFORT_MAX || ef_chain || ef == SFH_EFFORT_RECENT_ALL;  // every position searched
-  const sf::Options ko{o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path ? 0u : 1u,
+  const sf::Options ko{o.strategy, o.final_stream, o.lazy, o.no_stored_fast_path ? 0u : (o.strategy == 0 ? 2u : 1u),
                        resolve_block_bytes(o.block_bytes, n, o.effort),
                        (ef == SFH_EFFORT_FAST || ef == SFH_EFFORT_FASTEST) ? 0u : 1u,
                        ef == SFH_EFFORT_FASTEST ? 0u : 1u, ef_all ? 0u : 1u,

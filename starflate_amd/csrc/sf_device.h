@@ -129,7 +129,7 @@ struct Options {
   uint32_t strategy;
   uint32_t final_stream;
   uint32_t lazy;
-  uint32_t fast_skip;
+  uint32_t fast_skip;     // 0: off; 1: stored fast path; 2: ... and a chunk may be stored by its probe (strategy 0: sf_capi.hip)
   uint32_t strip_bytes;  // multiple of kChunk
   uint32_t depth2;       // 1: both history levels of a hash bucket are tried, 0: the newer one only
   uint32_t near;         // 1: the step-local candidate is tried as well (always with depth2)

@@ -76,6 +76,19 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) { return wave_incl_add(v); }
 
+// est_log2(x) ~ 256 * log2(x) for x >= 1: the exponent and the top six mantissa bits through a table -- plain integers, the
+// same in the specification (oracle: est_log2), so the stored-without-a-code rule of k_plan and the stored-by-the-probe rule of k_lz77 decide alike on both sides
+__constant__ uint8_t c_est_lg64[64] = {0, 6, 11, 17, 22, 28, 33, 38, 44, 49, 54, 59, 63, 68, 73, 78, 82, 87, 92, 96, 100, 105, 109, 113, 118, 122,
+                                       126, 130, 134, 138, 142, 146, 150, 154, 157, 161, 165, 169, 172, 176, 179, 183, 186, 190, 193, 197,
+                                       200, 203, 207, 210, 213, 216, 220, 223, 226, 229, 232, 235, 238, 241, 244, 247, 250, 253};
+__device__ __forceinline__ uint32_t est_log2(uint32_t x) {
+  const uint32_t e = 31 - __builtin_clz(x | 1u);
+  const uint32_t m = (e >= 6 ? x >> (e - 6) : x << (6 - e)) & 63u;
+  return (e << 8) + c_est_lg64[m];
+}
+constexpr uint32_t kEstHeaderBits = 17 + 3 * 4;  // block header, HLIT, HDIST, HCLEN and four code-length-code lengths: the least a dynamic header takes
+constexpr uint32_t kStoreMargin = 64;            // bytes: an estimate this close to the stored size settles for "stored"
+
 // ---------------------------------------------------------------------------
 // K1: LZ77 match finding + parse + histogram.  One 1024-thread workgroup per STRIP (block_bytes of
 // input), two workgroups per CU (LDS <= 80 KiB, 64 VGPRs).  The strip is processed in ROUNDS of
@@ -1304,32 +1317,25 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
       __builtin_amdgcn_s_setprio(0);  // emit, flush and the next round's stage: nothing waits for them
 
       // @phase skip_now trips=0
-      if (skip_now) {
+      if (__builtin_expect(skip_now, 0)) {
         // (qn == kRound here: the chunk is longer than the span.)  The REST of the chunk is taken right here, in one go: its
-        // bytes are only counted, so its rounds need no window, no table and no barrier of their own -- three loads per
-        // thread in flight together instead of three rounds of a stage each waiting for its own; the window the next
+        // bytes are only counted, so its rounds need no window, no table and no barrier of their own; the window the next
         // chunk's probe needs comes from the input again (lds_stale, see the stage).  Schedule only: the chunk's tokens,
-        // counts and sub-index are what the round-by-round version wrote
+        // counts and sub-index are what the round-by-round version wrote.
+        // Round 6, STORED BY THE PROBE (specification: probe_span_is_noise, fast_skip == 2: the block type is ours to choose):
+        // a full chunk whose probe span's BYTES are as good as uniform -- their entropy, the plan's fixed point, within
+        // kStoreMargin bytes of the span -- has no tokens at all, which k_plan stores; its other 24 KiB are never fetched.
         const uint32_t clen = (n - cstart) < kChunk ? (n - cstart) : kChunk;  // the chunk's bytes
         const uint2 B = *reinterpret_cast<const uint2*>(&s_bytes[kWindow + 8 * t]);
+        bool pstore = false;  // (uniform)
         if (clen == kChunk) {
-          // the chunk's bytes behind this round: [kRound, kRound + kLook) lie in the look-ahead, the kRound bytes from there on
-          // are the thread's prefetched eight (pre_lo, pre_hi: asked for in the stage, or behind the match phase), the rest
-          // comes in two loads -- every byte of the input is fetched by this kernel once
-          static_assert(kRoundsPerChunk == 4, "the fast path's loads");
-          uint2 w[kRoundsPerChunk - 1];
-          w[0] = make_uint2(pre_lo, pre_hi);
-          w[1] = *reinterpret_cast<const uint2*>(sp + cstart + 2 * kRound + kLook + 8 * t);
-          w[2] = make_uint2(0, 0);
-          const bool tail = 8 * t + kLook < kRound;  // (the last kLook bytes of that span belong to the next chunk -- or to nobody)
-          if (tail) w[2] = *reinterpret_cast<const uint2*>(sp + cstart + 3 * kRound + kLook + 8 * t);
-          const uint32_t look = t < kLook / 4 ? s_data[(kWindow + kRound) / 4 + t] : 0u;
-          // The chunk's 32,768 byte counts.  On the histogram itself a wave's 64 random bytes pile up on the LDS banks (one
-          // atomic instruction: six to eight cycles; 0.060 of the fast path's 0.186 ms per 256 MiB, 0.043 now).  The window is dead from
-          // here on (lds_stale), so its 32 KiB hold 32 COPIES of the 256 counters, copy = lane mod 32 at dword
-          // byte * 32 + copy: every lane of a half-wave has a bank of its own whatever the bytes are.  Then 1024 threads
-          // fold eight copies each and four neighbours meet over the DPP network.
+          // The byte counts.  On the histogram itself a wave's 64 random bytes pile up on the LDS banks (one atomic
+          // instruction: six to eight cycles).  The window is dead from here on (lds_stale), so its 32 KiB hold 32 COPIES
+          // of the 256 counters, copy = lane mod 32 at dword byte * 32 + copy: every lane of a half-wave has a bank of its
+          // own whatever the bytes are.  Then 1024 threads fold eight copies each and four neighbours meet over the DPP
+          // network: every thread of quad t / 4 holds the count of byte value t / 4.
           static_assert(256 * 32 * 4 <= kWindow && kWindow / 16 == 2 * K1_THREADS, "the copies fill the window");
+          static_assert(kRoundsPerChunk == 4, "the fast path's loads");
           uint4* const z4 = reinterpret_cast<uint4*>(smem + L_DATA);
           z4[t] = make_uint4(0, 0, 0, 0);
           z4[K1_THREADS + t] = make_uint4(0, 0, 0, 0);
@@ -1339,20 +1345,44 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
 #pragma unroll
             for (uint32_t j = 0; j < 8; ++j) atomicAdd(&rep[(((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xFFu) * 32u], 1u);
           };
-          count8(B.x, B.y);
-          count8(w[0].x, w[0].y);
-          count8(w[1].x, w[1].y);
-          if (tail) count8(w[2].x, w[2].y);
-          if (t < kLook / 4) {
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) atomicAdd(&rep[((look >> (8 * j)) & 0xFFu) * 32u], 1u);
-          }
-          __syncthreads();
-          {
+          auto fold = [&]() -> uint32_t {
             const uint4 p = z4[2 * t], q = z4[2 * t + 1];  // thread t: copies 8 (t mod 4) .. + 8 of byte value t / 4
             uint32_t sum = (p.x + p.y) + (p.z + p.w) + (q.x + q.y) + (q.z + q.w);
             sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
             sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true);
+            return sum;
+          };
+          count8(B.x, B.y);  // the probe span's bytes (kSkipSpan == kRound: this round's)
+          __syncthreads();
+          if (fast_skip > 1) {
+            const uint32_t f = fold();
+            uint32_t e = ((t & 3u) == 0 && f) ? f * (est_log2(kSkipSpan) - est_log2(f)) : 0u;
+            e = wave_sum(e);
+            if (lane == 0) s_wtot[wave] = e;  // (its last readers are behind two barriers)
+            __syncthreads();
+            const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum(lane < K1_WAVES ? s_wtot[lane] : 0u));
+            pstore = ((ent >> 8) + 7) / 8 + kStoreMargin >= kSkipSpan;
+          }
+          if (!pstore) {
+            // the chunk's bytes behind this round: [kRound, kRound + kLook) lie in the look-ahead, the kRound bytes from there
+            // on are the thread's prefetched eight (pre_lo, pre_hi: asked for in the stage, or behind the match phase), the
+            // rest comes in two loads; the last kLook bytes of the last span belong to the next chunk -- or to nobody
+            uint2 w[kRoundsPerChunk - 1];
+            w[0] = make_uint2(pre_lo, pre_hi);
+            w[1] = *reinterpret_cast<const uint2*>(sp + cstart + 2 * kRound + kLook + 8 * t);
+            w[2] = make_uint2(0, 0);
+            const bool tail = 8 * t + kLook < kRound;
+            if (tail) w[2] = *reinterpret_cast<const uint2*>(sp + cstart + 3 * kRound + kLook + 8 * t);
+            const uint32_t look = t < kLook / 4 ? s_data[(kWindow + kRound) / 4 + t] : 0u;
+            count8(w[0].x, w[0].y);
+            count8(w[1].x, w[1].y);
+            if (tail) count8(w[2].x, w[2].y);
+            if (t < kLook / 4) {
+#pragma unroll
+              for (uint32_t j = 0; j < 4; ++j) atomicAdd(&rep[((look >> (8 * j)) & 0xFFu) * 32u], 1u);
+            }
+            __syncthreads();
+            const uint32_t sum = fold();
             if ((t & 3u) == 0) s_hist[t >> 2] = sum;  // (this chunk has counted nothing else: its first round's emit was dropped)
           }
         } else {  // a strip's short last chunk: byte by byte
@@ -1361,13 +1391,14 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
           for (uint32_t pos = cstart + kRound + t; pos < cstart + clen; pos += K1_THREADS) atomicAdd(&s_hist[sp[pos]], 1u);
         }
         const uint32_t r_last = (r + kRoundsPerChunk - 1 < nrounds ? r + kRoundsPerChunk - 1 : nrounds - 1);  // the chunk's last round
-        if (t < kSubRegions) rtok_out[chunk * kSubRegions + t] = t * kSubBytes < clen ? t * kSubBytes : clen;
+        const uint32_t ctok = pstore ? 0u : clen;  // tokens = items = positions -- or none
+        if (t < kSubRegions) rtok_out[chunk * kSubRegions + t] = t * kSubBytes < ctok ? t * kSubBytes : ctok;
         skip = true;
         lds_stale = true;
         stale_span = short_probe ? kSkipProbe : kSkipSpan;  // (the positions of this chunk the match phase went over)
         chunk_done = true;
-        tot_tok = clen;  // tokens = items = positions
-        tot_items = clen;
+        tot_tok = ctok;
+        tot_items = ctok;
         rtotal = 0;
         r = r_last;
       } else
@@ -1799,19 +1830,6 @@ __device__ uint32_t rle_parallel(PlanSmem& S, const uint8_t* lens, uint32_t n, u
   return total;
 }
 
-// est_log2(x) ~ 256 * log2(x) for x >= 1: the exponent and the top six mantissa bits through a table -- plain integers, the
-// same in the specification (oracle: est_log2), so the stored-without-a-code rule of k_plan decides alike on both sides
-__constant__ uint8_t c_est_lg64[64] = {0, 6, 11, 17, 22, 28, 33, 38, 44, 49, 54, 59, 63, 68, 73, 78, 82, 87, 92, 96, 100, 105, 109, 113, 118, 122,
-                                       126, 130, 134, 138, 142, 146, 150, 154, 157, 161, 165, 169, 172, 176, 179, 183, 186, 190, 193, 197,
-                                       200, 203, 207, 210, 213, 216, 220, 223, 226, 229, 232, 235, 238, 241, 244, 247, 250, 253};
-__device__ __forceinline__ uint32_t est_log2(uint32_t x) {
-  const uint32_t e = 31 - __builtin_clz(x | 1u);
-  const uint32_t m = (e >= 6 ? x >> (e - 6) : x << (6 - e)) & 63u;
-  return (e << 8) + c_est_lg64[m];
-}
-constexpr uint32_t kEstHeaderBits = 17 + 3 * 4;  // block header, HLIT, HDIST, HCLEN and four code-length-code lengths: the least a dynamic header takes
-constexpr uint32_t kStoreMargin = 64;            // bytes: an estimate this close to the stored size settles for "stored"
-
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // MODE 0 (k_plan): the whole plan in one launch (rounds 1-5; SFH_PLAN_FUSED=1).  Round 6 -- three launches: MODE 1 (k_plan_sort)
@@ -1897,7 +1915,8 @@ __device__ __forceinline__ void plan_chunk(uint64_t n_total, uint32_t nchunks,
     const uint32_t est_b = fin ? (est_bits + 7) / 8 : (est_bits + 3 + 7) / 8 + 4;
     const uint32_t fix_b = fin ? (fixbits + 7) / 8 : (fixbits + 3 + 7) / 8 + 4;
     const uint32_t sto_b = n_raw + 5;
-    if (fix_b >= sto_b && est_b + kStoreMargin >= sto_b) {
+    // (... and a chunk with bytes but NO tokens was stored by k_lz77's probe: round 6, probe_span_is_noise in the specification)
+    if ((n_raw != 0 && tot == 1) || (fix_b >= sto_b && est_b + kStoreMargin >= sto_b)) {
       ChunkCodes& C0 = codes[chunk];
       for (uint32_t s0 = lane; s0 < 320; s0 += 64) C0.lens[s0] = 0;  // (no code was built)
       if (lane == 0) {

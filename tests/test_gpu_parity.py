@@ -308,6 +308,54 @@ def test_stored_fast_path(compressor):
                           O.compress(two, O.default_params(strip_bytes=2 * CHUNK)))
 
 
+def test_stored_by_the_probe(compressor):
+    """Round 6: a full chunk that takes the stored fast path and whose probe span's BYTES are as good as uniform is stored by
+    k_lz77 itself -- no tokens, no byte counts, its other 24 KiB never fetched -- when the block type is the encoder's choice.
+    Same rule in the specification (probe_span_is_noise): streams, token counts and histograms agree; a noise head in front of
+    six-bit bytes stores the whole chunk, 7.9 bits of entropy per byte do not, a forced block type keeps the literals, a strip's
+    short last chunk is counted as before."""
+    rng = np.random.default_rng(77)
+    rnd = rng.integers(0, 256, 6 * CHUNK, dtype=np.uint8)
+    six = rng.integers(0, 64, 6 * CHUNK, dtype=np.uint8)
+    pw = np.ones(256)
+    pw[:64] = 0.3
+    skew = rng.choice(256, size=4 * CHUNK, p=pw / pw.sum()).astype(np.uint8)  # 7.88 bits per byte: a Huffman block of literals
+    head = np.concatenate([rnd[:8192], six[: CHUNK - 8192], six[:CHUNK], rnd[: CHUNK + 9000], six[:5000]])
+    tail = np.concatenate([six[:8192], rnd[: CHUNK - 8192], rnd[: 2 * CHUNK + 8200]])  # (the last chunk: 8200 bytes, not a full one)
+    for k, data in enumerate((rnd, head, tail, skew, np.concatenate([rnd[: 2 * CHUNK], synth.gen_text(3 * CHUNK, seed=5), rnd[: 3 * CHUNK]]))):
+        nch = (data.size + CHUNK - 1) // CHUNK
+        for effort in ("default", "thorough", "best", "recent_all"):
+            for bb in (0, 4 * CHUNK):
+                par = O.default_params(strip_bytes=bb, **EFFORT_PARAMS[effort])
+                got = np.frombuffer(compressor.compress(data, effort=effort, block_bytes=bb), np.uint8)
+                want, widx, wsub = O.compress_indexed(data, par)
+                assert np.array_equal(got, want), (k, effort, bb)
+                assert np.array_equal(compressor.last_subindex(), wsub), (k, effort, bb)
+                _roundtrip(got, data)
+        # token counts per chunk: none where the probe stored the chunk
+        compressor.compress(data, block_bytes=4 * CHUNK)
+        ntok = compressor.debug(_capi.DBG_NTOK, nch)
+        want_ntok = []
+        for s0 in range(0, data.size, 4 * CHUNK):
+            _, nt = O.strip_tokens(data[s0: s0 + 4 * CHUNK], O.default_params(strip_bytes=4 * CHUNK))
+            R = 512
+            sn = min(4 * CHUNK, data.size - s0)
+            want_ntok += [int(nt[c0 // R: (min(c0 + CHUNK, sn) + R - 1) // R].sum()) for c0 in range(0, sn, CHUNK)]
+        assert [int(x) for x in ntok] == want_ntok, (k, ntok, want_ntok)
+        for strategy in ("dynamic", "fixed"):  # a forced block type: the chunk's literals are coded
+            got = np.frombuffer(compressor.compress(data, strategy=strategy), np.uint8)
+            assert np.array_equal(got, O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy]))), (k, strategy)
+            _roundtrip(got, data)
+    compressor.compress(rnd, block_bytes=4 * CHUNK)
+    assert not compressor.debug(_capi.DBG_NTOK, 6).any()
+    compressor.compress(head, block_bytes=4 * CHUNK)
+    nt = compressor.debug(_capi.DBG_NTOK, 4)
+    assert nt[0] == 0 and nt[1] == CHUNK and nt[2] == 0 and nt[3] > 0, nt  # noise head: stored whole; six-bit chunk: literals
+    compressor.compress(skew, block_bytes=4 * CHUNK)
+    assert compressor.debug(_capi.DBG_NTOK, 4).all()
+    assert len(compressor.compress(six)) < 0.8 * six.size
+
+
 EFFORT_PARAMS = {"default": {}, "fast": {"depth": 1}, "fastest": {"depth": 1, "use_near": 0}, "thorough": {"stride2": 0, "step": 512},
                  "max": {"stride2": 0, "step": 512, "hash_bits": 12, "long_hash_bytes": 7},
                  "best": {"chain_depth": 8}, "ultra": {"chain_depth": 16}, "extreme": {"chain_depth": 32},

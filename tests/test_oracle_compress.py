@@ -397,6 +397,51 @@ def test_short_probe_behind_a_skipped_block():
     assert np.any(toks[(CHUNK + 8192) // R * R:] & 0x80000000)  # the rest of the block is searched again
 
 
+def test_stored_by_the_probe():
+    """Round 6 (probe_span_is_noise): a full block that takes the stored fast path and whose first SFO_SKIP_SPAN bytes are as
+    good as uniform has NO tokens, and the plan stores a block with bytes but no tokens; the rest of such a block is never
+    looked at.  Not with a forced block type, not for a strip's short last block, not for bytes a Huffman code shortens."""
+    rng = np.random.default_rng(12)
+    rnd = rng.integers(0, 256, 4 * CHUNK, dtype=np.uint8)
+    six = rng.integers(0, 64, 4 * CHUNK, dtype=np.uint8)
+    R = 512
+    par = O.default_params(strip_bytes=4 * CHUNK)
+    toks, nt = O.strip_tokens(rnd, par)
+    assert not nt.any()
+    s = O.compress(rnd, par)
+    assert s.size == rnd.size + 5 * 4
+    _check(s, rnd)
+    _, nt = O.strip_tokens(rnd, O.default_params(strip_bytes=4 * CHUNK, strategy=3))
+    assert nt.sum() == rnd.size  # a forced block type: every byte a literal
+    _check(O.compress(rnd, O.default_params(strategy=3)), rnd)
+    _, nt = O.strip_tokens(six, par)
+    assert nt.sum() == six.size  # six bits per byte: the fast path, but literals under a Huffman code
+    assert O.compress(six, par).size < 0.8 * six.size
+    # a noise head stores the whole block; the block behind it is probed, and coded
+    mix = np.concatenate([rnd[:8192], six[: CHUNK - 8192], six[:CHUNK], rnd[: CHUNK + 8200]])
+    _, nt = O.strip_tokens(mix, par)
+    per = [int(nt[c // R: (min(c + CHUNK, mix.size) + R - 1) // R].sum()) for c in range(0, mix.size, CHUNK)]
+    assert per == [0, CHUNK, 0, 8200], per
+    s = O.compress(mix, par)
+    _check(s, mix)
+    assert s.size < CHUNK + 5 + 0.8 * CHUNK + CHUNK + 5 + 8200 + 5 + 64
+    # the rule looks at the probe span only, through the plan's fixed-point entropy
+    pw = np.ones(256)
+    pw[:64] = 0.3
+    skew = rng.choice(256, size=2 * CHUNK, p=pw / pw.sum()).astype(np.uint8)
+    _, nt = O.strip_tokens(skew, par)
+    assert nt.sum() == skew.size
+    # ... and sfo_parse_chunk (a chunk as a strip of its own) decides alike
+    ln, ds = O.match_chunk(rnd[:CHUNK], O.default_params(strip_bytes=CHUNK))
+    _, nt1 = O.parse_chunk(rnd[:CHUNK], O.default_params(strip_bytes=CHUNK), ln, ds)
+    assert not nt1.any()
+    # the plan: bytes but no tokens -> stored
+    ll = np.zeros(286, np.uint32)
+    ll[256] = 1
+    pl = O.plan_chunk(ll, np.zeros(30, np.uint32), CHUNK, False, O.default_params())
+    assert pl.btype == 0 and pl.out_bytes == CHUNK + 5
+
+
 def test_plan_stores_all_but_incompressible_chunks_without_a_code():
     """sfo_plan_chunk, round 5: when the fixed block is no shorter than the stored one and the integer entropy estimate of
     the dynamic block comes within SFO_STORE_MARGIN (64) bytes of it, the chunk is stored and no code is built.  The rule
