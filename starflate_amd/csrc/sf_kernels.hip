@@ -1471,10 +1471,13 @@ __global__ __launch_bounds__(K1_THREADS, CHAIN ? K1_THREADS / 256 : 2 * K1_THREA
     // ---- end of a chunk: its counts and histogram go out, the histogram starts over ----
     if (chunk_done || rc == kRoundsPerChunk - 1 || r + 1 == nrounds) {
       __syncthreads();  // this round's histogram updates are complete
-      for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) {
-        hist_out[(uint64_t)chunk * kHistStride + idx] = s_hist[idx];
-        s_hist[idx] = (idx == 256) ? 1u : 0u;
-      }
+      // (a chunk stored by its probe -- taken in one go, no tokens -- has counted nothing and has no histogram: k_plan goes by
+      // its token count)
+      if (!(chunk_done && tot_tok == 0))
+        for (uint32_t idx = t; idx < kHistStride; idx += K1_THREADS) {
+          hist_out[(uint64_t)chunk * kHistStride + idx] = s_hist[idx];
+          s_hist[idx] = (idx == 256) ? 1u : 0u;
+        }
       if (t == 0) { ntok_out[chunk] = tot_tok; nitems_out[chunk] = tot_items | (skip ? kItemsSkipped : 0u); }
       const uint32_t covered = chunk_done ? kSubRegions : (rc + 1) * kRSubs;  // sub-index regions of the rounds that ran
       if (t < kSubRegions && t >= covered) rtok_out[chunk * kSubRegions + t] = tot_tok;
@@ -1839,7 +1842,7 @@ __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 
 // 280 on machine code (1.0 ms per GiB there) -- and with a chunk per lane 64 of them share every instruction.
 template <int MODE>
 __device__ __forceinline__ void plan_chunk(uint64_t n_total, uint32_t nchunks,
-                                           uint32_t* __restrict__ hist,
+                                           uint32_t* __restrict__ hist, const uint32_t* __restrict__ ntok,
                                            ChunkPlan* __restrict__ plan, ChunkCodes* __restrict__ codes,
                                            uint32_t strategy, uint32_t final_stream,
                                            uint64_t* __restrict__ stamps, PlanTree* __restrict__ ptree) {
@@ -1865,6 +1868,23 @@ __device__ __forceinline__ void plan_chunk(uint64_t n_total, uint32_t nchunks,
   [[maybe_unused]] PlanTree* const T = MODE ? ptree + chunk : nullptr;
   if constexpr (MODE == 2) {
     if (T->done) return;  // (uniform: stored without a code by the sorting pass)
+  }
+  // A chunk with bytes but NO tokens was stored by k_lz77's probe (round 6; probe_span_is_noise in the specification, only ever
+  // with strategy 0): it has no histogram -- k_lz77 wrote none -- and nothing to plan
+  if (MODE != 2 && strategy == 0 && n_raw != 0 && ntok[chunk] == 0) {  // (uniform)
+    ChunkCodes& C0 = codes[chunk];
+    for (uint32_t s0 = lane; s0 < 320; s0 += 64) C0.lens[s0] = 0;
+    if (lane == 0) {
+      C0.header[0] = fin ? 1u : 0u;
+      ChunkPlan P;
+      P.btype = 0;
+      P.out_bytes = n_raw + 5;
+      P.header_bits = 3;
+      P.body_bits = 0;
+      plan[chunk] = P;
+      if constexpr (MODE == 1) T->done = 1;
+    }
+    return;
   }
   // both halves of the chunk's histogram are requested at once (one memory round trip, not two in a row)
   uint32_t rawf[4] = {0, 0, 0, 0};
@@ -1915,8 +1935,7 @@ __device__ __forceinline__ void plan_chunk(uint64_t n_total, uint32_t nchunks,
     const uint32_t est_b = fin ? (est_bits + 7) / 8 : (est_bits + 3 + 7) / 8 + 4;
     const uint32_t fix_b = fin ? (fixbits + 7) / 8 : (fixbits + 3 + 7) / 8 + 4;
     const uint32_t sto_b = n_raw + 5;
-    // (... and a chunk with bytes but NO tokens was stored by k_lz77's probe: round 6, probe_span_is_noise in the specification)
-    if ((n_raw != 0 && tot == 1) || (fix_b >= sto_b && est_b + kStoreMargin >= sto_b)) {
+    if (fix_b >= sto_b && est_b + kStoreMargin >= sto_b) {
       ChunkCodes& C0 = codes[chunk];
       for (uint32_t s0 = lane; s0 < 320; s0 += 64) C0.lens[s0] = 0;  // (no code was built)
       if (lane == 0) {
@@ -2100,9 +2119,10 @@ __device__ __forceinline__ void plan_chunk(uint64_t n_total, uint32_t nchunks,
 
 #define SF_PLAN_KERNEL(NAME, MODE)                                                                                          \
   __global__ __launch_bounds__(64) void NAME(uint64_t n_total, uint32_t nchunks, uint32_t* __restrict__ hist,                 \
-                                             ChunkPlan* __restrict__ plan, ChunkCodes* __restrict__ codes, uint32_t strategy, \
-                                             uint32_t final_stream, uint64_t* __restrict__ stamps, PlanTree* __restrict__ ptree) { \
-    plan_chunk<MODE>(n_total, nchunks, hist, plan, codes, strategy, final_stream, stamps, ptree);                             \
+                                             const uint32_t* __restrict__ ntok, ChunkPlan* __restrict__ plan,                 \
+                                             ChunkCodes* __restrict__ codes, uint32_t strategy, uint32_t final_stream,        \
+                                             uint64_t* __restrict__ stamps, PlanTree* __restrict__ ptree) {                   \
+    plan_chunk<MODE>(n_total, nchunks, hist, ntok, plan, codes, strategy, final_stream, stamps, ptree);                       \
   }
 SF_PLAN_KERNEL(k_plan, 0)         // one launch (rounds 1-5; SFH_PLAN_FUSED=1)
 SF_PLAN_KERNEL(k_plan_sort, 1)    // K2a
@@ -2583,15 +2603,15 @@ hipError_t launch_lz77(const uint8_t* src, uint64_t n, uint32_t nchunks, const W
 hipError_t launch_plan(uint64_t n, uint32_t nchunks, const Workspace& ws, const Options& opt,
                        hipStream_t s) {
   if (opt.plan_fused || !ws.ptree) {
-    hipLaunchKernelGGL(k_plan, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.plan, ws.codes,
+    hipLaunchKernelGGL(k_plan, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.ntok, ws.plan, ws.codes,
                        opt.strategy, opt.final_stream, ws.stamps, (PlanTree*)nullptr);
     return hipGetLastError();
   }
   // sort (a wave per chunk) -> merge (a lane per chunk) -> finish (a wave per chunk)
-  hipLaunchKernelGGL(k_plan_sort, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.plan, ws.codes,
+  hipLaunchKernelGGL(k_plan_sort, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.ntok, ws.plan, ws.codes,
                      opt.strategy, opt.final_stream, (uint64_t*)nullptr, ws.ptree);
   hipLaunchKernelGGL(k_plan_merge, dim3((nchunks + 63) / 64), dim3(64), 0, s, nchunks, ws.ptree);
-  hipLaunchKernelGGL(k_plan_finish, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.plan, ws.codes,
+  hipLaunchKernelGGL(k_plan_finish, dim3(nchunks), dim3(64), 0, s, n, nchunks, ws.hist, ws.ntok, ws.plan, ws.codes,
                      opt.strategy, opt.final_stream, ws.stamps, ws.ptree);
   return hipGetLastError();
 }

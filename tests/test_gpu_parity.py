@@ -342,6 +342,10 @@ def test_stored_by_the_probe(compressor):
             sn = min(4 * CHUNK, data.size - s0)
             want_ntok += [int(nt[c0 // R: (min(c0 + CHUNK, sn) + R - 1) // R].sum()) for c0 in range(0, sn, CHUNK)]
         assert [int(x) for x in ntok] == want_ntok, (k, ntok, want_ntok)
+        plan = compressor.debug(_capi.DBG_PLAN, nch)  # (k_plan goes by the token count: such a chunk has no histogram)
+        for c in range(nch):
+            if want_ntok[c] == 0:
+                assert plan[c, 0] == 0 and plan[c, 1] == CHUNK + 5, (k, c, plan[c])
         for strategy in ("dynamic", "fixed"):  # a forced block type: the chunk's literals are coded
             got = np.frombuffer(compressor.compress(data, strategy=strategy), np.uint8)
             assert np.array_equal(got, O.compress(data, O.default_params(strategy=_capi.STRATEGY[strategy]))), (k, strategy)
