@@ -721,7 +721,8 @@ def test_fuzz_bit_exact_vs_oracle(compressor):
 
 def test_fuzz_stored_fast_path_switching(compressor):
     """Seeded fuzz of the stored fast path's switching (round 6: a skipped chunk's later rounds in one go, the window reloaded
-    from the input behind it, bank-private byte counts): inputs stitched from CHUNK-SCALE pieces -- noise (stored), six-bit
+    from the input behind it, bank-private byte counts; a chunk stored by its probe): inputs stitched from CHUNK-SCALE pieces -- noise
+    (stored), bytes a shade off uniform (either side of the probe's threshold), six-bit
     noise (the fast path taken, the chunk NOT stored: k_emit takes the items from the input), text, zeros, text right behind
     noise with matches into the noise's probe span -- so that the path switches on and off at every offset of a strip, with
     ragged tails; every effort family, the switch on and off, strips of 1..8 chunks.  Bit-exact against the specification,
@@ -732,9 +733,13 @@ def test_fuzz_stored_fast_path_switching(compressor):
     text = synth.gen_text(600_000, seed=91)
 
     def piece(n):
-        kind = int(rng.integers(0, 7))
+        kind = int(rng.integers(0, 9))
         if kind in (0, 1):
             return rng.integers(0, 256, n, dtype=np.uint8)
+        if kind in (7, 8):  # all but uniform: 7.8 .. 7.999 bits per byte, around the threshold of "stored by the probe"
+            pw = np.ones(256)
+            pw[rng.permutation(256)[: int(rng.integers(1, 128))]] = rng.uniform(0.05, 0.95)  # (the rule fires for a good half of these)
+            return rng.choice(256, size=n, p=pw / pw.sum()).astype(np.uint8)
         if kind == 2:
             return rng.integers(0, 64, n, dtype=np.uint8)  # high entropy for the probe, compressible for the plan
         if kind == 3:
