@@ -39,7 +39,7 @@ out = {"_meta": dict(source_stamp(), command=sys.argv[3], bytes_per_launch=256 <
                      note="sums over the command's dispatches of each kernel (pmc_dispatches); reads = 2 x FETCH_SIZE KiB (gfx950 wide-read correction), "
                           "writes = WRITE_SIZE KiB; SQ_* are wave-instruction / cycle counts as rocprofv3 reports them")}
 for k, v in d.items():
-    if "k_lz77" in k or k in ("k_plan", "k_emit", "k_scan"):
+    if "k_lz77" in k or k.startswith("k_plan") or k in ("k_emit", "k_scan"):
         n = max(v.get("pmc_dispatches", 1), 1)
         e = dict(v)
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
