@@ -138,6 +138,9 @@ typedef struct sfh_device_props {
   uint64_t total_memory;
 } sfh_device_props;
 int sfh_get_device_props(int device, sfh_device_props* out);
+/* Environment read by sfh_create (diagnostics and tests; none changes a stream): SFH_BATCH_CHUNKS=<n> (32 KiB chunks per batch of
+ * the compressor and the decoder, default 32768 = 1 GiB), SFH_PLAN_FUSED=1 (the code-length stage as ONE launch, k_plan, instead
+ * of k_plan_sort / k_plan_merge / k_plan_finish), SFH_INFLATE_SERIAL=1, SFH_K1_STAMPS=1, SFH_FORCE_ORDER_FAIL=1 (below). */
 int sfh_create(sfh_ctx** out, int device);
 /* The chain efforts (SFH_EFFORT_BEST / _ULTRA / _EXTREME) and SFH_EFFORT_RECENT insert 64 positions into their hash buckets
  * with ONE returning LDS atomic and rely on the LDS executing that wave-instruction's lanes in ascending order where they
